@@ -1,0 +1,264 @@
+"""ctypes bindings for the CPU oracle (oracle/qmri_oracle.h).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+bench.py.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+_SRCS = ["orc_masks.c", "orc_fft.c", "orc_operator.c", "orc_lsqr.c", "orc_net.c", "orc_admm.c",
+         "orc_dictmatch.c", "orc_util.c", "qmri_oracle.h", "orc_internal.h", "Makefile"]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc if the .so is missing or older than its sources."""
+    stale = force or not os.path.exists(_LIB)
+    if not stale:
+        t = os.path.getmtime(_LIB)
+        stale = any(os.path.getmtime(os.path.join(_HERE, s)) > t for s in _SRCS)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB
+
+
+class AdmmParams(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("iters", C.c_int), ("cg_tol", C.c_double), ("cg_maxit", C.c_int),
+                ("solver", C.c_int), ("multi_level", C.c_int), ("noise_std", C.c_double),
+                ("residual_noise", C.c_int), ("want_diag", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        vp, ip, dp, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
+        L.orc_spiral_mask.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, C.c_int]
+        L.orc_epi_mask.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, ip, ip, C.c_int]
+        L.orc_op_create.restype = vp
+        L.orc_op_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, ip]
+        L.orc_op_destroy.argtypes = [vp]
+        L.orc_op_m.argtypes = [vp]
+        L.orc_forward.argtypes = [vp, dp, dp]
+        L.orc_adjoint.argtypes = [vp, dp, dp]
+        L.orc_fft2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.orc_lsqr_xupdate.argtypes = [vp, dp, dp, C.c_double, C.c_double, C.c_int, dp,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), dp]
+        L.orc_direct_xupdate.argtypes = [vp, dp, dp, C.c_double, dp]
+        L.orc_net_create.restype = vp
+        L.orc_net_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, fp, C.c_size_t]
+        L.orc_net_destroy.argtypes = [vp]
+        L.orc_net_nparams.restype = C.c_size_t
+        L.orc_net_nparams.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.orc_net_forward.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_denoise.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_pnp_admm.argtypes = [vp, vp, dp, C.POINTER(AdmmParams), dp, dp, dp, dp, ip]
+        L.orc_dict_match.argtypes = [dp, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_double,
+                                     fp, fp, fp, ip, fp]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _cplx_in(a):
+    """complex128 array -> contiguous Fortran-order memory viewed as doubles."""
+    a = np.asarray(a, dtype=np.complex128)
+    return np.ascontiguousarray(a.ravel(order="F")).view(np.float64)
+
+
+def spiral_mask(N: int, S: int, T: int):
+    cap = S * T
+    fp_ = np.zeros(T + 1, np.int32)
+    k = np.zeros(cap, np.int32)
+    m = lib().orc_spiral_mask(N, S, T, _ip(fp_), _ip(k), cap)
+    assert m >= 0
+    return fp_, k[:m].copy()
+
+
+def epi_mask(N: int, M: int, pct: float, T: int):
+    step = int(np.floor(1.0 / pct + 0.5))
+    cap = (N // step) * M * T
+    fp_ = np.zeros(T + 1, np.int32)
+    k = np.zeros(max(cap, 1), np.int32)
+    m = lib().orc_epi_mask(N, M, float(pct), T, _ip(fp_), _ip(k), cap)
+    assert m >= 0
+    return fp_, k[:m].copy()
+
+
+class Operator:
+    """struct F of main_recon_tsmis_FFT.m:228-229 (forward / adjoint), CPU oracle."""
+
+    def __init__(self, N, M, V, frame_ptr, kidx):
+        V = np.asarray(V, dtype=np.float64)
+        self.N, self.M = int(N), int(M)
+        self.T, self.s = V.shape
+        self._V = np.ascontiguousarray(V.ravel(order="F"))
+        self._fp = np.ascontiguousarray(frame_ptr, dtype=np.int32)
+        self._k = np.ascontiguousarray(kidx, dtype=np.int32)
+        self.h = lib().orc_op_create(self.N, self.M, self.s, self.T, _dp(self._V), _ip(self._fp), _ip(self._k))
+        self.m = lib().orc_op_m(self.h)
+
+    def __del__(self):
+        try:
+            lib().orc_op_destroy(self.h)
+        except Exception:
+            pass
+
+    def forward(self, x):
+        xin = _cplx_in(x)
+        y = np.empty(2 * self.m, np.float64)
+        lib().orc_forward(self.h, _dp(xin), _dp(y))
+        return y.view(np.complex128)
+
+    def adjoint(self, y):
+        yin = _cplx_in(y)
+        x = np.empty(2 * self.N * self.M * self.s, np.float64)
+        lib().orc_adjoint(self.h, _dp(yin), _dp(x))
+        return x.view(np.complex128).reshape((self.N, self.M, self.s), order="F")
+
+    def lsqr(self, y, z, r, tol=1e-4, maxit=100, x0=None):
+        yin, zin = _cplx_in(y), _cplx_in(z)
+        x = _cplx_in(x0 if x0 is not None else np.zeros((self.N, self.M, self.s))).copy()
+        it, fl, rr = C.c_int(0), C.c_int(0), C.c_double(0)
+        lib().orc_lsqr_xupdate(self.h, _dp(yin), _dp(zin), float(r), float(tol), int(maxit), _dp(x),
+                               C.byref(it), C.byref(fl), C.byref(rr))
+        return x.view(np.complex128).reshape((self.N, self.M, self.s), order="F"), it.value, fl.value, rr.value
+
+    def direct(self, y, z, r):
+        yin, zin = _cplx_in(y), _cplx_in(z)
+        x = np.empty(2 * self.N * self.M * self.s, np.float64)
+        lib().orc_direct_xupdate(self.h, _dp(yin), _dp(zin), float(r), _dp(x))
+        return x.view(np.complex128).reshape((self.N, self.M, self.s), order="F")
+
+
+def fft2(x, sign=-1):
+    """Per-channel 2-D DFT of an [N,M,s] complex array (unnormalised forward, 1/(NM) inverse)."""
+    x = np.asarray(x, dtype=np.complex128)
+    N, M, s = x.shape
+    xin = _cplx_in(x)
+    out = np.empty_like(xin)
+    lib().orc_fft2(N, M, s, sign, _dp(xin), _dp(out))
+    return out.view(np.complex128).reshape((N, M, s), order="F")
+
+
+class Net:
+    """param.net of main_recon_tsmis_FFT.m:164, CPU oracle.  arch 0 = UNetRes, 1 = sequential conv stack."""
+
+    def __init__(self, weights, in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4, arch=0):
+        self.in_nc, self.out_nc, self.nc, self.nb, self.arch = in_nc, out_nc, tuple(nc), nb, arch
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        nc4 = (C.c_int * 4)(*self.nc)
+        self.h = lib().orc_net_create(arch, in_nc, out_nc, nc4, nb, _fp(w), w.size)
+        if not self.h:
+            raise ValueError("weight blob size does not match the architecture")
+
+    def __del__(self):
+        try:
+            lib().orc_net_destroy(self.h)
+        except Exception:
+            pass
+
+    def forward_f32(self, x):
+        """x: [H,W,C] or [H,W,C,B] float32 (MATLAB dims) -> [H,W,out_nc(,B)] float32."""
+        x = np.asarray(x, dtype=np.float32)
+        squeeze = x.ndim == 3
+        if squeeze:
+            x = x[..., None]
+        H, W, Cc, B = x.shape
+        xin = np.ascontiguousarray(x.ravel(order="F"))
+        out = np.empty(H * W * self.out_nc * B, np.float32)
+        lib().orc_net_forward(self.h, _fp(xin), H, W, B, _fp(out))
+        out = out.reshape((H, W, self.out_nc, B), order="F")
+        return out[..., 0] if squeeze else out
+
+    def denoise(self, x, residual_noise=False):
+        """denoiseImage_PnP_ADMM(x, net, true, residual_noise): double in, double out."""
+        x = np.asarray(x, dtype=np.float64)
+        squeeze = x.ndim == 3
+        if squeeze:
+            x = x[..., None]
+        H, W, Cc, B = x.shape
+        xin = np.ascontiguousarray(x.ravel(order="F"))
+        out = np.empty(H * W * self.out_nc * B, np.float64)
+        lib().orc_denoise(self.h, _dp(xin), H, W, Cc, B, int(residual_noise), _dp(out))
+        out = out.reshape((H, W, self.out_nc, B), order="F")
+        return out[..., 0] if squeeze else out
+
+
+def pnp_admm(op: Operator, net: Net, y, gamma=0.05, iters=100, cg_tol=1e-4, cg_maxit=100, solver="lsqr",
+             multi_level=False, noise_std=0.01, residual_noise=False, x0=None, gt=None, want_diag=False):
+    """x = PnP_ADMM(y, param)  (PnP_ADMM.m:1).  Returns (x, diag[iters,2] or None, lsqr_iters[iters])."""
+    p = AdmmParams(float(gamma), int(iters), float(cg_tol), int(cg_maxit), 0 if solver == "lsqr" else 1,
+                   int(multi_level), float(noise_std), int(residual_noise), int(want_diag))
+    yin = _cplx_in(y)
+    n = op.N * op.M * op.s
+    x = np.empty(2 * n, np.float64)
+    x0in = _cplx_in(x0) if x0 is not None else None
+    gtin = _cplx_in(gt) if gt is not None else None
+    diag = np.zeros(2 * iters, np.float64) if want_diag else None
+    li = np.zeros(iters, np.int32)
+    lib().orc_pnp_admm(op.h, net.h, _dp(yin), C.byref(p), _dp(x0in), _dp(gtin), _dp(x), _dp(diag), _ip(li))
+    xo = x.view(np.complex128).reshape((op.N, op.M, op.s), order="F")
+    return xo, (diag.reshape(iters, 2) if diag is not None else None), li
+
+
+def dict_match(X, D, normD, lut, block_size=1e9, want_mt=True, want_dm=True, want_xfit=False):
+    """out = mrf_dtm_cpu(dict, data, par)  (mrf_dtm_cpu.m:1).  X: [...,s] complex; returns dict of arrays."""
+    X = np.asarray(X, dtype=np.complex128)
+    s = X.shape[-1]
+    lead = X.shape[:-1]
+    npix = int(np.prod(lead))
+    xin = np.ascontiguousarray(X.reshape((npix, s), order="F").ravel(order="F")).view(np.float64)
+    D = np.asarray(D, dtype=np.float32)
+    K = D.shape[0]
+    lut = np.asarray(lut, dtype=np.float32)
+    Q = lut.shape[1]
+    Df = np.ascontiguousarray(D.ravel(order="F"))
+    lf = np.ascontiguousarray(lut.ravel(order="F"))
+    nd = np.ascontiguousarray(normD, dtype=np.float32)
+    qmap = np.empty(npix * Q, np.float32)
+    pd = np.empty(2 * npix, np.float32)
+    mt = np.empty(npix, np.float32) if want_mt else None
+    dm = np.empty(npix, np.int32) if want_dm else None
+    xf = np.empty(2 * npix * s, np.float32) if want_xfit else None
+    lib().orc_dict_match(_dp(xin), npix, s, _fp(Df), _fp(nd), _fp(lf), K, Q, float(block_size),
+                         _fp(qmap), _fp(pd), _fp(mt), _ip(dm), _fp(xf))
+    out = {"qmap": qmap.reshape(lead + (Q,), order="F"),
+           "pd": pd.view(np.complex64).reshape(lead, order="F")}
+    if mt is not None:
+        out["mt"] = mt.reshape(lead, order="F")
+    if dm is not None:
+        out["dm"] = dm.reshape(lead, order="F")
+    if xf is not None:
+        out["Xfit"] = xf.view(np.complex64).reshape(lead + (s,), order="F")
+    return out
+
+
+def num_threads() -> int:
+    return lib().orc_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(int(n))
