@@ -1,0 +1,172 @@
+/*
+ * qmri.h -- C ABI of libqmri.so: the MI355X (gfx950) PnP-ADMM MR-Fingerprinting reconstruction engine.
+ *
+ * This is the drop-in boundary for the hot path of ketanfatania/QMRI-PnP-Recon-POC.  The reference has no
+ * FFI of its own (pure MATLAB); its plugin surface for this path is a set of MATLAB values, and every entry
+ * point below states which of them it replaces (file:line relative to the reference root):
+ *
+ *   struct F with F.forward / F.adjoint          main_recon_tsmis_FFT.m:228-229   -> qmri_set_operator, qmri_forward, qmri_adjoint
+ *   P = setup_subsampling_spiralgrided(N,M,S,V)   setup_subsampling_spiralgrided.m:1-43 -> qmri_build_spiral
+ *   P = setup_subsampling_epi(N,M,pct,V)          setup_subsampling_epi.m:1-36     -> qmri_build_epi
+ *   param.net = @(x) denoiseImage_PnP_ADMM(...)   main_recon_tsmis_FFT.m:164, denoiseImage_PnP_ADMM.m:1-117 -> qmri_set_denoiser, qmri_denoise
+ *   x = PnP_ADMM(y, param)                        PnP_ADMM.m:1                      -> qmri_pnp_admm
+ *   out = mrf_dtm_cpu(dict, data, par)            mrf_dtm_cpu.m:1                   -> qmri_set_dictionary, qmri_dict_match
+ *
+ * Conventions (frozen):
+ *   - every function returns 0 on success or a negative qmri_status; the message is qmri_last_error(ctx).
+ *     Nothing throws across the boundary.
+ *   - arrays are column-major; complex numbers are interleaved (re,im) doubles -- MATLAB R2018a+
+ *     mxComplexDouble layout.  A MATLAB array X(h,w,c) is the C array [c][w][h].
+ *   - k-space indices crossing the ABI are 0-based column-major k = row + N*col; the measurement vector is
+ *     ordered frame-major, ascending k inside a frame (the row order of P in setup_subsampling_*.m:34-37).
+ *   - dm (dictionary index) is 1-based, as mrf_dtm_cpu.m:92 returns it.
+ *   - host-pointer entry points copy in/out around the call; *_dev entry points take device pointers that are
+ *     already resident in HBM (used by the benchmark and by callers that chain stages on the GPU).
+ *   - a context is owned by one host thread at a time (MATLAB calls from one thread); it is not locked.
+ *   - the library fails loudly (QMRI_ERR_HIP) when no gfx950 device is usable; there is no CPU fallback.
+ */
+#ifndef QMRI_H
+#define QMRI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMRI_ABI_VERSION 1
+
+typedef enum {
+    QMRI_OK = 0,
+    QMRI_ERR_INVALID_ARG = -1,   /* bad pointer / size / enum (MATLAB: validateattributes errors) */
+    QMRI_ERR_STATE = -2,         /* operator / denoiser / dictionary not set yet */
+    QMRI_ERR_HIP = -3,           /* HIP runtime error, or no usable GPU */
+    QMRI_ERR_UNSUPPORTED = -4,   /* size or architecture outside what the kernels implement */
+    QMRI_ERR_NOMEM = -5
+} qmri_status;
+
+typedef struct qmri_ctx qmri_ctx;
+
+/* ---- context -------------------------------------------------------------------------------------- */
+int qmri_abi_version(void);
+/* One context = one device, one HIP stream, all device buffers and workspaces. */
+int qmri_create(int device, qmri_ctx** out);
+int qmri_destroy(qmri_ctx* ctx);
+/* Message of the last failing call on this context (ctx == NULL: last failing qmri_create on this thread). */
+const char* qmri_last_error(const qmri_ctx* ctx);
+/* Launch on the caller's hipStream_t instead of the context's own stream (NULL restores it). */
+int qmri_set_stream(qmri_ctx* ctx, void* hip_stream);
+int qmri_synchronize(qmri_ctx* ctx);
+
+/* ---- forward-operator plugin: struct F, main_recon_tsmis_FFT.m:228-229 ------------------------------ */
+/* Mask builders (host, integer): replace setup_subsampling_spiralgrided.m:7-34 / setup_subsampling_epi.m:20-33.
+ * frame_ptr has T+1 entries, kidx holds up to cap entries; *m_out receives the total sample count.
+ * Returns QMRI_ERR_INVALID_ARG with *m_out set if cap is too small.  ctx may be NULL. */
+int qmri_build_spiral(qmri_ctx* ctx, int N, int S, int T, int32_t* frame_ptr, int32_t* kidx, int cap, int* m_out);
+int qmri_build_epi(qmri_ctx* ctx, int N, int M, double percentage, int T, int32_t* frame_ptr, int32_t* kidx,
+                   int cap, int* m_out);
+/* Defines P (setup_subsampling_*.m:36-42): V is T x s column-major real (main_recon_tsmis_FFT.m:129).
+ * max_batch = number of slices the context can hold at once (>= 1). */
+int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, const double* V, const int32_t* frame_ptr,
+                      const int32_t* kidx, int max_batch);
+int qmri_operator_m(const qmri_ctx* ctx, int* m_out);
+/* y = F.forward(x): x is N*M*s (complex if x_is_complex else real doubles), y is m complex. */
+int qmri_forward(qmri_ctx* ctx, const void* x, int x_is_complex, void* y);
+/* x = F.adjoint(y): y m complex -> x N*M*s complex. */
+int qmri_adjoint(qmri_ctx* ctx, const void* y, void* x);
+/* device-resident variants, `batch` slices stored back to back */
+int qmri_forward_dev(qmri_ctx* ctx, const void* d_x, void* d_y, int batch);
+int qmri_adjoint_dev(qmri_ctx* ctx, const void* d_y, void* d_x, int batch);
+/* The x-update alone: x = lsqr(@afun,[y; sqrt(r) z], tol, maxit, [], [], x)  (PnP_ADMM.m:102,153-171), or the
+ * closed-form minimiser when solver == QMRI_SOLVER_DIRECT.  Host buffers; x is in/out (warm start). */
+int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double r, double tol, int maxit, int solver,
+                 void* x, int32_t* iters_out, int32_t* flag_out);
+
+/* ---- denoiser plugin: param.net, main_recon_tsmis_FFT.m:138-171 ----------------------------------- */
+enum { QMRI_ARCH_UNETRES = 0, QMRI_ARCH_SEQ_CONV = 1 };
+typedef struct {
+    int32_t arch;            /* QMRI_ARCH_UNETRES: network_unet.py:68-117;  QMRI_ARCH_SEQ_CONV: conv3x3(+ReLU) stack */
+    int32_t in_nc;           /* 10 single_level, 11 multi_level (main_test.py:245-252) */
+    int32_t out_nc;          /* 10 */
+    int32_t nc[4];           /* {64,128,256,512}; SEQ_CONV uses nc[0] as width */
+    int32_t nb;              /* ResBlocks per stage (4); SEQ_CONV: number of conv layers */
+    int32_t residual_noise;  /* denoiseImage_PnP_ADMM.m:99-104: 1 = return input - CNN(input) */
+} qmri_net_desc;
+/* weights: flat fp32 in state_dict() order, Conv2d OIHW / ConvTranspose2d IOHW (what export_to_onnx,
+ * PyTorch_Denoiser/utils.py:444-485, serialises).  nbytes must equal 4 * qmri_net_nparams(desc). */
+size_t qmri_net_nparams(const qmri_net_desc* desc);
+int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const float* weights, size_t nbytes,
+                      int H, int W, int max_batch);
+/* out = denoiseImage_PnP_ADMM(in, net, true, residual_noise): in H x W x C x B doubles -> out H x W x out_nc x B. */
+int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C, int B, double* out);
+/* raw network forward on device fp32 tensors [B][C][W][H] (no casts); the dominant kernel chain */
+int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, float* d_out);
+
+/* ---- PnP-ADMM: x = PnP_ADMM(y, param), PnP_ADMM.m:1 ----------------------------------------------- */
+enum { QMRI_SOLVER_LSQR = 0, QMRI_SOLVER_DIRECT = 1 };
+enum { QMRI_DENOISER_SINGLE_LEVEL = 0, QMRI_DENOISER_MULTI_LEVEL = 1 };
+typedef struct {
+    double gamma;            /* param.gamma = sigma_squared/eta = 0.05   main_recon_tsmis_FFT.m:285-287 */
+    int32_t iters;           /* param.iter = 100                          :288 */
+    double cg_tol;           /* param.cg_tol = 1e-4                       :289 */
+    int32_t cg_maxit;        /* 100 (literal in PnP_ADMM.m:102) */
+    int32_t solver;          /* QMRI_SOLVER_LSQR reproduces the reference; DIRECT is the exact minimiser */
+    int32_t denoiser_type;   /* param.denoiser_type                       :167 */
+    double noise_std;        /* build_noise_map(0.01,...)                 :76,:170 */
+    int32_t want_diag;       /* the two per-iteration diagnostics of PnP_ADMM.m:106-109 */
+} qmri_admm_params;
+/* y: m complex.  x0: N*M*s complex or NULL (=> F.adjoint(y), main_recon_tsmis_FFT.m:292).  gt: N*M*s complex or
+ * NULL (param.gt_tsmi, only for the second diagnostic).  x_out: N*M*s complex (the LAST lsqr solution, as the
+ * reference returns).  diag_out: iters*2 doubles or NULL.  lsqr_iters_out: iters int32 or NULL. */
+int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_params* p, const void* x0, const void* gt,
+                  void* x_out, double* diag_out, int32_t* lsqr_iters_out);
+/* nslices independent slices, device-resident y / x0 / gt / x_out (slice-major); diag/lsqr outputs are host. */
+int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* p, const void* d_x0,
+                      const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out);
+
+/* ---- dictionary match: out = mrf_dtm_cpu(dict, data, par), mrf_dtm_cpu.m:1 --------------------------- */
+/* D: K x s column-major unit-norm atoms, normD: K, lut: K x Q column-major (dict.D / .normD / .lut, :8-12). */
+int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const float* D, const float* normD, const float* lut);
+/* X: Npix x s complex double column-major (data.X reshaped, :50).  qmap: Npix x Q (NaN->0, :136-141);
+ * pd: Npix complex single interleaved (:144-148); mt: Npix or NULL (:150-154); dm: Npix 1-based or NULL (:156-160). */
+int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm);
+int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt,
+                        int32_t* d_dm);
+
+/* ---- slice batches over several GPUs of one node (slices are independent; no collective) ------------ */
+typedef struct {
+    int32_t N, M, s, T;
+    const double* V;                 /* T x s */
+    const int32_t* frame_ptr;        /* T+1 */
+    const int32_t* kidx;             /* m */
+    const qmri_net_desc* net;
+    const float* weights;
+    size_t weights_nbytes;
+    int32_t K, Q;                    /* dictionary (K == 0: skip the match) */
+    const float* D;
+    const float* normD;
+    const float* lut;
+    qmri_admm_params admm;
+    int32_t slices_per_launch;       /* slices batched through the denoiser on one GPU (>= 1) */
+} qmri_problem;
+/* Y: nslices x m complex (host).  X_out: nslices x N*M*s complex.  qmap_out: nslices x Npix x Q or NULL,
+ * pd_out: nslices x Npix complex single or NULL.  One host thread + one context per device in devs[]. */
+int qmri_recon_batch(int ndev, const int* devs, int nslices, const qmri_problem* prob, const void* Y,
+                     void* X_out, float* qmap_out, float* pd_out, char* errbuf, size_t errbuf_len);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------------ */
+typedef struct {
+    double ms_xupdate, ms_denoiser, ms_elementwise, ms_diag, ms_match;   /* hipEvent time per stage */
+    double ms_conv3x3;          /* summed duration of the dominant kernel's launches */
+    int64_t n_conv3x3;          /* number of those launches */
+    int64_t lsqr_iters;         /* LSQR iterations executed */
+    int64_t admm_iters;
+} qmri_profile;
+int qmri_profile_enable(qmri_ctx* ctx, int level);   /* 0 off, 1 per stage, 2 also per conv3x3 launch */
+int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMRI_H */

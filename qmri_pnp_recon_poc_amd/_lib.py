@@ -1,0 +1,110 @@
+"""ctypes loader for libqmri.so (include/qmri.h).
+
+The product path has no CPU fallback: if the shared library is missing it is built with hipcc (which
+cross-compiles gfx950 without a GPU); if that fails, or a symbol is absent, loading raises.  Compute entry
+points additionally need a gfx950 device and fail with QMRI_ERR_HIP otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libqmri.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+# every symbol include/qmri.h declares (checked at load time and by tests/test_abi.py)
+SYMBOLS = [
+    "qmri_abi_version", "qmri_create", "qmri_destroy", "qmri_last_error", "qmri_set_stream", "qmri_synchronize",
+    "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
+    "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
+    "qmri_net_forward_dev", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
+    "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
+]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("in_nc", C.c_int32), ("out_nc", C.c_int32), ("nc", C.c_int32 * 4),
+                ("nb", C.c_int32), ("residual_noise", C.c_int32)]
+
+
+class AdmmParams(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("iters", C.c_int32), ("cg_tol", C.c_double), ("cg_maxit", C.c_int32),
+                ("solver", C.c_int32), ("denoiser_type", C.c_int32), ("noise_std", C.c_double), ("want_diag", C.c_int32)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("s", C.c_int32), ("T", C.c_int32),
+                ("V", C.POINTER(C.c_double)), ("frame_ptr", C.POINTER(C.c_int32)), ("kidx", C.POINTER(C.c_int32)),
+                ("net", C.POINTER(NetDesc)), ("weights", C.POINTER(C.c_float)), ("weights_nbytes", C.c_size_t),
+                ("K", C.c_int32), ("Q", C.c_int32), ("D", C.POINTER(C.c_float)), ("normD", C.POINTER(C.c_float)),
+                ("lut", C.POINTER(C.c_float)), ("admm", AdmmParams), ("slices_per_launch", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms_xupdate", C.c_double), ("ms_denoiser", C.c_double), ("ms_elementwise", C.c_double),
+                ("ms_diag", C.c_double), ("ms_match", C.c_double), ("ms_conv3x3", C.c_double),
+                ("n_conv3x3", C.c_int64), ("lsqr_iters", C.c_int64), ("admm_iters", C.c_int64)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libqmri.so for gfx950 with hipcc (in-tree, next to this file)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "qmri.h"))
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(LIB_PATH)
+        stale = any(os.path.getmtime(s) > t for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", CSRC, "-s", "-j4"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"libqmri.so lacks symbols declared in include/qmri.h: {missing}")
+    vp, ip, dp, fp, i = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int
+    L.qmri_abi_version.restype = i
+    L.qmri_create.argtypes = [i, C.POINTER(vp)]
+    L.qmri_destroy.argtypes = [vp]
+    L.qmri_last_error.restype = C.c_char_p
+    L.qmri_last_error.argtypes = [vp]
+    L.qmri_set_stream.argtypes = [vp, vp]
+    L.qmri_synchronize.argtypes = [vp]
+    L.qmri_build_spiral.argtypes = [vp, i, i, i, ip, ip, i, C.POINTER(i)]
+    L.qmri_build_epi.argtypes = [vp, i, i, C.c_double, i, ip, ip, i, C.POINTER(i)]
+    L.qmri_set_operator.argtypes = [vp, i, i, i, i, dp, ip, ip, i]
+    L.qmri_operator_m.argtypes = [vp, C.POINTER(i)]
+    L.qmri_forward.argtypes = [vp, vp, i, vp]
+    L.qmri_adjoint.argtypes = [vp, vp, vp]
+    L.qmri_forward_dev.argtypes = [vp, vp, vp, i]
+    L.qmri_adjoint_dev.argtypes = [vp, vp, vp, i]
+    L.qmri_xupdate.argtypes = [vp, vp, vp, C.c_double, C.c_double, i, i, vp, ip, ip]
+    L.qmri_net_nparams.restype = C.c_size_t
+    L.qmri_net_nparams.argtypes = [C.POINTER(NetDesc)]
+    L.qmri_set_denoiser.argtypes = [vp, C.POINTER(NetDesc), fp, C.c_size_t, i, i, i]
+    L.qmri_denoise.argtypes = [vp, dp, i, i, i, i, dp]
+    L.qmri_net_forward_dev.argtypes = [vp, vp, i, vp]
+    L.qmri_pnp_admm.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
+    L.qmri_pnp_admm_dev.argtypes = [vp, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
+    L.qmri_set_dictionary.argtypes = [vp, i, i, i, fp, fp, fp]
+    L.qmri_dict_match.argtypes = [vp, vp, i, fp, fp, fp, ip]
+    L.qmri_dict_match_dev.argtypes = [vp, vp, i, vp, vp, vp, vp]
+    L.qmri_recon_batch.argtypes = [i, C.POINTER(i), i, C.POINTER(Problem), vp, vp, fp, fp, C.c_char_p, C.c_size_t]
+    L.qmri_profile_enable.argtypes = [vp, i]
+    L.qmri_profile_get.argtypes = [vp, C.POINTER(Profile), i]
+    if L.qmri_abi_version() != 1:
+        raise ImportError("libqmri.so ABI version mismatch")
+    _lib = L
+    return L

@@ -1,0 +1,505 @@
+// api_core.cpp -- context, error reporting, mask builders and the forward-operator plugin of libqmri.so.
+//
+// Replaces (reference file:line): struct F main_recon_tsmis_FFT.m:228-229; setup_subsampling_spiralgrided.m:1-43;
+// setup_subsampling_epi.m:1-36; the lsqr x-update call site PnP_ADMM.m:102 with afun PnP_ADMM.m:153-171.
+#include "qmri_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+static thread_local std::string g_create_err;
+
+void qmri_set_error(qmri_ctx* ctx, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+}
+
+extern "C" int qmri_abi_version(void) { return QMRI_ABI_VERSION; }
+
+extern "C" const char* qmri_last_error(const qmri_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int qmri_create(int device, qmri_ctx** out) {
+    if (!out) { qmri_set_error(nullptr, "qmri_create: out is NULL"); return QMRI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        qmri_set_error(nullptr, "no HIP device available (%s); libqmri has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return QMRI_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        qmri_set_error(nullptr, "device %d out of range (0..%d)", device, ndev - 1);
+        return QMRI_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        qmri_set_error(nullptr, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        return QMRI_ERR_HIP;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        qmri_set_error(nullptr, "device %d is %s; libqmri is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return QMRI_ERR_UNSUPPORTED;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        qmri_set_error(nullptr, "hipSetDevice failed: %s", hipGetErrorString(e));
+        return QMRI_ERR_HIP;
+    }
+    qmri_ctx* ctx = new (std::nothrow) qmri_ctx();
+    if (!ctx) { qmri_set_error(nullptr, "out of host memory"); return QMRI_ERR_NOMEM; }
+    ctx->device = device;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        qmri_set_error(nullptr, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return QMRI_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (auto& ev : ctx->ev) hipEventCreate(&ev);
+    *out = ctx;
+    return QMRI_OK;
+}
+
+static void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+void qmri_free_operator(qmri_ctx* ctx) {
+    OpHost& o = ctx->op;
+    void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
+                     o.ls.st, o.ls.pu[0], o.ls.pu[1], o.ls.pv, o.ls.pz, o.ls.ut, o.ls.ub, o.ls.v, o.ls.d, o.ls.yk,
+                     o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
+    for (void* p : ptrs) free_dev(p);
+    if (o.h_state) (void)hipHostFree(o.h_state);
+    o = OpHost();
+}
+
+void qmri_free_net(qmri_ctx* ctx);
+void qmri_free_dict(qmri_ctx* ctx);
+
+extern "C" int qmri_destroy(qmri_ctx* ctx) {
+    if (!ctx) return QMRI_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    qmri_free_operator(ctx);
+    qmri_free_net(ctx);
+    qmri_free_dict(ctx);
+    for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_set_stream(qmri_ctx* ctx, void* hip_stream) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_synchronize(qmri_ctx* ctx) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mask builders (host, integer index math)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int qmri_build_spiral(qmri_ctx* ctx, int N, int S, int T, int32_t* frame_ptr, int32_t* kidx, int cap, int* m_out) {
+    QMRI_CHECK_ARG(ctx, N > 0 && S > 1 && T > 0 && frame_ptr && (kidx || cap == 0) && m_out, "qmri_build_spiral arguments");
+    // setup_subsampling_spiralgrided.m:7-34.  8-turn exponential spiral sampled at S points, rotated 7.5 deg per
+    // frame, rounded onto the N x N grid (MATLAB round = half away from zero), clamped, fftshift-ed; the sample
+    // order inside a frame is find()'s ascending column-major order.
+    const double pi = 3.14159265358979323846;
+    const double delta = pi / 180.0 * 7.5;
+    std::vector<double> theta(S), rad(S);
+    double lo = HUGE_VAL, hi = -HUGE_VAL;
+    for (int j = 0; j < S; ++j) {
+        const double t = (j == S - 1) ? 2.0 * pi : (double)j * (2.0 * pi) / (double)(S - 1);   // linspace(0,2*pi,S)
+        theta[j] = 8.0 * t;
+        rad[j] = std::pow(1.05, theta[j]);
+        lo = std::min(lo, rad[j]);
+        hi = std::max(hi, rad[j]);
+    }
+    for (double& r : rad) r = (r - lo) / (hi - lo);
+    std::vector<uint8_t> grid((size_t)N * N);
+    const int half = N / 2;
+    long m = 0;
+    for (int f = 0; f < T; ++f) {
+        frame_ptr[f] = (int32_t)m;
+        std::fill(grid.begin(), grid.end(), 0);
+        const double rot = (double)f * delta;
+        for (int j = 0; j < S; ++j) {
+            double gx = std::round(rad[j] * std::cos(theta[j] + rot) * N / 2.0) + N / 2.0 + 1.0;
+            double gy = std::round(rad[j] * std::sin(theta[j] + rot) * N / 2.0) + N / 2.0 + 1.0;
+            gx = std::min(gx, (double)N);
+            gy = std::min(gy, (double)N);
+            const int r = ((int)gx - 1 + half) % N, c = ((int)gy - 1 + half) % N;     // fftshift
+            grid[(size_t)c * N + r] = 1;
+        }
+        for (int k = 0; k < N * N; ++k)
+            if (grid[k]) {
+                if (m < cap) kidx[m] = k;
+                ++m;
+            }
+    }
+    frame_ptr[T] = (int32_t)m;
+    *m_out = (int)m;
+    if (m > cap) { qmri_set_error(ctx, "kidx capacity %d too small, need %ld", cap, m); return QMRI_ERR_INVALID_ARG; }
+    return QMRI_OK;
+}
+
+extern "C" int qmri_build_epi(qmri_ctx* ctx, int N, int M, double percentage, int T, int32_t* frame_ptr, int32_t* kidx,
+                              int cap, int* m_out) {
+    QMRI_CHECK_ARG(ctx, N > 0 && M > 0 && T > 0 && percentage > 0 && frame_ptr && (kidx || cap == 0) && m_out,
+                   "qmri_build_epi arguments");
+    // setup_subsampling_epi.m:20-33.  Comb of floor(N/step) k-rows, step = round(1/percentage), shifted down by one
+    // row (cyclically) before every frame including the first; whole rows are sampled; no fftshift.
+    const int step = (int)std::round(1.0 / percentage);
+    const int nlines = N / step;
+    std::vector<int> rows;
+    for (int r = 0; r < step * nlines; r += step) rows.push_back(r);
+    long m = 0;
+    for (int f = 0; f < T; ++f) {
+        frame_ptr[f] = (int32_t)m;
+        for (int& r : rows) r = (r + 1) % N;
+        std::vector<int> sorted(rows);
+        std::sort(sorted.begin(), sorted.end());
+        for (int c = 0; c < M; ++c)
+            for (int r : sorted) {
+                if (m < cap) kidx[m] = r + N * c;
+                ++m;
+            }
+    }
+    frame_ptr[T] = (int32_t)m;
+    *m_out = (int)m;
+    if (m > cap) { qmri_set_error(ctx, "kidx capacity %d too small, need %ld", cap, m); return QMRI_ERR_INVALID_ARG; }
+    return QMRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// operator
+// ---------------------------------------------------------------------------------------------------
+OpDev qmri_opdev(const qmri_ctx* ctx) {
+    const OpHost& o = ctx->op;
+    OpDev d;
+    d.N = o.N; d.M = o.M; d.s = o.s; d.T = o.T; d.m = o.m;
+    d.Vt = o.d_Vt; d.ent = o.d_ent; d.perm = o.d_perm; d.kptr = o.d_kptr; d.tw = o.d_tw;
+    d.kslot = o.d_kslot; d.ginv = o.d_ginv;
+    return d;
+}
+
+template <typename T> static int dev_alloc(qmri_ctx* ctx, T** p, size_t count) {
+    *p = nullptr;
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+    return QMRI_OK;
+}
+
+extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, const double* V, const int32_t* frame_ptr,
+                                 const int32_t* kidx, int max_batch) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    QMRI_CHECK_ARG(ctx, V && frame_ptr && kidx, "V / frame_ptr / kidx must not be NULL");
+    QMRI_CHECK_ARG(ctx, N > 0 && M > 0 && s > 0 && T > 0 && max_batch > 0, "N, M, s, T, max_batch must be positive");
+    if (N != M || !dc_size_supported(N)) {
+        qmri_set_error(ctx, "grid %d x %d unsupported: the FFT kernels implement square grids of 32, 64, 128, 224, 256 "
+                            "(the reference's spiral mask assumes N == M, setup_subsampling_spiralgrided.m:28-31)", N, M);
+        return QMRI_ERR_UNSUPPORTED;
+    }
+    if (s > 12 || T > 65535 || M > 65535) { qmri_set_error(ctx, "s <= 12 and T, M <= 65535 required (got s=%d T=%d)", s, T); return QMRI_ERR_UNSUPPORTED; }
+    QMRI_CHECK_ARG(ctx, frame_ptr[0] == 0, "frame_ptr[0] must be 0");
+    const int m = frame_ptr[T];
+    QMRI_CHECK_ARG(ctx, m > 0, "empty measurement set");
+    for (int t = 0; t < T; ++t) QMRI_CHECK_ARG(ctx, frame_ptr[t + 1] >= frame_ptr[t], "frame_ptr must be non-decreasing");
+    for (int i = 0; i < m; ++i) QMRI_CHECK_ARG(ctx, kidx[i] >= 0 && kidx[i] < N * M, "kidx out of range");
+
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    qmri_free_operator(ctx);
+    OpHost& o = ctx->op;
+    o.N = N; o.M = M; o.s = s; o.T = T; o.m = m; o.maxB = max_batch;
+    o.V.assign(V, V + (size_t)T * s);
+    o.frame_ptr.assign(frame_ptr, frame_ptr + T + 1);
+    o.kidx.assign(kidx, kidx + m);
+
+    // k-sorted sample list: primary kh = k % N (k-space row), secondary kw = k / N, tertiary frame
+    const int NM = N * M;
+    o.kptr_h.assign(NM + 1, 0);
+    std::vector<int32_t> frame_of(m);
+    for (int t = 0; t < T; ++t)
+        for (int i = frame_ptr[t]; i < frame_ptr[t + 1]; ++i) frame_of[i] = t;
+    auto kprime = [&](int k) { return (k % N) * M + (k / N); };
+    for (int i = 0; i < m; ++i) o.kptr_h[kprime(kidx[i]) + 1]++;
+    for (int k = 0; k < NM; ++k) o.kptr_h[k + 1] += o.kptr_h[k];
+    std::vector<int32_t> fill(o.kptr_h.begin(), o.kptr_h.end() - 1);
+    o.ent_h.resize(m);
+    o.perm_h.resize(m);
+    for (int i = 0; i < m; ++i) {                    // ascending i == ascending frame inside each k
+        const int kp = kprime(kidx[i]);
+        const int e = fill[kp]++;
+        o.ent_h[e].kw = (uint16_t)(kidx[i] / N);
+        o.ent_h[e].t = (uint16_t)frame_of[i];
+        o.perm_h[e] = i;
+    }
+    std::vector<int32_t> kslot(NM, -1);
+    o.nsampled = 0;
+    for (int kp = 0; kp < NM; ++kp)
+        if (o.kptr_h[kp + 1] > o.kptr_h[kp]) kslot[kp] = o.nsampled++;
+    std::vector<double> Vt((size_t)T * s);
+    for (int t = 0; t < T; ++t)
+        for (int c = 0; c < s; ++c) Vt[(size_t)t * s + c] = V[t + (size_t)T * c];
+    std::vector<double2> tw(N);
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < N; ++j) { const double a = 2.0 * pi * j / N; tw[j] = make_double2(std::cos(a), -std::sin(a)); }
+
+    const size_t n = (size_t)N * M * s, B = (size_t)max_batch;
+    QMRI_TRY(dev_alloc(ctx, &o.d_Vt, Vt.size()));
+    QMRI_TRY(dev_alloc(ctx, &o.d_ent, (size_t)m));
+    QMRI_TRY(dev_alloc(ctx, &o.d_perm, (size_t)m));
+    QMRI_TRY(dev_alloc(ctx, &o.d_kptr, (size_t)NM + 1));
+    QMRI_TRY(dev_alloc(ctx, &o.d_tw, (size_t)N));
+    QMRI_TRY(dev_alloc(ctx, &o.d_kslot, (size_t)NM));
+    QMRI_TRY(dev_alloc(ctx, &o.d_ginv, (size_t)o.nsampled * s * s));
+    QMRI_HIP(ctx, hipMemcpy(o.d_Vt, Vt.data(), Vt.size() * sizeof(double), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_ent, o.ent_h.data(), (size_t)m * sizeof(KEntry), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_perm, o.perm_h.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_kptr, o.kptr_h.data(), ((size_t)NM + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_tw, tw.data(), (size_t)N * sizeof(double2), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_kslot, kslot.data(), (size_t)NM * sizeof(int32_t), hipMemcpyHostToDevice));
+
+    LsqrDev& ls = o.ls;
+    ls.nblk_h = dc_nblk_h(N, M, s);
+    ls.npu = ls.nblk_h + N;
+    ls.nblk_z = 256;
+    QMRI_TRY(dev_alloc(ctx, &o.d_tmp, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_xa, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_xb, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_ya, B * (size_t)m));
+    QMRI_TRY(dev_alloc(ctx, &ls.st, B));
+    QMRI_TRY(dev_alloc(ctx, &ls.pu[0], B * ls.npu));
+    QMRI_TRY(dev_alloc(ctx, &ls.pu[1], B * ls.npu));
+    QMRI_TRY(dev_alloc(ctx, &ls.pv, B * ls.nblk_h));
+    QMRI_TRY(dev_alloc(ctx, &ls.pz, B * ls.nblk_z));
+    QMRI_TRY(dev_alloc(ctx, &ls.ut, B * (size_t)m));
+    QMRI_TRY(dev_alloc(ctx, &ls.ub, B * n));
+    QMRI_TRY(dev_alloc(ctx, &ls.v, B * n));
+    QMRI_TRY(dev_alloc(ctx, &ls.d, B * n));
+    QMRI_TRY(dev_alloc(ctx, &ls.yk, B * (size_t)m));
+    QMRI_TRY(dev_alloc(ctx, &o.d_x, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_u, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_vv, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_z, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_chat, B * n));
+    QMRI_TRY(dev_alloc(ctx, &o.d_mm, B * ls.nblk_z * 2));
+    QMRI_TRY(dev_alloc(ctx, &o.d_norm, B * 2));
+    QMRI_TRY(dev_alloc(ctx, &o.d_pd, B * ((size_t)N + 2 * ls.nblk_z)));
+    QMRI_HIP(ctx, hipMemset(ls.st, 0, B * sizeof(LsqrState)));
+    QMRI_HIP(ctx, hipHostMalloc((void**)&o.h_state, B * sizeof(LsqrState), hipHostMallocDefault));
+    o.ginv_r = -1.0;
+    o.ready = true;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_operator_m(const qmri_ctx* ctx, int* m_out) {
+    if (!ctx || !m_out) return QMRI_ERR_INVALID_ARG;
+    if (!ctx->op.ready) return QMRI_ERR_STATE;
+    *m_out = ctx->op.m;
+    return QMRI_OK;
+}
+
+#define REQUIRE_OP(ctx)                                                                   \
+    do {                                                                                  \
+        if (!(ctx)) return QMRI_ERR_INVALID_ARG;                                          \
+        QMRI_HIP((ctx), hipSetDevice((ctx)->device));                                     \
+        if (!(ctx)->op.ready) { qmri_set_error((ctx), "operator not set: call qmri_set_operator first"); return QMRI_ERR_STATE; } \
+    } while (0)
+
+extern "C" int qmri_forward_dev(qmri_ctx* ctx, const void* d_x, void* d_y, int batch) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, d_x && d_y && batch >= 1 && batch <= ctx->op.maxB, "qmri_forward_dev arguments / batch > max_batch");
+    return dc_launch_fwd(ctx, qmri_opdev(ctx), ctx->op.ls, DC_PLAIN, batch, (const double2*)d_x, nullptr, ctx->op.d_tmp,
+                         (double2*)d_y, nullptr);
+}
+
+extern "C" int qmri_adjoint_dev(qmri_ctx* ctx, const void* d_y, void* d_x, int batch) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, d_x && d_y && batch >= 1 && batch <= ctx->op.maxB, "qmri_adjoint_dev arguments / batch > max_batch");
+    return dc_launch_adj(ctx, qmri_opdev(ctx), ctx->op.ls, DC_PLAIN, batch, (const double2*)d_y, ctx->op.d_tmp, (double2*)d_x,
+                         nullptr);
+}
+
+extern "C" int qmri_forward(qmri_ctx* ctx, const void* x, int x_is_complex, void* y) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, x && y, "x / y must not be NULL");
+    OpHost& o = ctx->op;
+    const size_t n = (size_t)o.N * o.M * o.s;
+    if (x_is_complex) {
+        QMRI_HIP(ctx, hipMemcpyAsync(o.d_xa, x, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        QMRI_HIP(ctx, hipMemcpyAsync(o.d_xb, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        QMRI_TRY(ew_launch_real_to_complex(ctx, n, (const double*)o.d_xb, o.d_xa));
+    }
+    QMRI_TRY(qmri_forward_dev(ctx, o.d_xa, o.d_ya, 1));
+    QMRI_HIP(ctx, hipMemcpyAsync(y, o.d_ya, (size_t)o.m * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+extern "C" int qmri_adjoint(qmri_ctx* ctx, const void* y, void* x) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, x && y, "x / y must not be NULL");
+    OpHost& o = ctx->op;
+    const size_t n = (size_t)o.N * o.M * o.s;
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_ya, y, (size_t)o.m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    QMRI_TRY(qmri_adjoint_dev(ctx, o.d_ya, o.d_xa, 1));
+    QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_xa, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// x-update drivers
+// ---------------------------------------------------------------------------------------------------
+// (G_k + r I)^-1 for every sampled k, G_k = sum_{t: k in Omega_t} V(t,:)' V(t,:)   
+int qmri_prepare_direct(qmri_ctx* ctx, double r) {
+    OpHost& o = ctx->op;
+    if (o.ginv_r == r) return QMRI_OK;
+    const int s = o.s, NM = o.N * o.M, T = o.T;
+    std::vector<double> ginv((size_t)o.nsampled * s * s);
+    std::vector<double> G(s * s), Li(s * s);
+    int slot = 0;
+    for (int kp = 0; kp < NM; ++kp) {
+        const int e0 = o.kptr_h[kp], e1 = o.kptr_h[kp + 1];
+        if (e1 == e0) continue;
+        std::fill(G.begin(), G.end(), 0.0);
+        for (int e = e0; e < e1; ++e) {
+            const int t = o.ent_h[e].t;
+            for (int a = 0; a < s; ++a)
+                for (int b = 0; b < s; ++b) G[a * s + b] += o.V[t + (size_t)T * a] * o.V[t + (size_t)T * b];
+        }
+        for (int a = 0; a < s; ++a) G[a * s + a] += r;
+        // Cholesky G = L L^T, then inverse = L^-T L^-1
+        for (int j = 0; j < s; ++j) {
+            double d = G[j * s + j];
+            for (int k = 0; k < j; ++k) d -= G[j * s + k] * G[j * s + k];
+            const double ljj = std::sqrt(d);
+            G[j * s + j] = ljj;
+            for (int i = j + 1; i < s; ++i) {
+                double v = G[i * s + j];
+                for (int k = 0; k < j; ++k) v -= G[i * s + k] * G[j * s + k];
+                G[i * s + j] = v / ljj;
+            }
+        }
+        std::fill(Li.begin(), Li.end(), 0.0);
+        for (int c = 0; c < s; ++c) {                 // Li = L^-1 (lower), column by column
+            for (int i = c; i < s; ++i) {
+                double v = (i == c) ? 1.0 : 0.0;
+                for (int k = c; k < i; ++k) v -= G[i * s + k] * Li[k * s + c];
+                Li[i * s + c] = v / G[i * s + i];
+            }
+        }
+        double* out = ginv.data() + (size_t)slot * s * s;
+        for (int a = 0; a < s; ++a)
+            for (int b = 0; b < s; ++b) {
+                double v = 0.0;
+                for (int k = std::max(a, b); k < s; ++k) v += Li[k * s + a] * Li[k * s + b];
+                out[a * s + b] = v;
+            }
+        ++slot;
+    }
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_ginv, ginv.data(), ginv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    o.ginv_r = r;
+    return QMRI_OK;
+}
+
+// LSQR on B slices; requires ls.yk / ny2 (dc_launch_sort_y) and ls.pz (dc_launch_prepare_z) to be current.
+int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
+                  int32_t* iters_out, int32_t* flag_out) {
+    OpHost& o = ctx->op;
+    const OpDev op = qmri_opdev(ctx);
+    LsqrDev ls = o.ls;
+    ls.sr = std::sqrt(r); ls.tol = tol; ls.maxit = maxit; ls.ii = 0;
+    QMRI_TRY(dc_launch_fwd(ctx, op, ls, DC_LSQR_INIT, B, d_x, d_z, o.d_tmp, nullptr, nullptr));
+    QMRI_TRY(dc_launch_adj(ctx, op, ls, DC_LSQR_INIT, B, nullptr, o.d_tmp, nullptr, nullptr));
+    int launched = 0;
+    int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
+    bool all_done = false;
+    while (launched < maxit && !all_done) {
+        const int nthis = std::min(chunk, maxit - launched);
+        for (int k = 0; k < nthis; ++k) {
+            ls.ii = launched + k + 1;
+            QMRI_TRY(dc_launch_fwd(ctx, op, ls, DC_LSQR_ITER, B, nullptr, nullptr, o.d_tmp, nullptr, nullptr));
+            QMRI_TRY(dc_launch_adj(ctx, op, ls, DC_LSQR_ITER, B, nullptr, o.d_tmp, nullptr, d_x));
+        }
+        launched += nthis;
+        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ls.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        all_done = true;
+        for (int b = 0; b < B; ++b) all_done = all_done && o.h_state[b].done;
+        chunk = 2;
+    }
+    if (maxit <= 0) {
+        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ls.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int worst = 0;
+    for (int b = 0; b < B; ++b) {
+        const int it = o.h_state[b].done ? o.h_state[b].iter : maxit;
+        if (iters_out) iters_out[b] = it;
+        if (flag_out) flag_out[b] = o.h_state[b].done ? o.h_state[b].flag : 1;
+        worst = std::max(worst, it);
+        ctx->prof.lsqr_iters += it;
+    }
+    ctx->lsqr_pred = worst + 2;      // convergence is detected one iteration after the last x update; +1 margin
+    return QMRI_OK;
+}
+
+extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double r, double tol, int maxit, int solver,
+                            void* x, int32_t* iters_out, int32_t* flag_out) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, y && z && x && r > 0 && maxit >= 0, "qmri_xupdate arguments");
+    OpHost& o = ctx->op;
+    const OpDev op = qmri_opdev(ctx);
+    const size_t n = (size_t)o.N * o.M * o.s;
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_ya, y, (size_t)o.m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_z, z, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_x, x, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    if (solver == QMRI_SOLVER_LSQR) {
+        QMRI_TRY(dc_launch_sort_y(ctx, op, o.ls, 1, o.d_ya));
+        // ||z||^2 partials: reuse prepare_z with u = 0
+        QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, n * sizeof(double2), ctx->stream));
+        QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, 1, o.d_z, o.d_u, o.d_vv));
+        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out));
+    } else if (solver == QMRI_SOLVER_DIRECT) {
+        QMRI_TRY(qmri_prepare_direct(ctx, r));
+        QMRI_TRY(dc_launch_adj(ctx, op, o.ls, DC_PLAIN, 1, o.d_ya, o.d_tmp, o.d_xa, nullptr));
+        QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, 1, o.d_xa, nullptr, o.d_tmp, o.d_chat, nullptr));
+        QMRI_TRY(dc_launch_direct(ctx, qmri_opdev(ctx), 1, o.d_z, o.d_chat, r, o.d_tmp, o.d_x));
+        if (iters_out) *iters_out = 0;
+        if (flag_out) *flag_out = 0;
+    } else {
+        qmri_set_error(ctx, "unknown solver %d", solver);
+        return QMRI_ERR_INVALID_ARG;
+    }
+    QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_x, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+extern "C" int qmri_profile_enable(qmri_ctx* ctx, int level) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    ctx->prof_level = level;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset) {
+    if (!ctx || !out) return QMRI_ERR_INVALID_ARG;
+    *out = ctx->prof;
+    if (reset) ctx->prof = qmri_profile();
+    return QMRI_OK;
+}

@@ -1,0 +1,497 @@
+// api_net.cpp -- denoiser plugin (param.net), PnP-ADMM driver, dictionary match and slice batching of libqmri.so.
+//
+// Replaces (reference file:line): param.net main_recon_tsmis_FFT.m:138-171 + denoiseImage_PnP_ADMM.m:1-117;
+// PnP_ADMM.m:1-148; mrf_dtm_cpu.m:1-166.  UNetRes layer order follows state_dict() of network_unet.py:68-117.
+#include "qmri_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+void qmri_free_operator(qmri_ctx* ctx);
+int qmri_prepare_direct(qmri_ctx* ctx, double r);
+int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
+                  int32_t* iters_out, int32_t* flag_out);
+
+// ---------------------------------------------------------------------------------------------------
+// denoiser
+// ---------------------------------------------------------------------------------------------------
+extern "C" size_t qmri_net_nparams(const qmri_net_desc* d) {
+    if (!d) return 0;
+    size_t n = 0;
+    if (d->arch == QMRI_ARCH_UNETRES) {
+        const int32_t* nc = d->nc;
+        n += (size_t)nc[0] * d->in_nc * 9;
+        for (int l = 0; l < 3; ++l) n += (size_t)2 * d->nb * nc[l] * nc[l] * 9 + (size_t)nc[l + 1] * nc[l] * 4;
+        n += (size_t)2 * d->nb * nc[3] * nc[3] * 9;
+        for (int l = 3; l > 0; --l) n += (size_t)nc[l] * nc[l - 1] * 4 + (size_t)2 * d->nb * nc[l - 1] * nc[l - 1] * 9;
+        n += (size_t)d->out_nc * nc[0] * 9;
+    } else if (d->arch == QMRI_ARCH_SEQ_CONV) {
+        if (d->nb == 1) return (size_t)d->out_nc * d->in_nc * 9;
+        n = (size_t)d->nc[0] * d->in_nc * 9 + (size_t)(d->nb - 2) * d->nc[0] * d->nc[0] * 9 + (size_t)d->out_nc * d->nc[0] * 9;
+    }
+    return n;
+}
+
+void qmri_free_net(qmri_ctx* ctx) {
+    NetPlan& p = ctx->net;
+    for (ConvLayer& L : p.layers) if (L.wp) (void)hipFree(L.wp);
+    float* bufs[] = { p.x1, p.x2, p.x3, p.x4, p.a, p.t1, p.in32, p.out32 };
+    for (float* b : bufs) if (b) (void)hipFree(b);
+    p = NetPlan();
+}
+
+static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const float*& w) {
+    ConvLayer L;
+    conv_plan_layer(L, kind, Cin, Cout);
+    std::vector<float> packed;
+    L.wp_floats = conv_pack_weights(L, w, packed);
+    hipError_t e = hipMalloc((void**)&L.wp, packed.size() * sizeof(float));
+    if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+    QMRI_HIP(ctx, hipMemcpy(L.wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int taps = (kind == CONV_3X3) ? 9 : 4;
+    w += (size_t)Cin * Cout * taps;
+    ctx->net.layers.push_back(L);
+    return QMRI_OK;
+}
+
+template <typename T> static int dev_alloc(qmri_ctx* ctx, T** p, size_t count) {
+    *p = nullptr;
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+    return QMRI_OK;
+}
+
+extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const float* weights, size_t nbytes, int H, int W,
+                                 int max_batch) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    QMRI_CHECK_ARG(ctx, desc && weights, "desc / weights must not be NULL");
+    QMRI_CHECK_ARG(ctx, H > 0 && W > 0 && max_batch > 0, "H, W, max_batch must be positive");
+    QMRI_CHECK_ARG(ctx, desc->in_nc > 0 && desc->out_nc > 0 && desc->nb >= 1, "in_nc, out_nc, nb must be positive");
+    if (desc->arch != QMRI_ARCH_UNETRES && desc->arch != QMRI_ARCH_SEQ_CONV) {
+        qmri_set_error(ctx, "unknown network architecture %d", desc->arch);
+        return QMRI_ERR_UNSUPPORTED;
+    }
+    if (desc->arch == QMRI_ARCH_UNETRES && (H % 8 != 0 || W % 8 != 0)) {
+        // UNetRes has three 2x down-samplers and no padding logic (network_unet.py:106-117)
+        qmri_set_error(ctx, "UNetRes needs H and W divisible by 8 (got %d x %d)", H, W);
+        return QMRI_ERR_UNSUPPORTED;
+    }
+    if (nbytes != 4 * qmri_net_nparams(desc)) {
+        qmri_set_error(ctx, "weight blob is %zu bytes, architecture needs %zu", nbytes, 4 * qmri_net_nparams(desc));
+        return QMRI_ERR_INVALID_ARG;
+    }
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    qmri_free_net(ctx);
+    NetPlan& p = ctx->net;
+    p.desc = *desc; p.H = H; p.W = W; p.maxB = max_batch;
+    const float* w = weights;
+    const int nb = desc->nb;
+    const size_t HW = (size_t)H * W, B = (size_t)max_batch;
+    size_t scratch = 0;
+    if (desc->arch == QMRI_ARCH_UNETRES) {
+        const int32_t* nc = desc->nc;
+        QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, nc[0], w));
+        for (int l = 0; l < 3; ++l) {
+            for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[l], nc[l], w));
+            QMRI_TRY(add_layer(ctx, CONV_DOWN, nc[l], nc[l + 1], w));
+        }
+        for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[3], nc[3], w));
+        for (int l = 3; l > 0; --l) {
+            QMRI_TRY(add_layer(ctx, CONV_UP, nc[l], nc[l - 1], w));
+            for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[l - 1], nc[l - 1], w));
+        }
+        QMRI_TRY(add_layer(ctx, CONV_3X3, nc[0], desc->out_nc, w));
+        for (int l = 0; l < 4; ++l) scratch = std::max(scratch, (size_t)nc[l] * (HW >> (2 * l)));
+        QMRI_TRY(dev_alloc(ctx, &p.x1, B * nc[0] * HW));
+        QMRI_TRY(dev_alloc(ctx, &p.x2, B * nc[1] * (HW >> 2)));
+        QMRI_TRY(dev_alloc(ctx, &p.x3, B * nc[2] * (HW >> 4)));
+        QMRI_TRY(dev_alloc(ctx, &p.x4, B * nc[3] * (HW >> 6)));
+    } else {
+        const int width = desc->nc[0];
+        if (nb == 1) QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, desc->out_nc, w));
+        else {
+            QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, width, w));
+            for (int l = 1; l < nb - 1; ++l) QMRI_TRY(add_layer(ctx, CONV_3X3, width, width, w));
+            QMRI_TRY(add_layer(ctx, CONV_3X3, width, desc->out_nc, w));
+        }
+        scratch = (size_t)width * HW;
+    }
+    QMRI_TRY(dev_alloc(ctx, &p.a, B * scratch));
+    QMRI_TRY(dev_alloc(ctx, &p.t1, B * scratch));
+    QMRI_TRY(dev_alloc(ctx, &p.in32, B * desc->in_nc * HW));
+    QMRI_TRY(dev_alloc(ctx, &p.out32, B * desc->out_nc * HW));
+    p.ready = true;
+    return QMRI_OK;
+}
+
+// one conv launch with optional per-launch timing of the dominant kernel (profile level 2)
+static int run_conv(qmri_ctx* ctx, const ConvLayer& L, int B, int H, int W, const float* in, float* out, const float* add1,
+                    const float* add2, int relu) {
+    const bool timed = ctx->prof_level >= 2 && L.kind == CONV_3X3 && L.Cin >= 64 && L.Cout >= 64;
+    if (timed) QMRI_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    QMRI_TRY(conv_launch(ctx, L, B, H, W, in, out, add1, add2, relu));
+    if (timed) {
+        QMRI_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        QMRI_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+        float ms = 0.f;
+        QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        ctx->prof.ms_conv3x3 += ms;
+        ctx->prof.n_conv3x3 += 1;
+    }
+    return QMRI_OK;
+}
+
+// nb ResBlocks: cur <- cur + conv(relu(conv(cur)))  (basicblock.py:211-223).  `src` is the block input of the first
+// ResBlock (may be a skip tensor that must stay intact); results land in `cur`; `skip` is added by the last conv.
+static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, int H, int W, const float* src, float* cur, float* tmp,
+                         const float* skip) {
+    const NetPlan& p = ctx->net;
+    const float* in = src;
+    for (int b = 0; b < nb; ++b) {
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, in, tmp, nullptr, nullptr, 1));
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, tmp, cur, in, (b == nb - 1) ? skip : nullptr, 0));
+        in = cur;
+    }
+    return QMRI_OK;
+}
+
+extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, float* d_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    NetPlan& p = ctx->net;
+    if (!p.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, d_in && d_out && B >= 1 && B <= p.maxB, "qmri_net_forward_dev arguments / batch > max_batch");
+    const int H = p.H, W = p.W, nb = p.desc.nb;
+    size_t li = 0;
+    if (p.desc.arch == QMRI_ARCH_SEQ_CONV) {
+        const size_t nl = p.layers.size();
+        const float* in = d_in;
+        float* bufs[2] = { p.a, p.t1 };
+        for (size_t l = 0; l < nl; ++l) {
+            float* out = (l == nl - 1) ? d_out : bufs[l & 1];
+            QMRI_TRY(run_conv(ctx, p.layers[l], B, H, W, in, out, nullptr, nullptr, l != nl - 1));
+            in = out;
+        }
+        return QMRI_OK;
+    }
+    // UNetRes.forward, network_unet.py:106-117
+    QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, d_in, p.x1, nullptr, nullptr, 0));                    // x1 = m_head(x0)
+    float* skips[4] = { p.x1, p.x2, p.x3, p.x4 };
+    for (int l = 0; l < 3; ++l) {                                                                          // x_{l+2} = m_down_{l+1}(x_{l+1})
+        QMRI_TRY(run_resblocks(ctx, li, nb, B, H >> l, W >> l, skips[l], p.a, p.t1, nullptr));
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H >> l, W >> l, p.a, skips[l + 1], nullptr, nullptr, 0));
+    }
+    QMRI_TRY(run_resblocks(ctx, li, nb, B, H >> 3, W >> 3, p.x4, p.a, p.t1, p.x4));                         // m_body(x4) + x4
+    float* cur = p.a;
+    float* tmp = p.t1;
+    for (int l = 3; l > 0; --l) {                                                                          // m_up_l(x + x_{l+1})
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H >> l, W >> l, cur, tmp, nullptr, nullptr, 0));         // transposed conv
+        std::swap(cur, tmp);
+        QMRI_TRY(run_resblocks(ctx, li, nb, B, H >> (l - 1), W >> (l - 1), cur, cur, tmp, skips[l - 1]));
+    }
+    QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, cur, d_out, nullptr, nullptr, 0));                     // m_tail(x + x1)
+    return QMRI_OK;
+}
+
+extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C, int B, double* out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    NetPlan& p = ctx->net;
+    if (!p.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, in && out, "in / out must not be NULL");
+    if (H != p.H || W != p.W || C != p.desc.in_nc) {
+        // MATLAB: images:denoiseImage:incompatibleImageNetwork-style size error from activations()
+        qmri_set_error(ctx, "input %d x %d x %d does not match the network input %d x %d x %d", H, W, C, p.H, p.W, p.desc.in_nc);
+        return QMRI_ERR_INVALID_ARG;
+    }
+    QMRI_CHECK_ARG(ctx, B >= 1 && B <= p.maxB, "batch exceeds max_batch of qmri_set_denoiser");
+    const size_t HW = (size_t)H * W, nin = HW * C * B, nout = HW * p.desc.out_nc * B;
+    double* d_io = nullptr;
+    QMRI_HIP(ctx, hipMalloc((void**)&d_io, std::max(nin, nout) * sizeof(double)));
+    int st = QMRI_OK;
+    do {
+        if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
+        if ((st = ew_launch_cast(ctx, nin, d_io, p.in32)) != QMRI_OK) break;                   // im2single: :72-77
+        if ((st = qmri_net_forward_dev(ctx, p.in32, B, p.out32)) != QMRI_OK) break;            // activations(...): :88
+        if ((st = ew_launch_denoise_out(ctx, HW, p.desc.out_nc, C, B, p.out32, p.in32, p.desc.residual_noise, d_io)) != QMRI_OK) break;
+        if (hipMemcpyAsync(out, d_io, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
+    } while (0);
+    (void)hipFree(d_io);
+    if (st == QMRI_ERR_HIP && ctx->err.empty()) qmri_set_error(ctx, "HIP failure in qmri_denoise");
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PnP-ADMM
+// ---------------------------------------------------------------------------------------------------
+struct StageTimer {
+    qmri_ctx* ctx;
+    bool on;
+    explicit StageTimer(qmri_ctx* c) : ctx(c), on(c->prof_level >= 1) {}
+    void start() { if (on) (void)hipEventRecord(ctx->ev[0], ctx->stream); }
+    void stop(double& acc) {
+        if (!on) return;
+        (void)hipEventRecord(ctx->ev[1], ctx->stream);
+        (void)hipEventSynchronize(ctx->ev[1]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+        acc += ms;
+    }
+};
+
+extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* prm, const void* d_x0,
+                                 const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    OpHost& o = ctx->op;
+    NetPlan& net = ctx->net;
+    if (!o.ready) { qmri_set_error(ctx, "operator not set: call qmri_set_operator first"); return QMRI_ERR_STATE; }
+    if (!net.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, d_y && prm && d_x_out, "y / params / x_out must not be NULL");
+    const int B = nslices;
+    QMRI_CHECK_ARG(ctx, B >= 1 && B <= o.maxB && B <= net.maxB, "nslices exceeds max_batch of the operator or the denoiser");
+    QMRI_CHECK_ARG(ctx, prm->iters >= 0 && prm->gamma > 0 && prm->cg_maxit >= 0, "iters >= 0, gamma > 0, cg_maxit >= 0 required");
+    const int multi = prm->denoiser_type == QMRI_DENOISER_MULTI_LEVEL;
+    if (net.H != o.N || net.W != o.M || net.desc.in_nc != o.s + (multi ? 1 : 0) || net.desc.out_nc != o.s) {
+        qmri_set_error(ctx, "denoiser (%d x %d, %d -> %d channels) does not fit the operator (%d x %d x %d, %s)", net.H, net.W,
+                       net.desc.in_nc, net.desc.out_nc, o.N, o.M, o.s, multi ? "multi_level" : "single_level");
+        return QMRI_ERR_INVALID_ARG;
+    }
+    const OpDev op = qmri_opdev(ctx);
+    const size_t plane = (size_t)o.N * o.M, n = plane * o.s, nb = (size_t)B * n * sizeof(double2);
+    const double2* y = (const double2*)d_y;
+    StageTimer tm(ctx);
+
+    QMRI_TRY(dc_launch_sort_y(ctx, op, o.ls, B, y));
+    if (d_x0) QMRI_HIP(ctx, hipMemcpyAsync(o.d_x, d_x0, nb, hipMemcpyDeviceToDevice, ctx->stream));        // x = param.X0
+    else QMRI_TRY(dc_launch_adj(ctx, op, o.ls, DC_PLAIN, B, y, o.d_tmp, o.d_x, nullptr));                    // F.adjoint(Y)
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_vv, o.d_x, nb, hipMemcpyDeviceToDevice, ctx->stream));                  // v = x
+    QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, nb, ctx->stream));                                                // uold = 0
+    if (prm->solver == QMRI_SOLVER_DIRECT) {
+        QMRI_TRY(qmri_prepare_direct(ctx, prm->gamma));
+        const double2* aty = o.d_x;
+        if (d_x0) { QMRI_TRY(dc_launch_adj(ctx, op, o.ls, DC_PLAIN, B, y, o.d_tmp, o.d_xa, nullptr)); aty = o.d_xa; }
+        QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, aty, nullptr, o.d_tmp, o.d_chat, nullptr));
+    } else if (prm->solver != QMRI_SOLVER_LSQR) {
+        qmri_set_error(ctx, "unknown solver %d", prm->solver);
+        return QMRI_ERR_INVALID_ARG;
+    }
+    if (prm->want_diag && diag_out) {
+        if (o.d_diag) { (void)hipFree(o.d_diag); o.d_diag = nullptr; }
+        QMRI_HIP(ctx, hipMalloc((void**)&o.d_diag, (size_t)B * std::max(prm->iters, 1) * 2 * sizeof(double)));
+    }
+    std::vector<int32_t> it_b(B);
+    for (int it = 0; it < prm->iters; ++it) {
+        // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
+        tm.start();
+        QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, B, o.d_vv, o.d_u, o.d_z));
+        if (prm->solver == QMRI_SOLVER_LSQR) {
+            QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr));
+            if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
+        } else {
+            QMRI_TRY(dc_launch_direct(ctx, op, B, o.d_z, o.d_chat, prm->gamma, o.d_tmp, o.d_x));
+            if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = 0;
+        }
+        tm.stop(ctx->prof.ms_xupdate);
+        if (prm->want_diag && diag_out) {                                                                    // PnP_ADMM.m:106-109
+            tm.start();
+            QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_DIAG, B, o.d_x, nullptr, o.d_tmp, nullptr, o.d_pd));
+            QMRI_TRY(ew_launch_diag(ctx, op, o.ls, B, o.d_x, (const double2*)d_gt, o.d_pd, o.d_diag, prm->iters, it));
+            tm.stop(ctx->prof.ms_diag);
+        }
+        // Step 2 (PnP_ADMM.m:115-138): v = real(x+uold) -> [0,1] -> net -> undo
+        tm.start();
+        QMRI_TRY(ew_launch_minmax_normalise(ctx, B, n, plane, net.desc.in_nc, multi, prm->noise_std, o.d_x, o.d_u, o.d_mm, o.d_norm,
+                                            o.ls.nblk_z, net.in32));
+        tm.stop(ctx->prof.ms_elementwise);
+        tm.start();
+        QMRI_TRY(qmri_net_forward_dev(ctx, net.in32, B, net.out32));
+        tm.stop(ctx->prof.ms_denoiser);
+        // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
+        tm.start();
+        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.d_vv));
+        tm.stop(ctx->prof.ms_elementwise);
+        ctx->prof.admm_iters += 1;
+    }
+    QMRI_HIP(ctx, hipMemcpyAsync(d_x_out, o.d_x, nb, hipMemcpyDeviceToDevice, ctx->stream));                 // returns x, not v
+    if (prm->want_diag && diag_out && prm->iters > 0)
+        QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+extern "C" int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_params* p, const void* x0, const void* gt,
+                             void* x_out, double* diag_out, int32_t* lsqr_iters_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    OpHost& o = ctx->op;
+    if (!o.ready) { qmri_set_error(ctx, "operator not set: call qmri_set_operator first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, y && p && x_out, "y / params / x_out must not be NULL");
+    const size_t n = (size_t)o.N * o.M * o.s;
+    double2* d_gt = nullptr;
+    double2* d_x0 = nullptr;
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_ya, y, (size_t)o.m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    if (x0) { d_x0 = o.d_xb; QMRI_HIP(ctx, hipMemcpyAsync(d_x0, x0, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream)); }
+    if (gt) {
+        QMRI_HIP(ctx, hipMalloc((void**)&d_gt, n * sizeof(double2)));
+        QMRI_HIP(ctx, hipMemcpyAsync(d_gt, gt, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    }
+    int st = qmri_pnp_admm_dev(ctx, 1, o.d_ya, p, d_x0, d_gt, o.d_xa, diag_out, lsqr_iters_out);
+    if (st == QMRI_OK) {
+        if (hipMemcpyAsync(x_out, o.d_xa, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            qmri_set_error(ctx, "copy of the result to the host failed");
+            st = QMRI_ERR_HIP;
+        }
+    }
+    if (d_gt) (void)hipFree(d_gt);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dictionary
+// ---------------------------------------------------------------------------------------------------
+void qmri_free_dict(qmri_ctx* ctx) {
+    DictHost& d = ctx->dict;
+    if (d.d_pack) (void)hipFree(d.d_pack);
+    if (d.d_normD) (void)hipFree(d.d_normD);
+    if (d.d_lut) (void)hipFree(d.d_lut);
+    d = DictHost();
+}
+
+extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const float* D, const float* normD, const float* lut) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    QMRI_CHECK_ARG(ctx, D && normD && lut, "D / normD / lut must not be NULL");
+    QMRI_CHECK_ARG(ctx, K > 0 && s > 0 && Q > 0, "K, s, Q must be positive");
+    if (s > 16) { qmri_set_error(ctx, "dictionary match supports s <= 16 channels (got %d)", s); return QMRI_ERR_UNSUPPORTED; }
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    qmri_free_dict(ctx);
+    DictHost& d = ctx->dict;
+    d.K = K; d.s = s; d.Q = Q;
+    d.ntiles = (K + 31) / 32;
+    const int npair = (s + 1) / 2;
+    std::vector<float> pack((size_t)d.ntiles * npair * 64, 0.f);
+    for (int t = 0; t < d.ntiles; ++t)
+        for (int q = 0; q < npair; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int atom = t * 32 + (lane & 31), c = 2 * q + (lane >> 5);
+                if (atom < K && c < s) pack[((size_t)t * npair + q) * 64 + lane] = D[(size_t)atom + (size_t)K * c];
+            }
+    QMRI_TRY(dev_alloc(ctx, &d.d_pack, pack.size()));
+    QMRI_TRY(dev_alloc(ctx, &d.d_normD, (size_t)K));
+    QMRI_TRY(dev_alloc(ctx, &d.d_lut, (size_t)K * Q));
+    QMRI_HIP(ctx, hipMemcpy(d.d_pack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(d.d_normD, normD, (size_t)K * sizeof(float), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(d.d_lut, lut, (size_t)K * Q * sizeof(float), hipMemcpyHostToDevice));
+    d.ready = true;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dict.ready) { qmri_set_error(ctx, "dictionary not set: call qmri_set_dictionary first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, d_X && Npix > 0, "X must not be NULL and Npix > 0");
+    ctx->prof.ms_match += 0.0;
+    return dict_launch(ctx, (const double2*)d_X, Npix, d_qmap, d_pd, d_mt, d_dm);
+}
+
+extern "C" int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dict.ready) { qmri_set_error(ctx, "dictionary not set: call qmri_set_dictionary first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, X && Npix > 0, "X must not be NULL and Npix > 0");
+    const DictHost& d = ctx->dict;
+    const size_t nx = (size_t)Npix * d.s;
+    double2* dX = nullptr; float* dq = nullptr; float* dp = nullptr; float* dmt = nullptr; int32_t* ddm = nullptr;
+    int st = QMRI_OK;
+    auto fail = [&](const char* what) { qmri_set_error(ctx, "%s failed in qmri_dict_match", what); st = QMRI_ERR_HIP; };
+    do {
+        if (hipMalloc((void**)&dX, nx * sizeof(double2)) != hipSuccess) { fail("hipMalloc"); break; }
+        if (qmap && hipMalloc((void**)&dq, (size_t)Npix * d.Q * sizeof(float)) != hipSuccess) { fail("hipMalloc"); break; }
+        if (pd && hipMalloc((void**)&dp, (size_t)Npix * 2 * sizeof(float)) != hipSuccess) { fail("hipMalloc"); break; }
+        if (mt && hipMalloc((void**)&dmt, (size_t)Npix * sizeof(float)) != hipSuccess) { fail("hipMalloc"); break; }
+        if (dm && hipMalloc((void**)&ddm, (size_t)Npix * sizeof(int32_t)) != hipSuccess) { fail("hipMalloc"); break; }
+        if (hipMemcpyAsync(dX, X, nx * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
+        if ((st = dict_launch(ctx, dX, Npix, dq, dp, dmt, ddm)) != QMRI_OK) break;
+        if (qmap && hipMemcpyAsync(qmap, dq, (size_t)Npix * d.Q * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        if (pd && hipMemcpyAsync(pd, dp, (size_t)Npix * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        if (mt && hipMemcpyAsync(mt, dmt, (size_t)Npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        if (dm && hipMemcpyAsync(dm, ddm, (size_t)Npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { fail("synchronize"); break; }
+    } while (0);
+    void* ptrs[] = { dX, dq, dp, dmt, ddm };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// slice batches over several GPUs: one host thread + one context per device, static round-robin of launches
+// (slices are independent, no collective)
+// ---------------------------------------------------------------------------------------------------
+static int recon_worker(int device, int widx, int nworkers, int nslices, const qmri_problem* pb, const char* Y, char* X_out,
+                        float* qmap_out, float* pd_out, std::string* err) {
+    qmri_ctx* ctx = nullptr;
+    int st = qmri_create(device, &ctx);
+    if (st != QMRI_OK) { *err = qmri_last_error(nullptr); return st; }
+    const int spl = std::max(1, pb->slices_per_launch);
+    const size_t n = (size_t)pb->N * pb->M * pb->s, npix = (size_t)pb->N * pb->M;
+    const int m = pb->frame_ptr[pb->T];
+    double2 *dY = nullptr, *dX = nullptr;
+    float *dq = nullptr, *dp = nullptr;
+    auto bail = [&](int code) { *err = qmri_last_error(ctx); return code; };
+    do {
+        if ((st = qmri_set_operator(ctx, pb->N, pb->M, pb->s, pb->T, pb->V, pb->frame_ptr, pb->kidx, spl)) != QMRI_OK) { bail(st); break; }
+        if ((st = qmri_set_denoiser(ctx, pb->net, pb->weights, pb->weights_nbytes, pb->N, pb->M, spl)) != QMRI_OK) { bail(st); break; }
+        if (pb->K > 0 && (st = qmri_set_dictionary(ctx, pb->K, pb->s, pb->Q, pb->D, pb->normD, pb->lut)) != QMRI_OK) { bail(st); break; }
+        if (hipMalloc((void**)&dY, (size_t)spl * m * sizeof(double2)) != hipSuccess || hipMalloc((void**)&dX, (size_t)spl * n * sizeof(double2)) != hipSuccess ||
+            hipMalloc((void**)&dq, npix * std::max(pb->Q, 1) * sizeof(float)) != hipSuccess || hipMalloc((void**)&dp, npix * 2 * sizeof(float)) != hipSuccess) {
+            *err = "hipMalloc failed in qmri_recon_batch"; st = QMRI_ERR_NOMEM; break;
+        }
+        const int nlaunch = (nslices + spl - 1) / spl;
+        for (int l = widx; l < nlaunch && st == QMRI_OK; l += nworkers) {
+            const int s0 = l * spl, cnt = std::min(spl, nslices - s0);
+            if (hipMemcpy(dY, Y + (size_t)s0 * m * sizeof(double2), (size_t)cnt * m * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) { *err = "H2D copy failed"; st = QMRI_ERR_HIP; break; }
+            if ((st = qmri_pnp_admm_dev(ctx, cnt, dY, &pb->admm, nullptr, nullptr, dX, nullptr, nullptr)) != QMRI_OK) { bail(st); break; }
+            if (hipMemcpy(X_out + (size_t)s0 * n * sizeof(double2), dX, (size_t)cnt * n * sizeof(double2), hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H copy failed"; st = QMRI_ERR_HIP; break; }
+            if (pb->K > 0 && (qmap_out || pd_out)) {
+                for (int i = 0; i < cnt && st == QMRI_OK; ++i) {
+                    if ((st = qmri_dict_match_dev(ctx, dX + (size_t)i * n, (int)npix, qmap_out ? dq : nullptr, pd_out ? dp : nullptr, nullptr, nullptr)) != QMRI_OK) { bail(st); break; }
+                    if (qmri_synchronize(ctx) != QMRI_OK) { bail(QMRI_ERR_HIP); st = QMRI_ERR_HIP; break; }
+                    if (qmap_out && hipMemcpy(qmap_out + (size_t)(s0 + i) * npix * pb->Q, dq, npix * pb->Q * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H copy failed"; st = QMRI_ERR_HIP; break; }
+                    if (pd_out && hipMemcpy(pd_out + (size_t)(s0 + i) * npix * 2, dp, npix * 2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H copy failed"; st = QMRI_ERR_HIP; break; }
+                }
+            }
+        }
+    } while (0);
+    void* ptrs[] = { dY, dX, dq, dp };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    qmri_destroy(ctx);
+    return st;
+}
+
+extern "C" int qmri_recon_batch(int ndev, const int* devs, int nslices, const qmri_problem* prob, const void* Y, void* X_out,
+                                float* qmap_out, float* pd_out, char* errbuf, size_t errbuf_len) {
+    auto report = [&](const std::string& s) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", s.c_str()); } };
+    if (ndev <= 0 || !devs || nslices <= 0 || !prob || !Y || !X_out || !prob->V || !prob->frame_ptr || !prob->kidx || !prob->net ||
+        !prob->weights) {
+        report("qmri_recon_batch: invalid arguments");
+        return QMRI_ERR_INVALID_ARG;
+    }
+    std::vector<std::thread> th;
+    std::vector<int> status(ndev, QMRI_OK);
+    std::vector<std::string> errs(ndev);
+    for (int w = 0; w < ndev; ++w)
+        th.emplace_back([&, w]() {
+            status[w] = recon_worker(devs[w], w, ndev, nslices, prob, (const char*)Y, (char*)X_out, qmap_out, pd_out, &errs[w]);
+        });
+    for (auto& t : th) t.join();
+    for (int w = 0; w < ndev; ++w)
+        if (status[w] != QMRI_OK) { report("device " + std::to_string(devs[w]) + ": " + errs[w]); return status[w]; }
+    return QMRI_OK;
+}

@@ -1,0 +1,124 @@
+// dict_kernels.hip -- MRF dictionary template match on the f32 MFMA (gfx950).
+//
+// Reference semantics: main_files/dictionary_matching/mrf_dtm_cpu.m
+//   :54      x = single(x)
+//   :91      ip = dict.D * ctranspose(x(cind,:))      (K x s) * (s x B): ip(j,p) = sum_c D(j,c) conj(x(p,c))
+//   :92      [mt,dm] = max(abs(ip),[],1)               first index wins ties
+//   :94-96   pd = ip(dm) / normD(dm)
+//   :136-160 qmap = lut(dm,:) (NaN -> 0), pd, mt, dm (1-based)
+// The reference materialises ip in blocks of <= 1e9 elements (:74) and then walks pixels in an interpreted
+// loop; here the K x Npix product never exists: each wave keeps one 32-pixel column tile's X fragment in
+// registers, streams 32-atom tiles of D through v_mfma_f32_32x32x2_f32 (real and imaginary chains) and
+// reduces |ip|^2 to a running (max, argmax) in the epilogue.  A f32 MFMA accumulates k in order with one
+// fma per product, so ip is bit-identical to a sequential fmaf chain over c = 0..s-1 -- the arithmetic the
+// oracle spells out -- and the argmax can be checked bit-exactly.
+//
+// Work split: one workgroup (4 waves) per 32-pixel tile; wave w takes atom tiles w, w+4, ...; the four
+// (max, argmax) candidates per pixel are merged through LDS preferring the lower index on ties.
+#include "qmri_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT = 256;
+constexpr int MAXPAIR = 8;      // s <= 16
+
+// D packed as MFMA A-fragments: pack[tile][pair q][lane] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s)
+template <int NPAIR>
+__global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X, int Npix, int s, const float* __restrict__ pack,
+                                                    int ntiles, int K, const float* __restrict__ normD,
+                                                    const float* __restrict__ lut, int Q, float* __restrict__ qmap,
+                                                    float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm) {
+    __shared__ float s_best[4][32];
+    __shared__ int s_idx[4][32];
+    __shared__ float s_re[4][32];
+    __shared__ float s_im[4][32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int p = blockIdx.x * 32 + j;
+    // B fragments: B[k = 2q + h][j] = x(p, c = 2q + h)  (real chain) and -imag (conjugate) for the imaginary chain
+    float bre[NPAIR], bim[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) {
+        const int c = 2 * q + h;
+        double2 v = make_double2(0.0, 0.0);
+        if (p < Npix && c < s) v = X[(size_t)p + (size_t)Npix * c];
+        bre[q] = (float)v.x;                   // single(x)  mrf_dtm_cpu.m:54
+        bim[q] = -(float)v.y;                  // conj
+    }
+    float best = -1.0f, cre = 0.f, cim = 0.f;
+    int bidx = 0;
+    for (int t = wave; t < ntiles; t += 4) {
+        const float* ap = pack + ((size_t)t * NPAIR) * 64 + lane;
+        float a[NPAIR];
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) a[q] = ap[q * 64];
+        f32x16 are = {0}, aim = {0};
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            are = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bre[q], are, 0, 0, 0);
+            aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bim[q], aim, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float re = are[r], im = aim[r];
+            const float m2 = __builtin_fmaf(im, im, re * re);
+            const int atom = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D row of the 32x32 MFMA tile
+            if (m2 > best) { best = m2; bidx = atom; cre = re; cim = im; }
+        }
+    }
+    // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
+    {
+        const float ob = __shfl(best, lane ^ 32, 64), ore = __shfl(cre, lane ^ 32, 64), oim = __shfl(cim, lane ^ 32, 64);
+        const int oi = __shfl(bidx, lane ^ 32, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; cre = ore; cim = oim; }
+    }
+    if (h == 0) { s_best[wave][j] = best; s_idx[wave][j] = bidx; s_re[wave][j] = cre; s_im[wave][j] = cim; }
+    __syncthreads();
+    if (tid < 32 && p < Npix) {
+        best = s_best[0][tid]; bidx = s_idx[0][tid]; cre = s_re[0][tid]; cim = s_im[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ob = s_best[w][tid];
+            const int oi = s_idx[w][tid];
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; cre = s_re[w][tid]; cim = s_im[w][tid]; }
+        }
+        if (bidx >= K) bidx = 0;       // cannot happen: padded atoms are all-zero and never beat a real one
+        const float nd = normD[bidx];
+        if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
+        if (mt) mt[p] = sqrtf(best);                                 // :150-154
+        if (pd) { pd[2 * (size_t)p] = cre / nd; pd[2 * (size_t)p + 1] = cim / nd; }     // :96,:144-148
+        if (qmap)
+            for (int q = 0; q < Q; ++q) {
+                const float v = lut[(size_t)bidx + (size_t)K * q];
+                qmap[(size_t)p + (size_t)Npix * q] = (v != v) ? 0.f : v;                  // NaN -> 0  :138
+            }
+    }
+}
+
+}  // namespace
+
+int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm) {
+    const DictHost& D = ctx->dict;
+    const int npair = (D.s + 1) / 2;
+    dim3 grid((Npix + 31) / 32), blk(NT);
+#define LAUNCH(NP)                                                                                                    \
+    k_dict_match<NP><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q, \
+                                                    d_qmap, d_pd, d_mt, d_dm)
+    switch (npair) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        case 4: LAUNCH(4); break;
+        case 5: LAUNCH(5); break;
+        case 6: LAUNCH(6); break;
+        case 7: LAUNCH(7); break;
+        case 8: LAUNCH(8); break;
+        default:
+            qmri_set_error(ctx, "dictionary match supports s <= %d channels (got %d)", 2 * MAXPAIR, D.s);
+            return QMRI_ERR_UNSUPPORTED;
+    }
+#undef LAUNCH
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}

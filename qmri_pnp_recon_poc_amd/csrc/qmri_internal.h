@@ -1,0 +1,205 @@
+// qmri_internal.h -- shared declarations of libqmri.so (host side + kernel launch prototypes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/qmri.h"
+
+// ---------------------------------------------------------------------------------------------------
+// error handling: nothing throws across the C ABI
+// ---------------------------------------------------------------------------------------------------
+struct qmri_ctx;
+void qmri_set_error(qmri_ctx* ctx, const char* fmt, ...);
+
+#define QMRI_HIP(ctx, expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            qmri_set_error((ctx), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return QMRI_ERR_HIP;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+#define QMRI_CHECK_ARG(ctx, cond, msg)                                                            \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            qmri_set_error((ctx), "invalid argument: %s", (msg));                                 \
+            return QMRI_ERR_INVALID_ARG;                                                          \
+        }                                                                                         \
+    } while (0)
+
+#define QMRI_TRY(expr)                                                                            \
+    do {                                                                                          \
+        int _s = (expr);                                                                          \
+        if (_s != QMRI_OK) return _s;                                                             \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// forward operator (struct F): device-side description
+// ---------------------------------------------------------------------------------------------------
+struct KEntry {          // one sample of the k-sorted measurement list
+    uint16_t kw;         // k-space column (second FFT dimension)
+    uint16_t t;          // frame
+};
+
+struct OpDev {
+    int N, M, s, T, m;
+    const double* Vt;        // [T][s]  V(t,c), frame-major
+    const KEntry* ent;       // [m]     k-sorted: (kh, kw, t) ascending
+    const int32_t* perm;     // [m]     k-sorted position -> frame-major measurement index (ABI order)
+    const int32_t* kptr;     // [N*M+1] CSR over k' = kh*M + kw into ent
+    const double2* tw;       // [N]     exp(-2*pi*i*j/N)
+    const int32_t* kslot;    // [N*M]   DIRECT solver: slot of k' among sampled locations or -1
+    const double* ginv;      // [nsampled][s*s] (G_k + r I)^-1, symmetric, row-major
+};
+
+// LSQR (PnP_ADMM.m:102) device state, one per slice
+struct LsqrScalars {
+    double c, s, phibar, normr, norma, factor;   // recurrences; normar = alpha * factor
+    double thet, rho, phi, beta, alpha;          // values A2 needs for the current iteration
+};
+struct LsqrState {
+    LsqrScalars sc[2];       // ping-pong by iteration parity
+    double n2b, tolb;
+    double ny2;              // ||y||^2
+    int32_t iter, done, flag, pad;
+};
+
+enum { DC_PLAIN = 0, DC_LSQR_INIT = 1, DC_LSQR_ITER = 2, DC_DIAG = 3, DC_DIRECT = 4, DC_SPECTRUM = 5 };
+
+struct LsqrDev {
+    LsqrState* st;           // [B]
+    double* pu[2];           // [B][npu] partial sums of |u|^2   (npu = nblk_h + N)
+    double* pv;              // [B][nblk_h] partial sums of |v|^2
+    double* pz;              // [B][nblk_z] partial sums of |z|^2
+    double2* ut;             // [B][m]  u(1:m) in k-sorted order (raw, unnormalised)
+    double2* ub;             // [B][n]  u(m+1:end)
+    double2* v;              // [B][n]
+    double2* d;              // [B][n]
+    double2* yk;             // [B][m]  y in k-sorted order
+    int npu, nblk_h, nblk_z;
+    double sr;               // sqrt(r)
+    double tol;              // cg_tol
+    int maxit;
+    int ii;                  // LSQR iteration (1-based; 0 during initialisation)
+};
+
+// ---------------------------------------------------------------------------------------------------
+// denoiser: one packed layer of the conv engine
+// ---------------------------------------------------------------------------------------------------
+enum ConvKind { CONV_3X3 = 0, CONV_DOWN = 1, CONV_UP = 2 };
+struct ConvLayer {
+    ConvKind kind;
+    int Cin, Cout;           // logical channels (UP: Cout = real output channels)
+    int cin_pad, n_ct;       // padded input channels, number of 32*MT-row output tiles
+    int MT;                  // 32-row MFMA tiles per wave
+    float* wp;               // packed weights (device)
+    size_t wp_floats;
+};
+
+struct NetPlan {
+    qmri_net_desc desc{};
+    int H = 0, W = 0, maxB = 0;
+    std::vector<ConvLayer> layers;
+    // activation buffers (device, fp32, [B][C][W][H])
+    float* x1 = nullptr; float* x2 = nullptr; float* x3 = nullptr; float* x4 = nullptr;
+    float* a = nullptr; float* t1 = nullptr;
+    float* in32 = nullptr;   // [B][in_nc][W][H] normalised network input
+    float* out32 = nullptr;  // [B][out_nc][W][H]
+    bool ready = false;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+struct OpHost {
+    bool ready = false;
+    int N = 0, M = 0, s = 0, T = 0, m = 0, maxB = 0, nsampled = 0;
+    double* d_Vt = nullptr; KEntry* d_ent = nullptr; int32_t* d_perm = nullptr; int32_t* d_kptr = nullptr;
+    double2* d_tw = nullptr; int32_t* d_kslot = nullptr; double* d_ginv = nullptr;
+    double ginv_r = -1.0;
+    std::vector<double> V;              // T x s column-major (host copy)
+    std::vector<int32_t> frame_ptr, kidx, kptr_h, perm_h;
+    std::vector<KEntry> ent_h;
+    // workspaces
+    double2* d_tmp = nullptr;           // [B][s][N][M]
+    double2* d_xa = nullptr; double2* d_xb = nullptr;   // [B][n] staging for host-pointer entry points
+    double2* d_ya = nullptr;            // [B][m]
+    LsqrDev ls{};
+    // ADMM state
+    double2* d_x = nullptr; double2* d_u = nullptr; double2* d_vv = nullptr; double2* d_z = nullptr;
+    double2* d_chat = nullptr;          // DIRECT: unitary FFT2 of A'y
+    double* d_mm = nullptr;             // [B][nblk_z][2] min/max partials
+    double* d_norm = nullptr;           // [B][2] lo, range
+    double* d_diag = nullptr;           // [B][iters][2]
+    double* d_pd = nullptr;             // diag partials
+    int32_t* h_flags = nullptr;         // pinned host mirror of done flags
+    LsqrState* h_state = nullptr;       // pinned
+};
+
+struct DictHost {
+    bool ready = false;
+    int K = 0, s = 0, Q = 0, ntiles = 0;
+    float* d_pack = nullptr;            // [ntiles][npair][64] MFMA A-fragments
+    float* d_normD = nullptr; float* d_lut = nullptr;
+    float* d_best = nullptr; int32_t* d_bidx = nullptr;   // workspaces
+};
+
+struct qmri_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    OpHost op;
+    NetPlan net;
+    DictHost dict;
+    int prof_level = 0;
+    qmri_profile prof{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
+};
+
+OpDev qmri_opdev(const qmri_ctx* ctx);
+
+// ---------------------------------------------------------------------------------------------------
+// kernel launchers (dc_kernels.hip)
+// ---------------------------------------------------------------------------------------------------
+bool dc_size_supported(int N);
+int dc_nblk_h(int N, int M, int s);     // blocks of the h-pass kernels (= partial sums per slice)
+// forward:  src [B][n] -> (mode-dependent) ; tmp workspace [B][n]
+int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B,
+                  const double2* src, const double2* zsrc, double2* tmp, double2* y_out, double* pdiag);
+// adjoint:  (mode-dependent source) -> dst [B][n]
+int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B,
+                  const double2* y_in, double2* tmp, double2* dst, double2* x_inout);
+int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
+                     double2* tmp, double2* x_out);
+// y (ABI order) -> k-sorted order, plus ||y||^2 into state
+int dc_launch_sort_y(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* y);
+// z = v - u, partial ||z||^2
+int dc_launch_prepare_z(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* v, const double2* u,
+                        double2* z);
+// elementwise ADMM stages (PnP_ADMM.m:115-121,138,144)
+int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, size_t plane, int in_nc, int multi_level, double noise_std,
+                               const double2* x, const double2* u, double* mm, double* norm, int nblk, float* in32);
+int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, const float* out32, const float* in32, int residual_noise,
+                               const double* norm, const double2* x, double2* u, double2* v);
+int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* x, const double2* gt,
+                   double* pd, double* diag_slot, int iters_total, int it);
+int ew_launch_cast(qmri_ctx* ctx, size_t count, const double* in, float* out);
+int ew_launch_denoise_out(qmri_ctx* ctx, size_t plane, int out_nc, int in_nc, int B, const float* out32, const float* in32,
+                          int residual_noise, double* out);
+int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out);
+
+// conv engine (conv_kernels.hip)
+int conv_launch(qmri_ctx* ctx, const ConvLayer& L, int B, int H, int W, const float* in, float* out,
+                const float* add1, const float* add2, int relu_out);
+size_t conv_pack_weights(const ConvLayer& L, const float* w_src, std::vector<float>& packed);
+void conv_plan_layer(ConvLayer& L, ConvKind kind, int Cin, int Cout);
+
+// dictionary match (dict_kernels.hip)
+int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm);

@@ -1,0 +1,232 @@
+"""numpy-facing wrapper of one libqmri context (include/qmri.h).
+
+Arrays follow MATLAB conventions: `X[h, w, c]` (any memory order; copied into column-major interleaved-complex
+buffers at the boundary), measurement vectors frame-major.  Every failure raises `QmriError` carrying the
+library's message -- the Python analogue of the MATLAB exceptions the reference's plugins throw.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AdmmParams, NetDesc, Profile
+
+ARCH_UNETRES, ARCH_SEQ_CONV = 0, 1
+SOLVER_LSQR, SOLVER_DIRECT = 0, 1
+
+
+class QmriError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libqmri error {code}: {msg}")
+        self.code = code
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _cbuf(a):
+    """complex array -> 1-D complex128 in column-major (MATLAB) element order."""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.complex128).ravel(order="F"))
+
+
+def build_spiral(N: int, S: int, T: int):
+    """setup_subsampling_spiralgrided.m:7-34 -> (frame_ptr[T+1], kidx[m]) int32 (0-based column-major k)."""
+    L = _lib.lib()
+    fp = np.zeros(T + 1, np.int32)
+    k = np.zeros(S * T, np.int32)
+    m = C.c_int(0)
+    st = L.qmri_build_spiral(None, N, S, T, fp.ctypes.data_as(C.POINTER(C.c_int32)), k.ctypes.data_as(C.POINTER(C.c_int32)), k.size, C.byref(m))
+    if st != 0:
+        raise QmriError(st, L.qmri_last_error(None).decode())
+    return fp, k[: m.value].copy()
+
+
+def build_epi(N: int, M: int, percentage: float, T: int):
+    """setup_subsampling_epi.m:20-33 -> (frame_ptr[T+1], kidx[m])."""
+    L = _lib.lib()
+    step = int(np.floor(1.0 / percentage + 0.5))
+    cap = max((N // step) * M * T, 1)
+    fp = np.zeros(T + 1, np.int32)
+    k = np.zeros(cap, np.int32)
+    m = C.c_int(0)
+    st = L.qmri_build_epi(None, N, M, float(percentage), T, fp.ctypes.data_as(C.POINTER(C.c_int32)), k.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(m))
+    if st != 0:
+        raise QmriError(st, L.qmri_last_error(None).decode())
+    return fp, k[: m.value].copy()
+
+
+class Engine:
+    """One device context: operator + denoiser + dictionary + workspaces."""
+
+    def __init__(self, device: int = 0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        st = self.L.qmri_create(int(device), C.byref(h))
+        if st != 0:
+            raise QmriError(st, self.L.qmri_last_error(None).decode())
+        self.h = h
+        self.device = device
+        self.N = self.M = self.s = self.T = self.m = 0
+        self.net_desc = None
+        self.dict_shape = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qmri_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise QmriError(st, self.L.qmri_last_error(self.h).decode())
+
+    # -- stream / sync ---------------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr: int | None):
+        self._check(self.L.qmri_set_stream(self.h, C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None))
+
+    def synchronize(self):
+        self._check(self.L.qmri_synchronize(self.h))
+
+    # -- operator ----------------------------------------------------------------------------------
+    def set_operator(self, N, M, V, frame_ptr, kidx, max_batch=1):
+        V = np.asarray(V, dtype=np.float64)
+        if V.ndim != 2:
+            raise ValueError("V must be T x s")
+        T, s = V.shape
+        Vf = np.ascontiguousarray(V.ravel(order="F"))
+        fp = np.ascontiguousarray(frame_ptr, dtype=np.int32)
+        k = np.ascontiguousarray(kidx, dtype=np.int32)
+        self._check(self.L.qmri_set_operator(self.h, int(N), int(M), int(s), int(T), Vf.ctypes.data_as(C.POINTER(C.c_double)),
+                                             fp.ctypes.data_as(C.POINTER(C.c_int32)), k.ctypes.data_as(C.POINTER(C.c_int32)), int(max_batch)))
+        self.N, self.M, self.s, self.T, self.m = int(N), int(M), int(s), int(T), int(fp[-1])
+
+    def forward(self, x):
+        """y = F.forward(x)  (main_recon_tsmis_FFT.m:228).  x: [N,M,s] real or complex."""
+        x = np.asarray(x)
+        if x.shape != (self.N, self.M, self.s):
+            raise ValueError(f"x must be {self.N}x{self.M}x{self.s}")
+        y = np.empty(self.m, np.complex128)
+        if np.iscomplexobj(x):
+            xb = _cbuf(x)
+            self._check(self.L.qmri_forward(self.h, _vp(xb), 1, _vp(y)))
+        else:
+            xb = np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel(order="F"))
+            self._check(self.L.qmri_forward(self.h, _vp(xb), 0, _vp(y)))
+        return y
+
+    def adjoint(self, y):
+        """x = F.adjoint(y)  (main_recon_tsmis_FFT.m:229)."""
+        yb = _cbuf(y)
+        if yb.size != self.m:
+            raise ValueError(f"y must have {self.m} elements")
+        x = np.empty(self.N * self.M * self.s, np.complex128)
+        self._check(self.L.qmri_adjoint(self.h, _vp(yb), _vp(x)))
+        return x.reshape((self.N, self.M, self.s), order="F")
+
+    def xupdate(self, y, z, r, tol=1e-4, maxit=100, x0=None, solver="lsqr"):
+        """The x-update of PnP_ADMM.m:102 alone.  Returns (x, iters, flag)."""
+        yb, zb = _cbuf(y), _cbuf(z)
+        x = _cbuf(x0 if x0 is not None else np.zeros((self.N, self.M, self.s))).copy()
+        it, fl = C.c_int32(0), C.c_int32(0)
+        self._check(self.L.qmri_xupdate(self.h, _vp(yb), _vp(zb), float(r), float(tol), int(maxit),
+                                        SOLVER_LSQR if solver == "lsqr" else SOLVER_DIRECT, _vp(x), C.byref(it), C.byref(fl)))
+        return x.reshape((self.N, self.M, self.s), order="F"), it.value, fl.value
+
+    # -- denoiser ------------------------------------------------------------------------------------
+    def set_denoiser(self, weights, H, W, in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4, arch=ARCH_UNETRES,
+                     residual_noise=False, max_batch=1):
+        d = NetDesc(int(arch), int(in_nc), int(out_nc), (C.c_int32 * 4)(*[int(v) for v in nc]), int(nb), int(bool(residual_noise)))
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        self._check(self.L.qmri_set_denoiser(self.h, C.byref(d), w.ctypes.data_as(C.POINTER(C.c_float)), w.nbytes, int(H), int(W), int(max_batch)))
+        self.net_desc = d
+        self.net_hw = (int(H), int(W))
+
+    def denoise(self, x):
+        """I = denoiseImage_PnP_ADMM(x, net, true, residual_noise): x [H,W,C] or [H,W,C,B] double."""
+        x = np.asarray(x, dtype=np.float64)
+        squeeze = x.ndim == 3
+        if squeeze:
+            x = x[..., None]
+        if x.ndim != 4:
+            raise ValueError("input must be H x W x C (x N)")       # images:denoiseImage:invalidImageFormat
+        H, W, Cc, B = x.shape
+        xb = np.ascontiguousarray(x.ravel(order="F"))
+        out_nc = self.net_desc.out_nc if self.net_desc is not None else 1    # unset: the library reports QMRI_ERR_STATE
+        out = np.empty(H * W * out_nc * B, np.float64)
+        self._check(self.L.qmri_denoise(self.h, xb.ctypes.data_as(C.POINTER(C.c_double)), H, W, Cc, B, out.ctypes.data_as(C.POINTER(C.c_double))))
+        out = out.reshape((H, W, out_nc, B), order="F")
+        return out[..., 0] if squeeze else out
+
+    # -- PnP-ADMM ------------------------------------------------------------------------------------
+    def pnp_admm(self, y, gamma=0.05, iters=100, cg_tol=1e-4, cg_maxit=100, solver="lsqr", multi_level=False,
+                 noise_std=0.01, x0=None, gt=None, want_diag=False):
+        """x = PnP_ADMM(y, param)  (PnP_ADMM.m:1).  Returns (x [N,M,s] complex, diag [iters,2] or None, lsqr_iters)."""
+        p = AdmmParams(float(gamma), int(iters), float(cg_tol), int(cg_maxit), SOLVER_LSQR if solver == "lsqr" else SOLVER_DIRECT,
+                       int(bool(multi_level)), float(noise_std), int(bool(want_diag)))
+        yb = _cbuf(y)
+        if yb.size != self.m:
+            raise ValueError(f"y must have {self.m} elements")
+        x0b = _cbuf(x0) if x0 is not None else None
+        gtb = _cbuf(gt) if gt is not None else None
+        x = np.empty(self.N * self.M * self.s, np.complex128)
+        diag = np.zeros(2 * max(iters, 1), np.float64) if want_diag else None
+        li = np.zeros(max(iters, 1), np.int32)
+        self._check(self.L.qmri_pnp_admm(self.h, _vp(yb), C.byref(p), _vp(x0b), _vp(gtb), _vp(x),
+                                         diag.ctypes.data_as(C.POINTER(C.c_double)) if diag is not None else None,
+                                         li.ctypes.data_as(C.POINTER(C.c_int32))))
+        return (x.reshape((self.N, self.M, self.s), order="F"),
+                diag[: 2 * iters].reshape(iters, 2) if diag is not None else None, li[:iters])
+
+    # -- dictionary ----------------------------------------------------------------------------------
+    def set_dictionary(self, D, normD, lut):
+        D = np.asarray(D, dtype=np.float32)
+        lut = np.asarray(lut, dtype=np.float32)
+        K, s = D.shape
+        Q = lut.shape[1]
+        Df = np.ascontiguousarray(D.ravel(order="F"))
+        lf = np.ascontiguousarray(lut.ravel(order="F"))
+        nd = np.ascontiguousarray(normD, dtype=np.float32)
+        f = C.POINTER(C.c_float)
+        self._check(self.L.qmri_set_dictionary(self.h, K, s, Q, Df.ctypes.data_as(f), nd.ctypes.data_as(f), lf.ctypes.data_as(f)))
+        self.dict_shape = (K, s, Q)
+
+    def dict_match(self, X, want_mt=True, want_dm=True):
+        """out = mrf_dtm_cpu(dict, data, par)  (mrf_dtm_cpu.m:1).  X [..., s] complex -> dict of arrays."""
+        X = np.asarray(X, dtype=np.complex128)
+        K, s, Q = self.dict_shape
+        if X.shape[-1] != s:
+            raise ValueError("last dimension of X must equal the dictionary's channel count")
+        lead = X.shape[:-1]
+        npix = int(np.prod(lead))
+        xb = np.ascontiguousarray(X.reshape((npix, s), order="F").ravel(order="F"))
+        qmap = np.empty(npix * Q, np.float32)
+        pd = np.empty(2 * npix, np.float32)
+        mt = np.empty(npix, np.float32) if want_mt else None
+        dm = np.empty(npix, np.int32) if want_dm else None
+        f = C.POINTER(C.c_float)
+        self._check(self.L.qmri_dict_match(self.h, _vp(xb), npix, qmap.ctypes.data_as(f), pd.ctypes.data_as(f),
+                                           mt.ctypes.data_as(f) if mt is not None else None,
+                                           dm.ctypes.data_as(C.POINTER(C.c_int32)) if dm is not None else None))
+        out = {"qmap": qmap.reshape(lead + (Q,), order="F"), "pd": pd.view(np.complex64).reshape(lead, order="F")}
+        if mt is not None:
+            out["mt"] = mt.reshape(lead, order="F")
+        if dm is not None:
+            out["dm"] = dm.reshape(lead, order="F")
+        return out
+
+    # -- profiling -----------------------------------------------------------------------------------
+    def profile_enable(self, level: int):
+        self._check(self.L.qmri_profile_enable(self.h, int(level)))
+
+    def profile_get(self, reset=True) -> dict:
+        p = Profile()
+        self._check(self.L.qmri_profile_get(self.h, C.byref(p), int(reset)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}

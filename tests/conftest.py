@@ -1,0 +1,56 @@
+"""pytest configuration: registers the `gpu` marker and shared fixtures.
+
+`-m "not gpu"` tests run in the build container (no GPU): oracle vs golden vectors, host logic, C-ABI symbols.
+`-m gpu` tests are the parity tests proper: they call the HIP path through the C ABI (ctypes) and compare with
+the CPU oracle on the same seeded inputs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def synth():
+    from qmri_pnp_recon_poc_amd import synth as S
+    return S
+
+
+@pytest.fixture(scope="session")
+def engine_mod():
+    from qmri_pnp_recon_poc_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="session")
+def case224(synth, oracle):
+    """cut3-like single slice: 224 x 224 x 10, T = 200, spiral mask, 30 dB measured AWGN."""
+    dic, q, X0 = synth.make_case(N=224, T=200, s=10, K=(128, 64), slice_seed=0)
+    fp, k = oracle.spiral_mask(224, 771, 200)
+    op = oracle.Operator(224, 224, dic["V"], fp, k)
+    y = synth.awgn_measured(op.forward(X0), 30.0, seed=0)
+    return {"dic": dic, "q": q, "X0": X0, "fp": fp, "k": k, "op": op, "y": y}
+
+
+def rel_err(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))

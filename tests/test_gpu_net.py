@@ -1,0 +1,74 @@
+"""GPU parity: the conv engine (UNetRes forward) through the C ABI vs the oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("in_nc", [10, 11])
+def test_tiny_unetres_vs_golden(engine_mod, oracle, in_nc):
+    g = np.load(os.path.join(GOLDEN, f"unetres_tiny_{in_nc}ch.npz"))
+    nc, nb = tuple(int(v) for v in g["nc"]), int(g["nb"])
+    e = engine_mod.Engine(0)
+    e.set_denoiser(g["weights"], 32, 32, in_nc=in_nc, out_nc=10, nc=nc, nb=nb)
+    x = g["x"].transpose(1, 2, 0).astype(np.float64)               # CHW (torch) -> HWC (MATLAB dims)
+    y = e.denoise(x).transpose(2, 0, 1)
+    assert rel_err(y, g["y"]) < 2e-5                               # fp32 network: 2e-5 relative L2
+    net = oracle.Net(g["weights"], in_nc=in_nc, out_nc=10, nc=nc, nb=nb)
+    assert rel_err(y, net.denoise(x).transpose(2, 0, 1)) < 2e-5
+    e.close()
+
+
+def test_full_unetres_64_vs_golden(engine_mod, synth):
+    g = np.load(os.path.join(GOLDEN, "unetres_full_64.npz"))
+    w = synth.random_weights(seed=1)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 64, 64)
+    y = e.denoise(g["x"].transpose(1, 2, 0).astype(np.float64)).transpose(2, 0, 1)
+    assert rel_err(y, g["y"]) < 5e-5
+    e.close()
+
+
+def test_full_unetres_224_vs_golden_and_batch(engine_mod, synth):
+    g = np.load(os.path.join(GOLDEN, "unetres_full_224.npz"))
+    w = synth.structured_weights(seed=2, eps=0.02)
+    x = synth.uniform01(9001, 10 * 224 * 224).astype(np.float32).reshape(10, 224, 224).transpose(1, 2, 0).astype(np.float64)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 224, 224, max_batch=2)
+    y = e.denoise(x).transpose(2, 0, 1)
+    assert rel_err(y[:, 96:128, 64:96], g["crop"]) < 2e-5
+    assert np.abs(y.sum(axis=(1, 2)) - g["ch_sum"]).max() / np.abs(g["ch_sum"]).max() < 1e-5
+    # batch of two (denoiseImage accepts H x W x C x N, denoiseImage_PnP_ADMM.m:13-17): slice 1 = 3 * slice 0
+    xb = np.stack([x, 3.0 * x], axis=3)
+    yb = e.denoise(xb)
+    assert rel_err(yb[..., 0].transpose(2, 0, 1), y) < 1e-6
+    assert rel_err(yb[..., 1], 3.0 * yb[..., 0]) < 2e-5           # positive homogeneity of a bias-free ReLU net
+    e.close()
+
+
+def test_seq_conv_and_residual(engine_mod, oracle, synth):
+    # DnCNN-style stack with residual_noise = true (denoiseImage_PnP_ADMM.m:99-104); no reference definition
+    nb, width = 5, 32
+    n = 32 * 10 * 9 + (nb - 2) * 32 * 32 * 9 + 10 * 32 * 9
+    w = ((synth.uniform01(5, n) - 0.5) * 0.2).astype(np.float32)
+    x = synth.uniform01(6, 48 * 40 * 10).reshape(48, 40, 10)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 48, 40, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1, residual_noise=True)
+    net = oracle.Net(w, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1)
+    assert rel_err(e.denoise(x), net.denoise(x, residual_noise=True)) < 1e-5
+    e.close()
+
+
+def test_denoiser_errors(engine_mod, synth):
+    e = engine_mod.Engine(0)
+    with pytest.raises(engine_mod.QmriError):
+        e.denoise(np.zeros((8, 8, 10)))                           # denoiser not set
+    with pytest.raises(engine_mod.QmriError):
+        e.set_denoiser(np.zeros(100, np.float32), 32, 32)         # wrong blob size
+    with pytest.raises(engine_mod.QmriError):
+        e.set_denoiser(np.zeros(synth.unetres_nparams(), np.float32), 36, 36)   # not divisible by 8
+    e.close()

@@ -1,0 +1,81 @@
+"""GPU parity: forward / adjoint operator and the LSQR x-update through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(engine_mod, case224):
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, case224["dic"]["V"], case224["fp"], case224["k"], max_batch=1)
+    yield e
+    e.close()
+
+
+def test_masks_match_oracle(engine_mod, oracle):
+    fp, k = engine_mod.build_spiral(224, 771, 200)
+    fo, ko = oracle.spiral_mask(224, 771, 200)
+    assert np.array_equal(fp, fo) and np.array_equal(k, ko)
+    fp, k = engine_mod.build_epi(224, 224, 1 / 65, 200)
+    fo, ko = oracle.epi_mask(224, 224, 1 / 65, 200)
+    assert np.array_equal(fp, fo) and np.array_equal(k, ko)
+
+
+def test_forward_adjoint_vs_oracle(eng, case224):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((224, 224, 10)) + 1j * rng.standard_normal((224, 224, 10))
+    y = rng.standard_normal(eng.m) + 1j * rng.standard_normal(eng.m)
+    op = case224["op"]
+    assert rel_err(eng.forward(x), op.forward(x)) < 1e-12          # fp64 both sides; tolerance 1e-12 relative
+    assert rel_err(eng.adjoint(y), op.adjoint(y)) < 1e-12
+    # real-input entry (F.forward(double(X0)), main_recon_tsmis_FFT.m:237)
+    assert rel_err(eng.forward(case224["X0"]), op.forward(case224["X0"])) < 1e-12
+    # adjointness <Ax,y> = <x,A'y>
+    lhs = np.vdot(y, eng.forward(x))
+    rhs = np.vdot(eng.adjoint(y), x)
+    assert abs(lhs - rhs) / abs(lhs) < 1e-12
+
+
+def test_epi_operator_vs_oracle(engine_mod, oracle, case224):
+    fp, k = oracle.epi_mask(224, 224, 1 / 65, 200)
+    V = case224["dic"]["V"]
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, V, fp, k)
+    op = oracle.Operator(224, 224, V, fp, k)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((224, 224, 10)) + 1j * rng.standard_normal((224, 224, 10))
+    y = rng.standard_normal(e.m) + 1j * rng.standard_normal(e.m)
+    assert e.m == 134400
+    assert rel_err(e.forward(x), op.forward(x)) < 1e-12
+    assert rel_err(e.adjoint(y), op.adjoint(y)) < 1e-12
+    e.close()
+
+
+def test_lsqr_xupdate_vs_oracle(eng, case224):
+    op, y = case224["op"], case224["y"]
+    x0 = op.adjoint(y)
+    z = x0.copy()
+    xo, ito, flo, _ = op.lsqr(y, z, 0.05, 1e-4, 100, x0)
+    xg, itg, flg = eng.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    assert (itg, flg) == (ito, flo)                                   # same iteration count and flag
+    assert rel_err(xg, xo) < 1e-10
+    # maxit cap: flag 1, iter == maxit
+    xo2, ito2, flo2, _ = op.lsqr(y, z, 0.05, 1e-12, 5, x0)
+    xg2, itg2, flg2 = eng.xupdate(y, z, 0.05, 1e-12, 5, x0, solver="lsqr")
+    assert (itg2, flg2) == (ito2, flo2) == (5, 1)
+    assert rel_err(xg2, xo2) < 1e-10
+
+
+def test_direct_xupdate_vs_oracle(eng, case224):
+    op, y = case224["op"], case224["y"]
+    x0 = op.adjoint(y)
+    z = 0.9 * x0
+    xd = op.direct(y, z, 0.05)
+    xg, _, _ = eng.xupdate(y, z, 0.05, solver="direct")
+    assert rel_err(xg, xd) < 1e-10
+    # and LSQR at tol 1e-4 lands within the stop-rule ambiguity of the exact minimiser
+    xl, _, _ = eng.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    assert rel_err(xl, xd) < 5e-4
