@@ -37,6 +37,23 @@ class AdmmParams(C.Structure):
 _lib = None
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box exposes every
+    host core but grants a share; running one OpenMP thread per visible core oversubscribes it badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        n = min(n, int(env)) if int(env) > 0 else n
+    return max(1, min(n, 64))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -66,6 +83,7 @@ def lib():
                                      fp, fp, fp, ip, fp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(usable_cpus())
         _lib = L
     return _lib
 
