@@ -1,0 +1,126 @@
+"""CPU: the oracle's restatement of masks, operator, LSQR x-update, ADMM and dictionary match, pinned by the
+survey-derived counts and analytic identities (no MATLAB fixtures exist: section 4)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+
+def test_spiral_mask_survey_counts(oracle):
+    fp, k = oracle.spiral_mask(224, 771, 200)
+    per = np.diff(fp)
+    assert fp[-1] == 123604                                   # m for cut3 spiral
+    assert per.min() == 613 and per.max() == 621
+    assert np.unique(k).size == 11051                         # k-locations ever sampled
+    assert np.array_equal(k[fp[0]:fp[1]], k[fp[48]:fp[49]])   # 48-frame rotation period (7.5 deg * 48 = 360)
+    assert not np.array_equal(k[fp[0]:fp[1]], k[fp[1]:fp[2]])
+    for t in (0, 17, 199):                                    # find(): ascending, duplicates collapsed
+        seg = k[fp[t]:fp[t + 1]]
+        assert np.all(np.diff(seg) > 0)
+        assert seg[0] == 0                                    # DC (fftshift-ed to index 1) is sampled in every frame
+    fp1000, _ = oracle.spiral_mask(224, 771, 1000)            # cut0
+    assert abs(fp1000[-1] / 1000 - 618) < 1
+
+
+def test_epi_mask_survey_counts(oracle):
+    fp, k = oracle.epi_mask(224, 224, 1 / 65, 200)
+    assert fp[-1] == 134400 and np.all(np.diff(fp) == 672)
+    assert np.array_equal(np.unique(k[:fp[1]] % 224), [1, 66, 131])          # rows {2,67,132} 1-based in frame 1
+    assert np.array_equal(np.unique(k[fp[1]:fp[2]] % 224), [2, 67, 132])     # +1 cyclic per frame
+    # wrap-around keeps ascending column-major order inside a frame
+    t = 223 - 130
+    seg = k[fp[t]:fp[t + 1]]
+    assert np.all(np.diff(seg) > 0) and 0 in (seg % 224)
+    # ragged / degenerate inputs
+    fp2, k2 = oracle.epi_mask(8, 4, 1 / 3, 5)
+    assert fp2[-1] == 2 * 4 * 5 and k2.max() < 32
+
+
+def test_fft_and_operator_identities(oracle, case224):
+    op = case224["op"]
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((224, 224, 10)) + 1j * rng.standard_normal((224, 224, 10))
+    y = rng.standard_normal(op.m) + 1j * rng.standard_normal(op.m)
+    X = oracle.fft2(x)
+    assert rel_err(X, np.fft.fft2(x, axes=(0, 1))) < 1e-13                   # fft2 definition
+    assert rel_err(oracle.fft2(X, +1), x) < 1e-13                            # ifft2 carries 1/(NM)
+    Ax, Aty = op.forward(x), op.adjoint(y)
+    assert abs(np.vdot(y, Ax) - np.vdot(Aty, x)) / abs(np.vdot(y, Ax)) < 1e-13      # exact adjoints
+    # numpy restatement of main_recon_tsmis_FFT.m:228 with P rows (t,k) = V(t,:)
+    V, fp, k = case224["dic"]["V"], case224["fp"], case224["k"]
+    Xh = np.fft.fft2(x, axes=(0, 1)).reshape(224 * 224, 10, order="F") / 224.0
+    tt = np.repeat(np.arange(200), np.diff(fp))
+    assert rel_err(Ax, np.einsum("ic,ic->i", V[tt], Xh[k])) < 1e-13
+    # ||A|| <= 1 (orthonormal V) and = 1 along DC for the spiral
+    assert np.linalg.norm(Ax) <= np.linalg.norm(x) * (1 + 1e-12)
+
+
+def test_lsqr_against_closed_form(oracle, case224):
+    op, y = case224["op"], case224["y"]
+    x0 = op.adjoint(y)
+    z = 0.7 * x0
+    xd = op.direct(y, z, 0.05)
+    xl, it, flag, relres = op.lsqr(y, z, 0.05, 1e-4, 100, x0)
+    assert flag == 0 and 5 <= it <= 30                                       # survey: ~16 at tol 1e-4
+    assert rel_err(xl, xd) < 5e-4                                            # stop-rule ambiguity bound
+    xt, it2, flag2, _ = op.lsqr(y, z, 0.05, 1e-12, 200, x0)
+    assert flag2 == 0 and rel_err(xt, xd) < 1e-9                             # tight LSQR reproduces the minimiser
+    # optimality of the closed form: gradient A'(Ax - y) + r (x - z) = 0
+    grad = op.adjoint(op.forward(xd) - y) + 0.05 * (xd - z)
+    assert np.linalg.norm(grad) / np.linalg.norm(op.adjoint(y)) < 1e-10
+    # maxit reached -> flag 1, iter == maxit; exact start -> iter 0
+    _, it3, flag3, _ = op.lsqr(y, z, 0.05, 1e-12, 3, x0)
+    assert (it3, flag3) == (3, 1)
+    _, it4, flag4, _ = op.lsqr(y, z, 0.05, 1e-4, 100, xt)
+    assert flag4 == 0 and it4 <= 1
+
+
+def test_dict_match_semantics(oracle, synth):
+    dic = synth.make_dictionary(T=100, n_t1=16, n_t2=8)
+    D, nd, lut = dic["D"], dic["normD"], dic["lut"].copy()
+    lut[5, 0] = np.nan
+    X = np.zeros((3, 4, 10), np.complex128)
+    X[0, 1] = 2.5 * D[5]                 # exact atom -> index 6 (1-based), pd = 2.5/normD
+    X[1, 2] = (0.3 - 0.4j) * D[77]       # complex scale: ip = D x^H carries conj phase (mrf_dtm_cpu.m:91)
+    o = oracle.dict_match(X, D, nd, lut, want_xfit=True)
+    assert o["dm"][0, 1] == 6 and o["dm"][1, 2] == 78
+    assert o["dm"][0, 0] == 1                                  # all-zero pixel: ties -> first atom (MATLAB max)
+    assert o["qmap"][0, 1, 0] == 0.0                           # NaN -> 0 (:138)
+    assert abs(o["pd"][0, 1] - 2.5 / nd[5]) < 1e-5
+    assert abs(o["pd"][1, 2] - np.conj(0.3 - 0.4j) / nd[77]) < 1e-5
+    assert abs(o["mt"][1, 2] - 0.5) < 1e-6
+    assert np.allclose(o["Xfit"][0, 1], 2.5 * D[5], atol=1e-5)
+    # numpy restatement on random data
+    rng = np.random.default_rng(1)
+    Xr = rng.standard_normal((6, 5, 10)) + 1j * rng.standard_normal((6, 5, 10))
+    ip = D.astype(np.float64) @ np.conj(Xr.reshape(30, 10, order="F").astype(np.complex64).astype(np.complex128)).T
+    dm = np.argmax(np.abs(ip), axis=0) + 1
+    o2 = oracle.dict_match(Xr, D, nd, dic["lut"])
+    assert np.mean(o2["dm"].ravel(order="F") == dm) > 0.95     # fp32 vs fp64 near-ties may differ
+
+
+def test_admm_small_runs_and_matches_numpy(oracle, synth):
+    """PnP_ADMM.m:76-146 step by step in numpy (using oracle pieces) vs orc_pnp_admm."""
+    N, T, s = 32, 24, 6
+    dic = synth.make_dictionary(T=T, n_t1=24, n_t2=16, s=s)
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=0), dic)
+    fp, k = oracle.spiral_mask(N, 120, T)
+    op = oracle.Operator(N, N, dic["V"], fp, k)
+    y = synth.awgn_measured(op.forward(X0), 30.0, seed=0)
+    nc = (8, 16, 16, 32)
+    for multi in (False, True):
+        w = synth.structured_weights(in_nc=s + multi, out_nc=s, nc=nc, nb=2, seed=3, eps=0.05)
+        net = oracle.Net(w, in_nc=s + multi, out_nc=s, nc=nc, nb=2)
+        xo, diag, li = oracle.pnp_admm(op, net, y, iters=4, multi_level=multi, gt=X0, want_diag=True)
+        x = op.adjoint(y); v = x.copy(); u = np.zeros_like(x)
+        for it in range(4):
+            x, n_it, _, _ = op.lsqr(y, v - u, 0.05, 1e-4, 100, x)
+            assert n_it == li[it]
+            assert abs(np.linalg.norm(y - op.forward(x)) / np.linalg.norm(y) - diag[it, 0]) < 1e-12
+            w_ = np.real(x + u); lo, hi = w_.min(), w_.max()
+            w_ = (w_ - lo) / (hi - lo)
+            if multi:
+                w_ = np.concatenate([w_, np.full((N, N, 1), 0.01)], axis=2)
+            v = net.denoise(w_) * (hi - lo) + lo
+            u = u + x - v
+        assert rel_err(xo, x) < 1e-12
