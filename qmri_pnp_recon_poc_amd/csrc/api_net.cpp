@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <cstdlib>
 
 void qmri_free_operator(qmri_ctx* ctx);
 int qmri_prepare_direct(qmri_ctx* ctx, double r);
@@ -36,10 +37,23 @@ extern "C" size_t qmri_net_nparams(const qmri_net_desc* d) {
 
 void qmri_free_net(qmri_ctx* ctx) {
     NetPlan& p = ctx->net;
-    for (ConvLayer& L : p.layers) if (L.wp) (void)hipFree(L.wp);
-    float* bufs[] = { p.x1, p.x2, p.x3, p.x4, p.a, p.t1, p.in32, p.out32 };
-    for (float* b : bufs) if (b) (void)hipFree(b);
+    for (ConvLayer& L : p.layers) { if (L.wp) (void)hipFree(L.wp); if (L.d_tab) (void)hipFree(L.d_tab); }
+    for (float* b : p.allocs) if (b) (void)hipFree(b);
+    if (p.d_counter) (void)hipFree(p.d_counter);
+    if (p.d_stamps) (void)hipFree(p.d_stamps);
     p = NetPlan();
+}
+
+// zero-initialised padded activation tensor; Cal channels are allocated (>= C; the extra ones stay zero forever because
+// kernels only ever write channels < C and plane interiors), plus slack for tiles that overhang the image
+static int alloc_tensor(qmri_ctx* ctx, PTensor& t, int C, int Cal, int H, int W, size_t B) {
+    t.C = C; t.Cal = std::max(C, Cal); t.H = H; t.W = W;
+    const size_t count = B * t.batch_stride() + 8192;
+    hipError_t e = hipMalloc((void**)&t.p, count * sizeof(float));
+    if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(float), hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+    ctx->net.allocs.push_back(t.p);
+    QMRI_HIP(ctx, hipMemset(t.p, 0, count * sizeof(float)));
+    return QMRI_OK;
 }
 
 static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const float*& w) {
@@ -89,8 +103,7 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     p.desc = *desc; p.H = H; p.W = W; p.maxB = max_batch;
     const float* w = weights;
     const int nb = desc->nb;
-    const size_t HW = (size_t)H * W, B = (size_t)max_batch;
-    size_t scratch = 0;
+    const size_t B = (size_t)max_batch;
     if (desc->arch == QMRI_ARCH_UNETRES) {
         const int32_t* nc = desc->nc;
         QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, nc[0], w));
@@ -104,11 +117,15 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
             for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[l - 1], nc[l - 1], w));
         }
         QMRI_TRY(add_layer(ctx, CONV_3X3, nc[0], desc->out_nc, w));
-        for (int l = 0; l < 4; ++l) scratch = std::max(scratch, (size_t)nc[l] * (HW >> (2 * l)));
-        QMRI_TRY(dev_alloc(ctx, &p.x1, B * nc[0] * HW));
-        QMRI_TRY(dev_alloc(ctx, &p.x2, B * nc[1] * (HW >> 2)));
-        QMRI_TRY(dev_alloc(ctx, &p.x3, B * nc[2] * (HW >> 4)));
-        QMRI_TRY(dev_alloc(ctx, &p.x4, B * nc[3] * (HW >> 6)));
+        for (int l = 0; l < 4; ++l) {
+            // channels allocated = the largest padded Cin of any layer that reads a level-l tensor
+            int cal = conv_cin_pad(CONV_3X3, nc[l]);
+            if (l < 3) cal = std::max(cal, conv_cin_pad(CONV_DOWN, nc[l]));
+            if (l > 0) cal = std::max(cal, conv_cin_pad(CONV_UP, nc[l]));
+            QMRI_TRY(alloc_tensor(ctx, p.x[l], nc[l], cal, H >> l, W >> l, B));
+            QMRI_TRY(alloc_tensor(ctx, p.a[l], nc[l], cal, H >> l, W >> l, B));
+            QMRI_TRY(alloc_tensor(ctx, p.t[l], nc[l], cal, H >> l, W >> l, B));
+        }
     } else {
         const int width = desc->nc[0];
         if (nb == 1) QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, desc->out_nc, w));
@@ -117,22 +134,25 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
             for (int l = 1; l < nb - 1; ++l) QMRI_TRY(add_layer(ctx, CONV_3X3, width, width, w));
             QMRI_TRY(add_layer(ctx, CONV_3X3, width, desc->out_nc, w));
         }
-        scratch = (size_t)width * HW;
+        QMRI_TRY(alloc_tensor(ctx, p.a[0], width, conv_cin_pad(CONV_3X3, width), H, W, B));
+        QMRI_TRY(alloc_tensor(ctx, p.t[0], width, conv_cin_pad(CONV_3X3, width), H, W, B));
     }
-    QMRI_TRY(dev_alloc(ctx, &p.a, B * scratch));
-    QMRI_TRY(dev_alloc(ctx, &p.t1, B * scratch));
-    QMRI_TRY(dev_alloc(ctx, &p.in32, B * desc->in_nc * HW));
-    QMRI_TRY(dev_alloc(ctx, &p.out32, B * desc->out_nc * HW));
+    QMRI_TRY(alloc_tensor(ctx, p.in32, desc->in_nc, conv_cin_pad(CONV_3X3, desc->in_nc), H, W, B));
+    QMRI_TRY(alloc_tensor(ctx, p.out32, desc->out_nc, desc->out_nc, H, W, B));
+    QMRI_TRY(dev_alloc(ctx, &p.d_counter, (size_t)1));
+    QMRI_HIP(ctx, hipMemset(p.d_counter, 0, sizeof(unsigned)));
+    if (getenv("QMRI_CONV_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_stamps, 4096 * 11 * sizeof(unsigned long long))); }
+    p.counter_base = 0;
     p.ready = true;
     return QMRI_OK;
 }
 
 // one conv launch with optional per-launch timing of the dominant kernel (profile level 2)
-static int run_conv(qmri_ctx* ctx, const ConvLayer& L, int B, int H, int W, const float* in, float* out, const float* add1,
-                    const float* add2, int relu) {
-    const bool timed = ctx->prof_level >= 2 && L.kind == CONV_3X3 && L.Cin >= 64 && L.Cout >= 64;
+static int run_conv(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
+                    const PTensor* add2, int relu) {
+    const bool timed = ctx->prof_level >= 2 && (L.kind == CONV_3X3 || L.kind == CONV_3X3N) && L.Cin >= 64 && L.Cout >= 64;
     if (timed) QMRI_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    QMRI_TRY(conv_launch(ctx, L, B, H, W, in, out, add1, add2, relu));
+    QMRI_TRY(conv_launch(ctx, L, B, in, out, add1, add2, relu));
     if (timed) {
         QMRI_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         QMRI_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
@@ -146,15 +166,46 @@ static int run_conv(qmri_ctx* ctx, const ConvLayer& L, int B, int H, int W, cons
 
 // nb ResBlocks: cur <- cur + conv(relu(conv(cur)))  (basicblock.py:211-223).  `src` is the block input of the first
 // ResBlock (may be a skip tensor that must stay intact); results land in `cur`; `skip` is added by the last conv.
-static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, int H, int W, const float* src, float* cur, float* tmp,
-                         const float* skip) {
-    const NetPlan& p = ctx->net;
-    const float* in = src;
+static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, const PTensor& src, const PTensor& cur, const PTensor& tmp,
+                         const PTensor* skip) {
+    NetPlan& p = ctx->net;
+    const PTensor* in = &src;
     for (int b = 0; b < nb; ++b) {
-        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, in, tmp, nullptr, nullptr, 1));
-        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, tmp, cur, in, (b == nb - 1) ? skip : nullptr, 0));
-        in = cur;
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, *in, tmp, nullptr, nullptr, 1));
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, tmp, cur, in, (b == nb - 1) ? skip : nullptr, 0));
+        in = &cur;
     }
+    return QMRI_OK;
+}
+
+// network forward on the context's padded tensors: in32 -> out32
+static int net_forward_padded(qmri_ctx* ctx, int B) {
+    NetPlan& p = ctx->net;
+    const int nb = p.desc.nb;
+    size_t li = 0;
+    if (p.desc.arch == QMRI_ARCH_SEQ_CONV) {
+        const size_t nl = p.layers.size();
+        const PTensor* in = &p.in32;
+        const PTensor* bufs[2] = { &p.a[0], &p.t[0] };
+        for (size_t l = 0; l < nl; ++l) {
+            const PTensor* out = (l == nl - 1) ? &p.out32 : bufs[l & 1];
+            QMRI_TRY(run_conv(ctx, p.layers[l], B, *in, *out, nullptr, nullptr, l != nl - 1));
+            in = out;
+        }
+        return QMRI_OK;
+    }
+    // UNetRes.forward, network_unet.py:106-117
+    QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.in32, p.x[0], nullptr, nullptr, 0));                       // x1 = m_head(x0)
+    for (int l = 0; l < 3; ++l) {                                                                          // x_{l+2} = m_down_{l+1}(x_{l+1})
+        QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[l], p.a[l], p.t[l], nullptr));
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[l], p.x[l + 1], nullptr, nullptr, 0));
+    }
+    QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[3], p.a[3], p.t[3], &p.x[3]));                               // m_body(x4) + x4
+    for (int l = 3; l > 0; --l) {                                                                          // m_up_l(x + x_{l+1})
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[l], p.a[l - 1], nullptr, nullptr, 0));               // transposed conv
+        QMRI_TRY(run_resblocks(ctx, li, nb, B, p.a[l - 1], p.a[l - 1], p.t[l - 1], &p.x[l - 1]));
+    }
+    QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[0], p.out32, nullptr, nullptr, 0));                      // m_tail(x + x1)
     return QMRI_OK;
 }
 
@@ -164,35 +215,9 @@ extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, flo
     NetPlan& p = ctx->net;
     if (!p.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
     QMRI_CHECK_ARG(ctx, d_in && d_out && B >= 1 && B <= p.maxB, "qmri_net_forward_dev arguments / batch > max_batch");
-    const int H = p.H, W = p.W, nb = p.desc.nb;
-    size_t li = 0;
-    if (p.desc.arch == QMRI_ARCH_SEQ_CONV) {
-        const size_t nl = p.layers.size();
-        const float* in = d_in;
-        float* bufs[2] = { p.a, p.t1 };
-        for (size_t l = 0; l < nl; ++l) {
-            float* out = (l == nl - 1) ? d_out : bufs[l & 1];
-            QMRI_TRY(run_conv(ctx, p.layers[l], B, H, W, in, out, nullptr, nullptr, l != nl - 1));
-            in = out;
-        }
-        return QMRI_OK;
-    }
-    // UNetRes.forward, network_unet.py:106-117
-    QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, d_in, p.x1, nullptr, nullptr, 0));                    // x1 = m_head(x0)
-    float* skips[4] = { p.x1, p.x2, p.x3, p.x4 };
-    for (int l = 0; l < 3; ++l) {                                                                          // x_{l+2} = m_down_{l+1}(x_{l+1})
-        QMRI_TRY(run_resblocks(ctx, li, nb, B, H >> l, W >> l, skips[l], p.a, p.t1, nullptr));
-        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H >> l, W >> l, p.a, skips[l + 1], nullptr, nullptr, 0));
-    }
-    QMRI_TRY(run_resblocks(ctx, li, nb, B, H >> 3, W >> 3, p.x4, p.a, p.t1, p.x4));                         // m_body(x4) + x4
-    float* cur = p.a;
-    float* tmp = p.t1;
-    for (int l = 3; l > 0; --l) {                                                                          // m_up_l(x + x_{l+1})
-        QMRI_TRY(run_conv(ctx, p.layers[li++], B, H >> l, W >> l, cur, tmp, nullptr, nullptr, 0));         // transposed conv
-        std::swap(cur, tmp);
-        QMRI_TRY(run_resblocks(ctx, li, nb, B, H >> (l - 1), W >> (l - 1), cur, cur, tmp, skips[l - 1]));
-    }
-    QMRI_TRY(run_conv(ctx, p.layers[li++], B, H, W, cur, d_out, nullptr, nullptr, 0));                     // m_tail(x + x1)
+    QMRI_TRY(ew_launch_pack(ctx, B, p.desc.in_nc, p.H, p.W, d_in, 0, p.in32));
+    QMRI_TRY(net_forward_padded(ctx, B));
+    QMRI_TRY(ew_launch_unpack(ctx, B, p.desc.out_nc, p.H, p.W, p.out32, p.in32, 0, d_out, 0));
     return QMRI_OK;
 }
 
@@ -214,9 +239,9 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
     int st = QMRI_OK;
     do {
         if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
-        if ((st = ew_launch_cast(ctx, nin, d_io, p.in32)) != QMRI_OK) break;                   // im2single: :72-77
-        if ((st = qmri_net_forward_dev(ctx, p.in32, B, p.out32)) != QMRI_OK) break;            // activations(...): :88
-        if ((st = ew_launch_denoise_out(ctx, HW, p.desc.out_nc, C, B, p.out32, p.in32, p.desc.residual_noise, d_io)) != QMRI_OK) break;
+        if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32)) != QMRI_OK) break;         // im2single: :72-77
+        if ((st = net_forward_padded(ctx, B)) != QMRI_OK) break;                               // activations(...): :88
+        if ((st = ew_launch_unpack(ctx, B, p.desc.out_nc, H, W, p.out32, p.in32, p.desc.residual_noise, d_io, 1)) != QMRI_OK) break;
         if (hipMemcpyAsync(out, d_io, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
     } while (0);
@@ -305,15 +330,15 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         }
         // Step 2 (PnP_ADMM.m:115-138): v = real(x+uold) -> [0,1] -> net -> undo
         tm.start();
-        QMRI_TRY(ew_launch_minmax_normalise(ctx, B, n, plane, net.desc.in_nc, multi, prm->noise_std, o.d_x, o.d_u, o.d_mm, o.d_norm,
+        QMRI_TRY(ew_launch_minmax_normalise(ctx, B, n, (int)plane, o.N, o.s, multi, prm->noise_std, o.d_x, o.d_u, o.d_mm, o.d_norm,
                                             o.ls.nblk_z, net.in32));
         tm.stop(ctx->prof.ms_elementwise);
         tm.start();
-        QMRI_TRY(qmri_net_forward_dev(ctx, net.in32, B, net.out32));
+        QMRI_TRY(net_forward_padded(ctx, B));
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
         tm.start();
-        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.d_vv));
+        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.d_vv));
         tm.stop(ctx->prof.ms_elementwise);
         ctx->prof.admm_iters += 1;
     }
@@ -493,5 +518,13 @@ extern "C" int qmri_recon_batch(int ndev, const int* devs, int nslices, const qm
     for (auto& t : th) t.join();
     for (int w = 0; w < ndev; ++w)
         if (status[w] != QMRI_OK) { report("device " + std::to_string(devs[w]) + ": " + errs[w]); return status[w]; }
+    return QMRI_OK;
+}
+
+// diagnostic: copy the per-workgroup stamps of the most recent conv launch (see conv_kernels.hip) to the host
+extern "C" int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int nwg) {
+    if (!ctx || !ctx->net.d_stamps) return QMRI_ERR_STATE;
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    QMRI_HIP(ctx, hipMemcpy(out, ctx->net.d_stamps, (size_t)4096 * 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QMRI_OK;
 }

@@ -63,10 +63,10 @@ __global__ __launch_bounds__(NT) void k_minmax(size_t n, const double2* __restri
 }
 
 // pass 2: reduce the partials (min/max are order independent), normalise, cast to single, append noise map
-__global__ __launch_bounds__(NT) void k_normalise(size_t n, size_t plane, int in_nc, int multi_level, double noise_std,
+__global__ __launch_bounds__(NT) void k_normalise(size_t n, int plane, int H, int s, int multi_level, double noise_std,
                                                    const double2* __restrict__ x, const double2* __restrict__ u,
                                                    const double* __restrict__ mm, int nblk, double* __restrict__ norm,
-                                                   float* __restrict__ in32) {
+                                                   float* __restrict__ in32, int php, int pplane, size_t pbs) {
     __shared__ double sh[2 * NT / 64];
     const int b = blockIdx.y;
     double lo = INFINITY, hi = -INFINITY;
@@ -79,20 +79,26 @@ __global__ __launch_bounds__(NT) void k_normalise(size_t n, size_t plane, int in
     if (blockIdx.x == 0 && threadIdx.x == 0) { norm[2 * b] = lo; norm[2 * b + 1] = range; }
     const size_t chunk = (n + gridDim.x - 1) / gridDim.x;
     const size_t i0 = (size_t)blockIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
-    float* dst = in32 + (size_t)b * in_nc * plane;
+    float* dst = in32 + (size_t)b * pbs;                 // padded planes [c][w+1][h+1], zero halo untouched
     for (size_t i = i0 + threadIdx.x; i < i1; i += NT) {
         const double v = x[(size_t)b * n + i].x + u[(size_t)b * n + i].x;
-        dst[i] = (float)((v - lo) / range);
+        const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
+        const int w = rem / H, h = rem - w * H;
+        dst[(size_t)c * pplane + (size_t)(w + 1) * php + h + 1] = (float)((v - lo) / range);
     }
     if (multi_level) {
-        const size_t c0 = (size_t)blockIdx.x * ((plane + gridDim.x - 1) / gridDim.x);
-        const size_t c1 = (c0 + (plane + gridDim.x - 1) / gridDim.x < plane) ? c0 + (plane + gridDim.x - 1) / gridDim.x : plane;
-        for (size_t i = c0 + threadIdx.x; i < c1; i += NT) dst[n + i] = (float)noise_std;
+        const int per = (plane + gridDim.x - 1) / gridDim.x;
+        const int c0 = blockIdx.x * per, c1 = (c0 + per < plane) ? c0 + per : plane;
+        for (int i = c0 + threadIdx.x; i < c1; i += NT) {
+            const int w = i / H, h = i - w * H;
+            dst[(size_t)s * pplane + (size_t)(w + 1) * php + h + 1] = (float)noise_std;
+        }
     }
 }
 
 // v = double(I)*range + min ;  uold = uold + x - v     (I = CNN output, or input - CNN output)
-__global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, size_t in_stride, const float* __restrict__ out32,
+__global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, int plane, int H, int php, int pplane, size_t out_bs,
+                                                          size_t in_bs, const float* __restrict__ out32,
                                                           const float* __restrict__ in32, int residual_noise,
                                                           const double* __restrict__ norm, const double2* __restrict__ x,
                                                           double2* __restrict__ u, double2* __restrict__ v) {
@@ -100,8 +106,11 @@ __global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, size_t in_str
     const double lo = norm[2 * b], range = norm[2 * b + 1];
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
-    float I = out32[(size_t)b * n + i];
-    if (residual_noise) I = in32[(size_t)b * in_stride + i] - I;
+    const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
+    const int w = rem / H, h = rem - w * H;
+    const size_t pi = (size_t)c * pplane + (size_t)(w + 1) * php + h + 1;
+    float I = out32[(size_t)b * out_bs + pi];
+    if (residual_noise) I = in32[(size_t)b * in_bs + pi] - I;
     const double vv = (double)I * range + lo;
     const double2 xv = x[(size_t)b * n + i];
     double2 uv = u[(size_t)b * n + i];
@@ -151,20 +160,32 @@ __global__ __launch_bounds__(NT) void k_diag_final(const LsqrState* __restrict__
     }
 }
 
-__global__ __launch_bounds__(NT) void k_cast_d2f(size_t count, const double* __restrict__ in, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i < count) out[i] = (float)in[i];
-}
-
-__global__ __launch_bounds__(NT) void k_denoise_out(size_t plane, int out_nc, int in_nc, const float* __restrict__ out32,
-                                                     const float* __restrict__ in32, int residual_noise,
-                                                     double* __restrict__ out) {
+// compact [B][C][W][H] (double or float) -> padded planes (im2single of a double is a cast, denoiseImage_PnP_ADMM.m:72-77)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_pack(size_t count, int C, int plane, int H, int php, int pplane, size_t pbs,
+                                              const T* __restrict__ in, float* __restrict__ out) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= plane * out_nc) return;
-    float I = out32[(size_t)b * out_nc * plane + i];
-    if (residual_noise) I = in32[(size_t)b * in_nc * plane + i] - I;      // denoiseImage_PnP_ADMM.m:101
-    out[(size_t)b * out_nc * plane + i] = (double)I;
+    if (i >= count) return;
+    const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
+    const int w = rem / H, h = rem - w * H;
+    out[(size_t)b * pbs + (size_t)c * pplane + (size_t)(w + 1) * php + h + 1] = (float)in[(size_t)b * count + i];
+}
+
+// padded network output -> compact; optional residual I = input - CNN(input) (denoiseImage_PnP_ADMM.m:99-104,111-115)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_unpack(size_t count, int plane, int H, int php, int pplane, size_t out_bs, size_t in_bs,
+                                                const float* __restrict__ out32, const float* __restrict__ in32,
+                                                int residual_noise, T* __restrict__ out) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= count) return;
+    const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
+    const int w = rem / H, h = rem - w * H;
+    const size_t pi = (size_t)c * pplane + (size_t)(w + 1) * php + h + 1;
+    float I = out32[(size_t)b * out_bs + pi];
+    if (residual_noise) I = in32[(size_t)b * in_bs + pi] - I;
+    out[(size_t)b * count + i] = (T)I;
 }
 
 __global__ __launch_bounds__(NT) void k_real_to_complex(size_t count, const double* __restrict__ in, double2* __restrict__ out) {
@@ -174,20 +195,20 @@ __global__ __launch_bounds__(NT) void k_real_to_complex(size_t count, const doub
 
 }  // namespace
 
-int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, size_t plane, int in_nc, int multi_level, double noise_std,
-                               const double2* x, const double2* u, double* mm, double* norm, int nblk, float* in32) {
+int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H, int s, int multi_level, double noise_std,
+                               const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32) {
     k_minmax<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, x, u, mm);
-    k_normalise<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, plane, in_nc, multi_level, noise_std, x, u, mm, nblk, norm, in32);
+    k_normalise<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, plane, H, s, multi_level, noise_std, x, u, mm, nblk, norm, in32.p,
+                                                             in32.H + 2, (int)in32.plane(), in32.batch_stride());
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
 
-int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, const float* out32, const float* in32, int residual_noise,
-                               const double* norm, const double2* x, double2* u, double2* v) {
-    // in32 holds in_nc planes per slice; its slice stride is passed through ctx->net
-    const size_t in_stride = (size_t)ctx->net.desc.in_nc * ctx->net.H * ctx->net.W;
-    k_unnormalise_dual<<<dim3((unsigned)((n + NT - 1) / NT), B), dim3(NT), 0, ctx->stream>>>(n, in_stride, out32, in32,
-                                                                                             residual_noise, norm, x, u, v);
+int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H, const PTensor& out32, const PTensor& in32,
+                               int residual_noise, const double* norm, const double2* x, double2* u, double2* v) {
+    k_unnormalise_dual<<<dim3((unsigned)((n + NT - 1) / NT), B), dim3(NT), 0, ctx->stream>>>(
+        n, plane, H, out32.H + 2, (int)out32.plane(), out32.batch_stride(), in32.batch_stride(), out32.p, in32.p, residual_noise, norm,
+        x, u, v);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -203,16 +224,27 @@ int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, con
     return QMRI_OK;
 }
 
-int ew_launch_cast(qmri_ctx* ctx, size_t count, const double* in, float* out) {
-    k_cast_d2f<<<dim3((unsigned)((count + NT - 1) / NT)), dim3(NT), 0, ctx->stream>>>(count, in, out);
+int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst) {
+    const size_t count = (size_t)C * H * W;
+    dim3 grid((unsigned)((count + NT - 1) / NT), B), blk(NT);
+    if (src_is_double)
+        k_pack<double><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.H + 2, (int)dst.plane(), dst.batch_stride(), (const double*)src, dst.p);
+    else
+        k_pack<float><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.H + 2, (int)dst.plane(), dst.batch_stride(), (const float*)src, dst.p);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
 
-int ew_launch_denoise_out(qmri_ctx* ctx, size_t plane, int out_nc, int in_nc, int B, const float* out32, const float* in32,
-                          int residual_noise, double* out) {
-    k_denoise_out<<<dim3((unsigned)((plane * out_nc + NT - 1) / NT), B), dim3(NT), 0, ctx->stream>>>(plane, out_nc, in_nc, out32,
-                                                                                                   in32, residual_noise, out);
+int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& out32, const PTensor& in32, int residual_noise,
+                     void* dst, int dst_is_double) {
+    const size_t count = (size_t)C * H * W;
+    dim3 grid((unsigned)((count + NT - 1) / NT), B), blk(NT);
+    if (dst_is_double)
+        k_unpack<double><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.H + 2, (int)out32.plane(), out32.batch_stride(),
+                                                       in32.batch_stride(), out32.p, in32.p, residual_noise, (double*)dst);
+    else
+        k_unpack<float><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.H + 2, (int)out32.plane(), out32.batch_stride(),
+                                                      in32.batch_stride(), out32.p, in32.p, residual_noise, (float*)dst);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }

@@ -91,25 +91,38 @@ struct LsqrDev {
 // ---------------------------------------------------------------------------------------------------
 // denoiser: one packed layer of the conv engine
 // ---------------------------------------------------------------------------------------------------
-enum ConvKind { CONV_3X3 = 0, CONV_DOWN = 1, CONV_UP = 2 };
+enum ConvKind { CONV_3X3 = 0, CONV_DOWN = 1, CONV_UP = 2, CONV_3X3N = 3 };   // 3X3N: 3x3 with 32-channel chunks (Cin <= 64)
 struct ConvLayer {
     ConvKind kind;
     int Cin, Cout;           // logical channels (UP: Cout = real output channels)
-    int cin_pad, n_ct;       // padded input channels, number of 32*MT-row output tiles
+    int cin_pad, n_ct;       // padded input channels, number of 32-row output tiles in the packed weights
     int MT;                  // 32-row MFMA tiles per wave
     float* wp;               // packed weights (device)
     size_t wp_floats;
+    void* d_tab;             // tile table {cout tile, ow0, oh0, batch} for (tab_B, tab_MT)
+    int tab_B, tab_MT;
+};
+
+// activation tensor in HBM: [B][Cal][W+2][H+2] fp32, h fastest, permanent zero halo, channels >= C are zero
+struct PTensor {
+    float* p = nullptr;
+    int C = 0, Cal = 0, H = 0, W = 0;
+    size_t plane() const { return (size_t)(H + 2) * (W + 2); }
+    size_t batch_stride() const { return (size_t)Cal * plane(); }
 };
 
 struct NetPlan {
     qmri_net_desc desc{};
     int H = 0, W = 0, maxB = 0;
     std::vector<ConvLayer> layers;
-    // activation buffers (device, fp32, [B][C][W][H])
-    float* x1 = nullptr; float* x2 = nullptr; float* x3 = nullptr; float* x4 = nullptr;
-    float* a = nullptr; float* t1 = nullptr;
-    float* in32 = nullptr;   // [B][in_nc][W][H] normalised network input
-    float* out32 = nullptr;  // [B][out_nc][W][H]
+    // activation buffers (device, padded planes): per UNet level the skip tensor x and two work tensors a, t
+    PTensor x[4], a[4], t[4];
+    PTensor in32;            // normalised network input (in_nc channels, allocated up to the head's padded Cin)
+    PTensor out32;           // network output (out_nc channels)
+    std::vector<float*> allocs;
+    unsigned* d_counter = nullptr;   // tile-queue counter of the persistent conv kernels
+    unsigned counter_base = 0;       // host mirror of its value after the launches issued so far
+    void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
     bool ready = false;
 };
 
@@ -184,20 +197,21 @@ int dc_launch_sort_y(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, c
 int dc_launch_prepare_z(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* v, const double2* u,
                         double2* z);
 // elementwise ADMM stages (PnP_ADMM.m:115-121,138,144)
-int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, size_t plane, int in_nc, int multi_level, double noise_std,
-                               const double2* x, const double2* u, double* mm, double* norm, int nblk, float* in32);
-int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, const float* out32, const float* in32, int residual_noise,
-                               const double* norm, const double2* x, double2* u, double2* v);
+int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H, int s, int multi_level, double noise_std,
+                               const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32);
+int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H, const PTensor& out32, const PTensor& in32,
+                               int residual_noise, const double* norm, const double2* x, double2* u, double2* v);
 int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* x, const double2* gt,
                    double* pd, double* diag_slot, int iters_total, int it);
-int ew_launch_cast(qmri_ctx* ctx, size_t count, const double* in, float* out);
-int ew_launch_denoise_out(qmri_ctx* ctx, size_t plane, int out_nc, int in_nc, int B, const float* out32, const float* in32,
-                          int residual_noise, double* out);
+int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst);
+int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& out32, const PTensor& in32, int residual_noise,
+                     void* dst, int dst_is_double);
 int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out);
 
 // conv engine (conv_kernels.hip)
-int conv_launch(qmri_ctx* ctx, const ConvLayer& L, int B, int H, int W, const float* in, float* out,
-                const float* add1, const float* add2, int relu_out);
+int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
+                const PTensor* add2, int relu_out);
+int conv_cin_pad(ConvKind kind, int Cin);
 size_t conv_pack_weights(const ConvLayer& L, const float* w_src, std::vector<float>& packed);
 void conv_plan_layer(ConvLayer& L, ConvKind kind, int Cin, int Cout);
 
