@@ -278,6 +278,9 @@ __global__ __launch_bounds__(NT, 4) void k_conv(const ConvArgs A) {
             for (int c = 0; c < nch; ++c) {
                 __syncthreads();
                 const float* bt = inbuf + (sp & 1) * (CC * PL) + b_base;
+                float bnxt[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bnxt[jj] = bt[2 * jj * PL];      // unit 0: tap (0,0), pairs 0..3
                 unsigned wnxt[MT];                                       // weights of the step after this one
                 if (c + 1 < nch) {
 #pragma unroll
@@ -299,14 +302,23 @@ __global__ __launch_bounds__(NT, 4) void k_conv(const ConvArgs A) {
                     for (int mt = 0; mt < MT; ++mt)
                         wload(a[un % R][mt], (un < U) ? wcur[mt] + un * 1024 : wnxt[mt] + (un - U) * 1024, A.wp);
                     if (MT == 2) wwait<LA * MT>(a[u % R][0], a[u % R][MT - 1]); else wwait<LA * MT>(a[u % R][0]);
-                    const int t = u / G, g = u - t * G;
-                    const int kh = t / TW, kw = t - kh * TW;
+                    // B operands of unit u were read from LDS one unit ago (bcur); read unit u+1's now (bnxt) so the
+                    // LDS latency hides behind this unit's MFMAs instead of sitting in front of each of them
+                    float bcur[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) bcur[jj] = bnxt[jj];
+                    if (u + 1 < U) {
+                        const int t1 = (u + 1) / G, g1 = (u + 1) - t1 * G;
+                        const int kh1 = t1 / TW, kw1 = t1 - kh1 * TW;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) bnxt[jj] = bt[2 * (4 * g1 + jj) * PL + kw1 * IH + kh1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                   // keep those reads ABOVE this unit's MFMAs
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const float bv = bt[2 * (4 * g + jj) * PL + kw * IH + kh];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u % R][mt][jj], bv, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u % R][mt][jj], bcur[jj], acc[mt], 0, 0, 0);
                     }
                 }
 #pragma unroll
@@ -355,7 +367,8 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
     // two MFMA row tiles per wave when the layer still has several tiles per workgroup slot that way
     const long t2 = (long)(n32 / 2) * n_pt * B;
     const bool is3 = (KIND == CONV_3X3 || KIND == CONV_3X3N);           // the six 2x2 layers always run one row tile per wave
-    const int MT = (is3 && n32 % 2 == 0 && t2 >= 1024) ? 2 : 1;
+    static const long mt2_min = getenv("QMRI_CONV_MT2") ? atol(getenv("QMRI_CONV_MT2")) : 1024;
+    const int MT = (is3 && n32 % 2 == 0 && t2 >= mt2_min) ? 2 : 1;
     const int n_ctiles = n32 / MT, ntiles = n_ctiles * n_pt * B;
     if (L.tab_B != B || L.tab_MT != MT || !L.d_tab) {                  // tile table: cout tile fastest (shared input tile -> L2 hits)
         std::vector<int4> tab((size_t)ntiles);
@@ -392,7 +405,8 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         int nb = 0;
         if (MT == 2) QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2>, NT, 0));
         else QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_conv<KIND, 1>, NT, 0));
-        occ[MT - 1] = std::max(1, std::min(nb, 2));
+        static const int occ_cap = getenv("QMRI_CONV_OCC") ? atoi(getenv("QMRI_CONV_OCC")) : 2;
+        occ[MT - 1] = std::max(1, std::min(nb, occ_cap));
     }
     const int grid = std::min(ntiles, ncu * occ[MT - 1]);
     // every workgroup issues (tiles it processes + 2) fetches, so a launch advances the counter by ntiles + 2*grid
