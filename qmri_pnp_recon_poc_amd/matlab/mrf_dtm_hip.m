@@ -1,0 +1,17 @@
+function out = mrf_dtm_hip(dict, data, par)
+% MRF_DTM_HIP  Drop-in for  out = mrf_dtm_cpu(dict, data, par)  (main_files/dictionary_matching/mrf_dtm_cpu.m:1).
+%   Same fields in, same fields out (qmap, pd, mt, dm, mask, X as gated by par.f.*); par.fp.blockSize is accepted and
+%   ignored (the K x Npix product is never materialised on the GPU).
+datadims = size(data.X);
+T = datadims(end);
+Npix = prod(datadims(1:end-1));
+Q = size(dict.lut, 2);
+qmri_mex('set_dictionary', single(dict.D), single(dict.normD(:)), single(dict.lut));
+[qmap, pd, mt, dm] = qmri_mex('dict_match', complex(double(reshape(data.X, [Npix, T]))), Q);
+if par.f.qout,  out.qmap = reshape(qmap, [datadims(1:end-1), Q]);  out.mask = true(datadims(1:end-1)); end
+if par.f.pdout, out.pd = reshape(pd, [datadims(1:end-1), 1]); end
+if par.f.mtout, out.mt = reshape(mt, [datadims(1:end-1), 1]); end
+if par.f.dmout, out.dm = reshape(single(dm), [datadims(1:end-1), 1]); end
+if par.f.Xout,  out.X = data.X; end
+if par.f.Yout && isfield(data, 'Y'), out.Y = data.Y; end
+end

@@ -1,0 +1,80 @@
+"""GPU: the hot path driven through the mirror of the reference's own plugin surface, reading like
+main_recon_tsmis_FFT.m:220-318 (build F, build net, PnP_ADMM, mrf_dtm_cpu) and checked against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main_recon_flow_small(oracle, synth):
+    from qmri_pnp_recon_poc_amd import reference_api as R
+    N = M = 32
+    dic = synth.make_dictionary(T=24, n_t1=24, n_t2=16, s=6)
+    V = dic["V"]
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=1), dic)
+    nc = (8, 16, 16, 32)
+    w = synth.structured_weights(in_nc=6, out_nc=6, nc=nc, nb=2, seed=3, eps=0.05)
+    # -- Build Gridded FFT Subsampling Operators (main_recon_tsmis_FFT.m:220-229)
+    P = R.setup_subsampling_spiralgrided(N, M, 120, V)
+    F = R.make_F(P)
+    # -- Subsample TSMIs and add noise (:237-246)
+    Y = synth.awgn_measured(F.forward(X0.astype(np.float64)), 30.0, seed=1)
+    # -- TSMI reconstruction (:284-293)
+    param = {"eta": 20, "sigma_squared": 1}
+    param["gamma"] = param["sigma_squared"] / param["eta"]
+    param.update(iter=6, cg_tol=1e-4, F=F, gt_tsmi=X0, X0=F.adjoint(Y), denoiser_type="single_level")
+    param["net"] = R.make_net(w, "single_level", residual_noise=False, H=N, W=M, nc=nc, nb=2, out_nc=6)
+    X = R.PnP_ADMM(Y, param)
+    # -- Dictionary matching (:304-318)
+    par = {"f": dict(qout=1, pdout=1, mtout=0, Xout=0, dmout=1, Yout=0, verbose=1), "fp": {"blockSize": 1e9}}
+    out = R.mrf_dtm_cpu(dic, {"X": X}, par)
+    # oracle
+    fo, ko = oracle.spiral_mask(N, 120, 24)
+    op = oracle.Operator(N, M, V, fo, ko)
+    xo, do, lo = oracle.pnp_admm(op, oracle.Net(w, in_nc=6, out_nc=6, nc=nc, nb=2), Y, iters=6, x0=op.adjoint(Y), gt=X0, want_diag=True)
+    err = rel_err(X, xo)
+    assert err < 1e-4
+    assert np.array_equal(R.PnP_ADMM.last_lsqr_iters, lo)
+    assert np.allclose(R.PnP_ADMM.last_diagnostics, do, rtol=1e-4)
+    oo = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"])
+    same = bool(np.array_equal(out["qmap"], oo["qmap"])) and bool(np.array_equal(out["dm"], oo["dm"].astype(np.float32)))
+    assert same
+    # error behaviour of the denoiser plugin (validateInputImage, denoiseImage_PnP_ADMM.m:119-127)
+    with pytest.raises(ValueError):
+        param["net"](np.full((N, M, 6), np.nan))
+    with pytest.raises(TypeError):
+        param["net"](np.zeros((N, M, 6), complex))
+    with pytest.raises(ValueError):
+        param["net"](np.zeros((N, M, 6, 1, 1)))
+    with pytest.raises(E_QmriError()):
+        param["net"](np.zeros((N, M, 5)))                      # channel count does not match the network
+    R.release()
+
+
+def E_QmriError():
+    from qmri_pnp_recon_poc_amd.engine import QmriError
+    return QmriError
+
+
+def test_epi_multi_level_flow(oracle, synth):
+    from qmri_pnp_recon_poc_amd import reference_api as R
+    N = M = 32
+    dic = synth.make_dictionary(T=30, n_t1=16, n_t2=8, s=5)
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=2), dic)
+    nc = (8, 8, 16, 16)
+    w = synth.structured_weights(in_nc=6, out_nc=5, nc=nc, nb=1, seed=4, eps=0.05)
+    P = R.setup_subsampling_epi(N, M, 1 / 8, dic["V"])
+    F = R.make_F(P)
+    Y = synth.awgn_measured(F.forward(X0), 30.0, seed=2)
+    param = dict(gamma=0.05, iter=5, cg_tol=1e-4, F=F, X0=F.adjoint(Y), denoiser_type="multi_level",
+                 noise_map=R.build_noise_map(0.01, N, M))
+    param["net"] = R.make_net(w, "multi_level", H=N, W=M, nc=nc, nb=1, out_nc=5)
+    X = R.PnP_ADMM(Y, param)
+    fo, ko = oracle.epi_mask(N, M, 1 / 8, 30)
+    op = oracle.Operator(N, M, dic["V"], fo, ko)
+    xo, _, lo = oracle.pnp_admm(op, oracle.Net(w, in_nc=6, out_nc=5, nc=nc, nb=1), Y, iters=5, multi_level=True, noise_std=0.01)
+    err = rel_err(X, xo)
+    assert err < 1e-4
+    R.release()
