@@ -70,7 +70,7 @@ static void free_dev(void* p) { if (p) (void)hipFree(p); }
 void qmri_free_operator(qmri_ctx* ctx) {
     OpHost& o = ctx->op;
     void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
-                     o.ls.st, o.ls.pu[0], o.ls.pu[1], o.ls.pv, o.ls.pz, o.ls.ut, o.ls.ub, o.ls.v, o.ls.d, o.ls.yk,
+                     o.ls.st, o.ls.pu[0], o.ls.pu[1], o.ls.pv[0], o.ls.pv[1], o.ls.pz, o.ls.ut, o.ls.ub, o.ls.v, o.ls.d, o.ls.yk, o.ls.stamps,
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
     for (void* p : ptrs) free_dev(p);
     if (o.h_state) (void)hipHostFree(o.h_state);
@@ -207,11 +207,11 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_CHECK_ARG(ctx, V && frame_ptr && kidx, "V / frame_ptr / kidx must not be NULL");
     QMRI_CHECK_ARG(ctx, N > 0 && M > 0 && s > 0 && T > 0 && max_batch > 0, "N, M, s, T, max_batch must be positive");
     if (N != M || !dc_size_supported(N)) {
-        qmri_set_error(ctx, "grid %d x %d unsupported: the FFT kernels implement square grids of 32, 64, 128, 224, 256 "
+        qmri_set_error(ctx, "grid %d x %d unsupported: the FFT kernels implement square grids of 32, 64, 128, 224 "
                             "(the reference's spiral mask assumes N == M, setup_subsampling_spiralgrided.m:28-31)", N, M);
         return QMRI_ERR_UNSUPPORTED;
     }
-    if (s > 12 || T > 65535 || M > 65535) { qmri_set_error(ctx, "s <= 12 and T, M <= 65535 required (got s=%d T=%d)", s, T); return QMRI_ERR_UNSUPPORTED; }
+    if (s > 10 || T > 65535 || M > 65535) { qmri_set_error(ctx, "s <= 10 and T, M <= 65535 required (got s=%d T=%d)", s, T); return QMRI_ERR_UNSUPPORTED; }
     QMRI_CHECK_ARG(ctx, frame_ptr[0] == 0, "frame_ptr[0] must be 0");
     const int m = frame_ptr[T];
     QMRI_CHECK_ARG(ctx, m > 0, "empty measurement set");
@@ -272,8 +272,14 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_HIP(ctx, hipMemcpy(o.d_kslot, kslot.data(), (size_t)NM * sizeof(int32_t), hipMemcpyHostToDevice));
 
     LsqrDev& ls = o.ls;
-    ls.nblk_h = dc_nblk_h(N, M, s);
-    ls.npu = ls.nblk_h + N;
+    int maxrow = 0;
+    for (int kh = 0; kh < N; ++kh) maxrow = std::max(maxrow, o.kptr_h[(kh + 1) * M] - o.kptr_h[kh * M]);
+    ls.nblk_h = dc_lsqr_nblk_h(M, s);
+    if (!dc_lsqr_plan(N, T, s, maxrow, &ls.ucap, &ls.vcap)) {
+        qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
+        return QMRI_ERR_UNSUPPORTED;
+    }
+    ls.npu = 2 * N;
     ls.nblk_z = 256;
     QMRI_TRY(dev_alloc(ctx, &o.d_tmp, B * n));
     QMRI_TRY(dev_alloc(ctx, &o.d_xa, B * n));
@@ -282,8 +288,13 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &ls.st, B));
     QMRI_TRY(dev_alloc(ctx, &ls.pu[0], B * ls.npu));
     QMRI_TRY(dev_alloc(ctx, &ls.pu[1], B * ls.npu));
-    QMRI_TRY(dev_alloc(ctx, &ls.pv, B * ls.nblk_h));
+    QMRI_TRY(dev_alloc(ctx, &ls.pv[0], B * ls.nblk_h));
+    QMRI_TRY(dev_alloc(ctx, &ls.pv[1], B * ls.nblk_h));
     QMRI_TRY(dev_alloc(ctx, &ls.pz, B * ls.nblk_z));
+    ls.stamps = nullptr;
+    if (const char* e = getenv("QMRI_LSQR_STAMPS")) {
+        if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ls.stamps, (size_t)2 * 512 * 8)); QMRI_HIP(ctx, hipMemset(ls.stamps, 0, 2 * 512 * 8 * 8)); }
+    }
     QMRI_TRY(dev_alloc(ctx, &ls.ut, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &ls.ub, B * n));
     QMRI_TRY(dev_alloc(ctx, &ls.v, B * n));
@@ -321,15 +332,14 @@ extern "C" int qmri_operator_m(const qmri_ctx* ctx, int* m_out) {
 extern "C" int qmri_forward_dev(qmri_ctx* ctx, const void* d_x, void* d_y, int batch) {
     REQUIRE_OP(ctx);
     QMRI_CHECK_ARG(ctx, d_x && d_y && batch >= 1 && batch <= ctx->op.maxB, "qmri_forward_dev arguments / batch > max_batch");
-    return dc_launch_fwd(ctx, qmri_opdev(ctx), ctx->op.ls, DC_PLAIN, batch, (const double2*)d_x, nullptr, ctx->op.d_tmp,
+    return dc_launch_fwd(ctx, qmri_opdev(ctx), ctx->op.ls, DC_PLAIN, batch, (const double2*)d_x, ctx->op.d_tmp,
                          (double2*)d_y, nullptr);
 }
 
 extern "C" int qmri_adjoint_dev(qmri_ctx* ctx, const void* d_y, void* d_x, int batch) {
     REQUIRE_OP(ctx);
     QMRI_CHECK_ARG(ctx, d_x && d_y && batch >= 1 && batch <= ctx->op.maxB, "qmri_adjoint_dev arguments / batch > max_batch");
-    return dc_launch_adj(ctx, qmri_opdev(ctx), ctx->op.ls, DC_PLAIN, batch, (const double2*)d_y, ctx->op.d_tmp, (double2*)d_x,
-                         nullptr);
+    return dc_launch_adj(ctx, qmri_opdev(ctx), batch, (const double2*)d_y, ctx->op.d_tmp, (double2*)d_x);
 }
 
 extern "C" int qmri_forward(qmri_ctx* ctx, const void* x, int x_is_complex, void* y) {
@@ -424,8 +434,8 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     const OpDev op = qmri_opdev(ctx);
     LsqrDev ls = o.ls;
     ls.sr = std::sqrt(r); ls.tol = tol; ls.maxit = maxit; ls.ii = 0;
-    QMRI_TRY(dc_launch_fwd(ctx, op, ls, DC_LSQR_INIT, B, d_x, d_z, o.d_tmp, nullptr, nullptr));
-    QMRI_TRY(dc_launch_adj(ctx, op, ls, DC_LSQR_INIT, B, nullptr, o.d_tmp, nullptr, nullptr));
+    QMRI_TRY(dc_launch_fwd(ctx, op, ls, DC_FWD_H_ONLY, B, d_x, o.d_tmp, nullptr, nullptr));
+    QMRI_TRY(dc_launch_lsqr(ctx, op, ls, true, B, d_x, d_z, o.d_tmp, d_x));
     int launched = 0;
     int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
     bool all_done = false;
@@ -433,8 +443,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         const int nthis = std::min(chunk, maxit - launched);
         for (int k = 0; k < nthis; ++k) {
             ls.ii = launched + k + 1;
-            QMRI_TRY(dc_launch_fwd(ctx, op, ls, DC_LSQR_ITER, B, nullptr, nullptr, o.d_tmp, nullptr, nullptr));
-            QMRI_TRY(dc_launch_adj(ctx, op, ls, DC_LSQR_ITER, B, nullptr, o.d_tmp, nullptr, d_x));
+            QMRI_TRY(dc_launch_lsqr(ctx, op, ls, false, B, nullptr, nullptr, o.d_tmp, d_x));
         }
         launched += nthis;
         QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ls.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
@@ -477,8 +486,8 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
         QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out));
     } else if (solver == QMRI_SOLVER_DIRECT) {
         QMRI_TRY(qmri_prepare_direct(ctx, r));
-        QMRI_TRY(dc_launch_adj(ctx, op, o.ls, DC_PLAIN, 1, o.d_ya, o.d_tmp, o.d_xa, nullptr));
-        QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, 1, o.d_xa, nullptr, o.d_tmp, o.d_chat, nullptr));
+        QMRI_TRY(dc_launch_adj(ctx, op, 1, o.d_ya, o.d_tmp, o.d_xa));
+        QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, 1, o.d_xa, o.d_tmp, o.d_chat, nullptr));
         QMRI_TRY(dc_launch_direct(ctx, qmri_opdev(ctx), 1, o.d_z, o.d_chat, r, o.d_tmp, o.d_x));
         if (iters_out) *iters_out = 0;
         if (flag_out) *flag_out = 0;
@@ -488,6 +497,14 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
     }
     QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_x, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+// diagnostic: phase stamps of the most recent LSQR launches (see lsqr_kernels.hip); out holds 2*512*8 values
+extern "C" int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out) {
+    if (!ctx || !ctx->op.ls.stamps) return QMRI_ERR_STATE;
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    QMRI_HIP(ctx, hipMemcpy(out, ctx->op.ls.stamps, (size_t)2 * 512 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QMRI_OK;
 }
 

@@ -293,14 +293,14 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
 
     QMRI_TRY(dc_launch_sort_y(ctx, op, o.ls, B, y));
     if (d_x0) QMRI_HIP(ctx, hipMemcpyAsync(o.d_x, d_x0, nb, hipMemcpyDeviceToDevice, ctx->stream));        // x = param.X0
-    else QMRI_TRY(dc_launch_adj(ctx, op, o.ls, DC_PLAIN, B, y, o.d_tmp, o.d_x, nullptr));                    // F.adjoint(Y)
+    else QMRI_TRY(dc_launch_adj(ctx, op, B, y, o.d_tmp, o.d_x));                    // F.adjoint(Y)
     QMRI_HIP(ctx, hipMemcpyAsync(o.d_vv, o.d_x, nb, hipMemcpyDeviceToDevice, ctx->stream));                  // v = x
     QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, nb, ctx->stream));                                                // uold = 0
     if (prm->solver == QMRI_SOLVER_DIRECT) {
         QMRI_TRY(qmri_prepare_direct(ctx, prm->gamma));
         const double2* aty = o.d_x;
-        if (d_x0) { QMRI_TRY(dc_launch_adj(ctx, op, o.ls, DC_PLAIN, B, y, o.d_tmp, o.d_xa, nullptr)); aty = o.d_xa; }
-        QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, aty, nullptr, o.d_tmp, o.d_chat, nullptr));
+        if (d_x0) { QMRI_TRY(dc_launch_adj(ctx, op, B, y, o.d_tmp, o.d_xa)); aty = o.d_xa; }
+        QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, aty, o.d_tmp, o.d_chat, nullptr));
     } else if (prm->solver != QMRI_SOLVER_LSQR) {
         qmri_set_error(ctx, "unknown solver %d", prm->solver);
         return QMRI_ERR_INVALID_ARG;
@@ -324,7 +324,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_xupdate);
         if (prm->want_diag && diag_out) {                                                                    // PnP_ADMM.m:106-109
             tm.start();
-            QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_DIAG, B, o.d_x, nullptr, o.d_tmp, nullptr, o.d_pd));
+            QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_DIAG, B, o.d_x, o.d_tmp, nullptr, o.d_pd));
             QMRI_TRY(ew_launch_diag(ctx, op, o.ls, B, o.d_x, (const double2*)d_gt, o.d_pd, o.d_diag, prm->iters, it));
             tm.stop(ctx->prof.ms_diag);
         }

@@ -1,0 +1,97 @@
+// dc_device.h -- device-side helpers shared by the data-consistency kernels (dc_kernels.hip, lsqr_kernels.hip).
+#pragma once
+#include "qmri_internal.h"
+#include "fft_codelets.h"
+
+namespace dcdev {
+using namespace qfft;
+
+constexpr int NT = 256;          // threads per block for every kernel in this file
+constexpr int DC_MAXS = 10;      // channel lines the w-pass kernels hold in LDS (the reference always has s = 10)
+constexpr int DC_VCAP = 2048;    // doubles of V kept in LDS by the w-pass kernels (T*s <= 2048, e.g. T = 200, s = 10)
+constexpr int DC_CH = 512;       // samples of a k-row staged in LDS at a time by the adjoint scatter
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it stalls until every global
+// store the wave has issued is acknowledged; the kernels here never communicate through global memory inside a
+// block, so their stores are left in flight.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lds_barrier();
+    if (lane == 0) sh[wid] = v;
+    lds_barrier();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    return r;
+}
+
+// fixed-order reduction of a partial-sum array by a whole block (every block gets the same bits)
+__device__ __forceinline__ double reduce_array(const double* __restrict__ p, int n, double* sh) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += NT) a += p[i];
+    return block_sum(a, sh);
+}
+
+// Two-step FFT of `nlines` lines held in LDS (natural order, pitch LINE).  On return thread (line2,k1) holds
+// X[k1 + R1*k2] in out[k2].  LINE_FAST selects the step-2 thread layout: line fastest or k1 fastest.
+template <int R1, int R2, bool LINE_FAST>
+__device__ __forceinline__ bool fft_lds(cd* lds, int nlines, const double2* __restrict__ tw, cd* out, int& line2, int& k1) {
+    typedef Plan<R1, R2> P;
+    const int tid = threadIdx.x;
+    const int line1 = tid / R2, n2 = tid - line1 * R2;
+    const bool act1 = tid < nlines * R2;
+    cd a[R1];
+    lds_barrier();
+    if (act1) {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) a[n1] = lds[line1 * P::LINE + R2 * n1 + n2];
+        Dft<R1>::run(a);
+#pragma unroll
+        for (int q = 1; q < R1; ++q) a[q] = mul(a[q], tw[n2 * q]);
+    }
+    lds_barrier();
+    if (act1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) lds[line1 * P::LINE + P::SP * n2 + q] = a[q];
+    }
+    lds_barrier();
+    if (LINE_FAST) { k1 = tid / nlines; line2 = tid - k1 * nlines; }
+    else { line2 = tid / R1; k1 = tid - line2 * R1; }
+    const bool act2 = tid < nlines * R1;
+    if (act2) {
+#pragma unroll
+        for (int q = 0; q < R2; ++q) out[q] = lds[line2 * P::LINE + P::SP * q + k1];
+        Dft<R2>::run(out);
+    }
+    return act2;
+}
+
+template <int R1, int R2> struct Cfg {
+    typedef Plan<R1, R2> P;
+    static constexpr int L = (16 * P::LINE * 16 <= 65536 && 16 * (R1 > R2 ? R1 : R2) <= NT) ? 16 : 8;   // lines per h-pass block
+};
+
+
+// two sums at once (one pair of barriers)
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lds_barrier();
+    if (lane == 0) { sh[wid] = a; sh[NT / 64 + wid] = b; }
+    lds_barrier();
+    double ra = 0.0, rb = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { ra += sh[i]; rb += sh[NT / 64 + i]; }
+    a = ra; b = rb;
+}
+
+}  // namespace dcdev

@@ -17,128 +17,26 @@
 // so both the gather and the scatter stream contiguously; `perm` converts at the ABI boundary.
 //
 // Layouts: x [c][w][h] complex (MATLAB N x M x s); tmp [c][kh][w]; every per-slice array is slice-major.
-#include "qmri_internal.h"
-#include "fft_codelets.h"
+#include "dc_device.h"
 
-using namespace qfft;
+using namespace dcdev;
 
 namespace {
-
-constexpr int NT = 256;          // threads per block for every kernel in this file
-constexpr int DC_MAXS = 12;      // channel lines the w-pass kernels hold in LDS
-
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) sh[wid] = v;
-    __syncthreads();
-    double r = 0.0;
-#pragma unroll
-    for (int i = 0; i < NT / 64; ++i) r += sh[i];
-    return r;
-}
-
-// fixed-order reduction of a partial-sum array by a whole block (every block gets the same bits)
-__device__ __forceinline__ double reduce_array(const double* __restrict__ p, int n, double* sh) {
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) a += p[i];
-    return block_sum(a, sh);
-}
-
-// Two-step FFT of `nlines` lines held in LDS (natural order, pitch LINE).  On return thread (line2,k1) holds
-// X[k1 + R1*k2] in out[k2].  LINE_FAST selects the step-2 thread layout: line fastest or k1 fastest.
-template <int R1, int R2, bool LINE_FAST>
-__device__ __forceinline__ bool fft_lds(cd* lds, int nlines, const double2* __restrict__ tw, cd* out, int& line2, int& k1) {
-    typedef Plan<R1, R2> P;
-    const int tid = threadIdx.x;
-    const int line1 = tid / R2, n2 = tid - line1 * R2;
-    const bool act1 = tid < nlines * R2;
-    cd a[R1];
-    __syncthreads();
-    if (act1) {
-#pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) a[n1] = lds[line1 * P::LINE + R2 * n1 + n2];
-        Dft<R1>::run(a);
-#pragma unroll
-        for (int q = 1; q < R1; ++q) a[q] = mul(a[q], tw[n2 * q]);
-    }
-    __syncthreads();
-    if (act1) {
-#pragma unroll
-        for (int q = 0; q < R1; ++q) lds[line1 * P::LINE + P::SP * n2 + q] = a[q];
-    }
-    __syncthreads();
-    if (LINE_FAST) { k1 = tid / nlines; line2 = tid - k1 * nlines; }
-    else { line2 = tid / R1; k1 = tid - line2 * R1; }
-    const bool act2 = tid < nlines * R1;
-    if (act2) {
-#pragma unroll
-        for (int q = 0; q < R2; ++q) out[q] = lds[line2 * P::LINE + P::SP * q + k1];
-        Dft<R2>::run(out);
-    }
-    return act2;
-}
-
-template <int R1, int R2> struct Cfg {
-    typedef Plan<R1, R2> P;
-    static constexpr int L = (16 * P::LINE * 16 <= 65536 && 16 * (R1 > R2 ? R1 : R2) <= NT) ? 16 : 8;   // lines per h-pass block
-};
 
 // ---------------------------------------------------------------------------------------------------
 // forward, pass 1: FFT along h (contiguous) of L lines; transposed store tmp[c][kh][w]
 // ---------------------------------------------------------------------------------------------------
-template <int R1, int R2, int MODE>
-__global__ __launch_bounds__(NT) void k_fwd_h(OpDev op, LsqrDev ls, const double2* __restrict__ src,
-                                               const double2* __restrict__ zsrc, double2* __restrict__ tmp) {
+template <int R1, int R2>
+__global__ __launch_bounds__(NT) void k_fwd_h(OpDev op, const double2* __restrict__ src, double2* __restrict__ tmp) {
     typedef Plan<R1, R2> P;
     constexpr int N = P::N, L = Cfg<R1, R2>::L;
     __shared__ cd lds[L * P::LINE];
-    __shared__ double red[NT / 64];
     const int tid = threadIdx.x, b = blockIdx.y;
     const size_t n = (size_t)op.s * N * op.M;
     const size_t base = (size_t)b * n + (size_t)blockIdx.x * L * N;
-    double alpha = 0.0, inv_alpha = 1.0, inv_bprev = 1.0;
-    const double sr = ls.sr;
-    if (MODE == DC_LSQR_ITER) {
-        if (ls.st[b].done) return;
-        alpha = sqrt(reduce_array(ls.pv + (size_t)b * ls.nblk_h, ls.nblk_h, red));
-        const double bp = sqrt(reduce_array(ls.pu[(ls.ii - 1) & 1] + (size_t)b * ls.npu, ls.npu, red));
-        inv_alpha = 1.0 / alpha;
-        inv_bprev = 1.0 / bp;
-    }
-    double acc = 0.0;
     for (int i = tid; i < L * N; i += NT) {
         const int line = i / N, nn = i - line * N;
-        const size_t g = base + i;
-        cd a;
-        if (MODE == DC_LSQR_INIT) {
-            // u(m+1:end) = sqrt(r) z - sqrt(r) x0          (b - B*x0, PnP_ADMM.m:102,160-162)
-            const double2 xv = src[g], zv = zsrc[g];
-            a = xv;
-            double2 ub = make_double2(zv.x * sr - xv.x * sr, zv.y * sr - xv.y * sr);
-            ls.ub[g] = ub;
-            acc += ub.x * ub.x + ub.y * ub.y;
-        } else if (MODE == DC_LSQR_ITER) {
-            // v = v/alpha ;  u(m+1:end) = sqrt(r) v - alpha * (u/beta_prev)
-            double2 v = ls.v[g];
-            v.x *= inv_alpha; v.y *= inv_alpha;
-            ls.v[g] = v;
-            a = v;
-            double2 ub = ls.ub[g];
-            ub.x = v.x * sr - alpha * (ub.x * inv_bprev);
-            ub.y = v.y * sr - alpha * (ub.y * inv_bprev);
-            ls.ub[g] = ub;
-            acc += ub.x * ub.x + ub.y * ub.y;
-        } else {
-            a = src[g];
-        }
-        lds[line * P::LINE + nn] = a;
-    }
-    if (MODE == DC_LSQR_INIT || MODE == DC_LSQR_ITER) {
-        const double tot = block_sum(acc, red);
-        if (tid == 0) ls.pu[ls.ii & 1][(size_t)b * ls.npu + blockIdx.x] = tot;
+        lds[line * P::LINE + nn] = src[base + i];
     }
     cd out[R2];
     int line2, k1;
@@ -162,15 +60,12 @@ __global__ __launch_bounds__(NT) void k_fwd_w(OpDev op, LsqrDev ls, const double
     typedef Plan<R1, R2> P;
     constexpr int N = P::N;
     __shared__ cd lds[DC_MAXS * P::LINE];
+    __shared__ double vlds[DC_VCAP];
     __shared__ double red[NT / 64];
     const int tid = threadIdx.x, b = blockIdx.y, kh = blockIdx.x, s = op.s, M = op.M;
     const size_t n = (size_t)s * N * M;
-    double alpha = 0.0, inv_bprev = 1.0;
-    if (MODE == DC_LSQR_ITER) {
-        if (ls.st[b].done) return;
-        alpha = sqrt(reduce_array(ls.pv + (size_t)b * ls.nblk_h, ls.nblk_h, red));
-        inv_bprev = 1.0 / sqrt(reduce_array(ls.pu[(ls.ii - 1) & 1] + (size_t)b * ls.npu, ls.npu, red));
-    }
+    const bool v_in_lds = op.T * s <= DC_VCAP;           // V(t,:) rows are read once per sample: keep them on chip
+    if (v_in_lds) for (int i = tid; i < op.T * s; i += NT) vlds[i] = op.Vt[i];
     for (int i = tid; i < s * M; i += NT) {
         const int c = i / M, w = i - c * M;
         lds[c * P::LINE + w] = tmp[(size_t)b * n + ((size_t)c * N + kh) * M + w];
@@ -232,7 +127,7 @@ __global__ __launch_bounds__(NT) void k_fwd_w(OpDev op, LsqrDev ls, const double
     double acc = 0.0;
     for (int e = e0 + tid; e < e1; e += NT) {
         const KEntry en = op.ent[e];
-        const double* vrow = op.Vt + (size_t)en.t * s;
+        const double* vrow = v_in_lds ? vlds + en.t * s : op.Vt + (size_t)en.t * s;
         double re = 0.0, im = 0.0;
         for (int c = 0; c < s; ++c) {
             const double v = vrow[c];
@@ -243,27 +138,13 @@ __global__ __launch_bounds__(NT) void k_fwd_w(OpDev op, LsqrDev ls, const double
         re *= sc; im *= sc;
         if (MODE == DC_PLAIN) {
             y_out[mb + op.perm[e]] = make_double2(re, im);
-        } else if (MODE == DC_LSQR_INIT) {
-            const double2 yv = ls.yk[mb + e];                       // u(1:m) = y - A*x0
-            const double2 u = make_double2(yv.x - re, yv.y - im);
-            ls.ut[mb + e] = u;
-            acc += u.x * u.x + u.y * u.y;
-        } else if (MODE == DC_LSQR_ITER) {
-            double2 u = ls.ut[mb + e];                              // u(1:m) = A*v - alpha*(u/beta_prev)
-            u.x = re - alpha * (u.x * inv_bprev);
-            u.y = im - alpha * (u.y * inv_bprev);
-            ls.ut[mb + e] = u;
-            acc += u.x * u.x + u.y * u.y;
         } else if (MODE == DC_DIAG) {
             const double2 yv = ls.yk[mb + e];                       // ||y - F.forward(x)||  PnP_ADMM.m:106
             const double dx = yv.x - re, dy = yv.y - im;
             acc += dx * dx + dy * dy;
         }
     }
-    if (MODE == DC_LSQR_INIT || MODE == DC_LSQR_ITER) {
-        const double tot = block_sum(acc, red);
-        if (tid == 0) ls.pu[ls.ii & 1][(size_t)b * ls.npu + ls.nblk_h + kh] = tot;
-    } else if (MODE == DC_DIAG) {
+    if (MODE == DC_DIAG) {
         const double tot = block_sum(acc, red);
         if (tid == 0) pdiag[(size_t)b * N + kh] = tot;
     }
@@ -272,79 +153,81 @@ __global__ __launch_bounds__(NT) void k_fwd_w(OpDev op, LsqrDev ls, const double
 // ---------------------------------------------------------------------------------------------------
 // adjoint, pass 1: one block per k-row kh.  Scatter-combine  Zhat_c[k] = sum_{t: k in Omega_t} V(t,c) y[(t,k)]
 // (atomics-free: thread (kw,c) walks the samples of its own k), then inverse FFT along w.
-// In LSQR modes this kernel also advances the scalar recurrences and evaluates the stopping tests.
 // ---------------------------------------------------------------------------------------------------
-template <int R1, int R2, int MODE>
-__global__ __launch_bounds__(NT) void k_adj_w(OpDev op, LsqrDev ls, const double2* __restrict__ y_in,
+template <int R1, int R2>
+__global__ __launch_bounds__(NT) void k_adj_w(OpDev op, const double2* __restrict__ y_in,
                                                double2* __restrict__ tmp) {
     typedef Plan<R1, R2> P;
     constexpr int N = P::N;
     __shared__ cd lds[DC_MAXS * P::LINE];
-    __shared__ double red[NT / 64];
+    __shared__ double vlds[DC_VCAP];
+    __shared__ double2 ulds[DC_CH];
+    __shared__ unsigned short tlds[DC_CH];
     const int tid = threadIdx.x, b = blockIdx.y, kh = blockIdx.x, s = op.s, M = op.M;
     const size_t n = (size_t)s * N * M;
-    double inv_beta = 1.0;
-    if (MODE == DC_LSQR_INIT) {
-        LsqrState* st = ls.st + b;
-        const double beta0 = sqrt(reduce_array(ls.pu[0] + (size_t)b * ls.npu, ls.npu, red));
-        const double nz2 = reduce_array(ls.pz + (size_t)b * ls.nblk_z, ls.nblk_z, red);
-        inv_beta = (beta0 != 0.0) ? 1.0 / beta0 : 0.0;
-        if (kh == 0 && tid == 0) {
-            LsqrScalars S;
-            S.c = 1.0; S.s = 0.0; S.phibar = beta0; S.normr = beta0; S.norma = 0.0; S.factor = beta0;
-            S.thet = 0.0; S.rho = 1.0; S.phi = 0.0; S.beta = beta0; S.alpha = 0.0;
-            st->sc[0] = S;
-            const double n2b = sqrt(st->ny2 + ls.sr * ls.sr * nz2);
-            st->n2b = n2b;
-            st->tolb = ls.tol * n2b;
-            st->iter = ls.maxit; st->flag = 1;
-            st->done = (beta0 == 0.0 || n2b == 0.0) ? 1 : 0;      // x0 already exact, or b = 0
-            if (st->done) { st->iter = 0; st->flag = 0; }
-        }
-    } else if (MODE == DC_LSQR_ITER) {
-        LsqrState* st = ls.st + b;
-        if (st->done) return;
-        const double alpha = sqrt(reduce_array(ls.pv + (size_t)b * ls.nblk_h, ls.nblk_h, red));
-        const double beta = sqrt(reduce_array(ls.pu[ls.ii & 1] + (size_t)b * ls.npu, ls.npu, red));
-        const LsqrScalars O = st->sc[(ls.ii - 1) & 1];
-        LsqrScalars S;
-        const double normar = alpha * O.factor;
-        S.norma = sqrt(O.norma * O.norma + alpha * alpha + beta * beta);
-        S.thet = -O.s * alpha;
-        const double rhot = O.c * alpha;
-        S.rho = sqrt(rhot * rhot + beta * beta);
-        S.c = rhot / S.rho;
-        S.s = -beta / S.rho;
-        S.phi = S.c * O.phibar;
-        S.phibar = S.s * O.phibar;
-        S.beta = beta; S.alpha = alpha;
-        bool conv = false;
-        if (normar == 0.0) conv = true;                                   // all-zero correction
-        if (normar / (S.norma * O.normr) <= ls.tol) conv = true;         // min ||b - Bx|| test
-        if (O.normr <= st->tolb) conv = true;                             // Bx = b test
-        S.normr = fabs(S.s) * O.normr;
-        S.factor = fabs(S.s * S.phi);
-        if (kh == 0 && tid == 0) {
-            st->sc[ls.ii & 1] = S;
-            if (conv) { st->done = 1; st->flag = 0; st->iter = ls.ii - 1; }
-        }
-        if (conv) return;
-        inv_beta = 1.0 / beta;
-    }
+    const bool v_in_lds = op.T * s <= DC_VCAP;
+    if (v_in_lds) for (int i = tid; i < op.T * s; i += NT) vlds[i] = op.Vt[i];
+    // Scatter-combine, atomics-free and in a fixed order: thread (kw, c) owns Zhat_c[kh,kw] and walks the samples of its
+    // k in frame order.  The row's samples (k-sorted, hence contiguous) are first staged in LDS by the whole block with
+    // coalesced loads, DC_CH at a time, so the serial walk of a heavily sampled k (200 frames at DC) runs at LDS latency,
+    // four independent loads at a time, instead of one dependent global round trip per sample.
     const size_t mb = (size_t)b * op.m;
-    for (int item = tid; item < M * s; item += NT) {
-        const int kw = item / s, c = item - kw * s;
-        const int e0 = op.kptr[kh * M + kw], e1 = op.kptr[kh * M + kw + 1];
-        double ar = 0.0, ai = 0.0;
-        for (int e = e0; e < e1; ++e) {
-            double2 yv;
-            if (MODE == DC_PLAIN) yv = y_in[mb + op.perm[e]];
-            else { yv = ls.ut[mb + e]; yv.x *= inv_beta; yv.y *= inv_beta; }
-            const double v = op.Vt[(size_t)op.ent[e].t * s + c];
-            ar += v * yv.x;
-            ai += v * yv.y;
+    constexpr int NQ = (N * DC_MAXS + NT - 1) / NT;
+    double ar[NQ], ai[NQ];
+    int e0[NQ], e1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int item = tid + NT * q;
+        ar[q] = 0.0; ai[q] = 0.0;
+        if (item < M * s) {
+            const int kw = item / s;
+            e0[q] = op.kptr[kh * M + kw]; e1[q] = op.kptr[kh * M + kw + 1];
+        } else { e0[q] = 0; e1[q] = 0; }
+    }
+    const int r0 = op.kptr[kh * M], r1 = op.kptr[(kh + 1) * M];
+    for (int lo = r0; lo < r1; lo += DC_CH) {
+        const int hi = (lo + DC_CH < r1) ? lo + DC_CH : r1;
+        __syncthreads();
+        for (int i = tid; i < hi - lo; i += NT) {
+            const int e = lo + i;
+            ulds[i] = y_in[mb + op.perm[e]];
+            tlds[i] = op.ent[e].t;
         }
-        lds[c * P::LINE + kw] = mk(ar, -ai);          // conjugate for the inverse transform
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (tid + NT * q) % s;
+            const int a0 = (e0[q] > lo) ? e0[q] : lo, a1 = (e1[q] < hi) ? e1[q] : hi;
+            double xr = ar[q], xi = ai[q];
+            int e = a0;
+            for (; e + 4 <= a1; e += 4) {
+                double2 u0 = ulds[e - lo], u1 = ulds[e - lo + 1], u2 = ulds[e - lo + 2], u3 = ulds[e - lo + 3];
+                const int t0 = tlds[e - lo], t1 = tlds[e - lo + 1], t2 = tlds[e - lo + 2], t3 = tlds[e - lo + 3];
+                const double v0 = v_in_lds ? vlds[t0 * s + c] : op.Vt[(size_t)t0 * s + c];
+                const double v1 = v_in_lds ? vlds[t1 * s + c] : op.Vt[(size_t)t1 * s + c];
+                const double v2 = v_in_lds ? vlds[t2 * s + c] : op.Vt[(size_t)t2 * s + c];
+                const double v3 = v_in_lds ? vlds[t3 * s + c] : op.Vt[(size_t)t3 * s + c];
+                xr += v0 * u0.x; xi += v0 * u0.y;
+                xr += v1 * u1.x; xi += v1 * u1.y;
+                xr += v2 * u2.x; xi += v2 * u2.y;
+                xr += v3 * u3.x; xi += v3 * u3.y;
+            }
+            for (; e < a1; ++e) {
+                const double2 u0 = ulds[e - lo];
+                const int t0 = tlds[e - lo];
+                const double v0 = v_in_lds ? vlds[t0 * s + c] : op.Vt[(size_t)t0 * s + c];
+                xr += v0 * u0.x; xi += v0 * u0.y;
+            }
+            ar[q] = xr; ai[q] = xi;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int item = tid + NT * q;
+        if (item < M * s) {
+            const int kw = item / s, c = item - kw * s;
+            lds[c * P::LINE + kw] = mk(ar[q], -ai[q]);          // conjugate for the inverse transform
+        }
     }
     cd out[R2];
     int line2, k1;
@@ -359,26 +242,13 @@ __global__ __launch_bounds__(NT) void k_adj_w(OpDev op, LsqrDev ls, const double
 // adjoint, pass 2: inverse FFT along h of L lines (c, w0..w0+L), un-conjugate, scale by 1/sqrt(NM)
 //   (= ifft2(.)*sqrt(NM)), and the fused LSQR updates of v, d, x.
 // ---------------------------------------------------------------------------------------------------
-template <int R1, int R2, int MODE>
-__global__ __launch_bounds__(NT) void k_adj_h(OpDev op, LsqrDev ls, const double2* __restrict__ tmp,
-                                               double2* __restrict__ dst, double2* __restrict__ xio) {
+template <int R1, int R2>
+__global__ __launch_bounds__(NT) void k_adj_h(OpDev op, const double2* __restrict__ tmp, double2* __restrict__ dst) {
     typedef Plan<R1, R2> P;
     constexpr int N = P::N, L = Cfg<R1, R2>::L;
     __shared__ cd lds[L * P::LINE];
-    __shared__ double red[NT / 64];
     const int tid = threadIdx.x, b = blockIdx.y, M = op.M;
     const size_t n = (size_t)op.s * N * M;
-    double inv_beta = 1.0, beta = 0.0, thet = 0.0, inv_rho = 1.0, phi = 0.0;
-    const double sr = ls.sr;
-    if (MODE == DC_LSQR_INIT) {
-        if (ls.st[b].done) return;
-        const double beta0 = sqrt(reduce_array(ls.pu[0] + (size_t)b * ls.npu, ls.npu, red));
-        inv_beta = 1.0 / beta0;
-    } else if (MODE == DC_LSQR_ITER) {
-        if (ls.st[b].done) return;
-        const LsqrScalars S = ls.st[b].sc[ls.ii & 1];
-        beta = S.beta; inv_beta = 1.0 / beta; thet = S.thet; inv_rho = 1.0 / S.rho; phi = S.phi;
-    }
     const int l0 = blockIdx.x * L;
     const int c = l0 / M, w0 = l0 - c * M;
     const double2* srcp = tmp + (size_t)b * n + (size_t)c * N * M + w0;
@@ -388,44 +258,11 @@ __global__ __launch_bounds__(NT) void k_adj_h(OpDev op, LsqrDev ls, const double
     }
     cd out[R2];
     int line2, k1;
-    const bool act = fft_lds<R1, R2, false>(lds, L, op.tw, out, line2, k1);
-    const double sc = 1.0 / sqrt((double)N * (double)M);
-    double acc = 0.0;
-    if (act) {
+    if (fft_lds<R1, R2, false>(lds, L, op.tw, out, line2, k1)) {
+        const double sc = 1.0 / sqrt((double)N * (double)M);
         const size_t g0 = (size_t)b * n + (size_t)(l0 + line2) * N;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) {
-            const size_t g = g0 + k1 + R1 * k2;
-            const double vx = out[k2].x * sc, vy = -out[k2].y * sc;
-            if (MODE == DC_PLAIN) {
-                dst[g] = make_double2(vx, vy);
-            } else if (MODE == DC_LSQR_INIT) {
-                // v = B'*u = A'*u(1:m) + sqrt(r) u(m+1:end)       PnP_ADMM.m:164-167
-                const double2 ub = ls.ub[g];
-                const double2 vr = make_double2(vx + (ub.x * inv_beta) * sr, vy + (ub.y * inv_beta) * sr);
-                ls.v[g] = vr;
-                ls.d[g] = make_double2(0.0, 0.0);
-                acc += vr.x * vr.x + vr.y * vr.y;
-            } else if (MODE == DC_LSQR_ITER) {
-                const double2 ub = ls.ub[g];
-                const double2 vh = ls.v[g];
-                double2 dd = ls.d[g];
-                dd.x = (vh.x - thet * dd.x) * inv_rho;            // d = (v - thet d)/rho
-                dd.y = (vh.y - thet * dd.y) * inv_rho;
-                ls.d[g] = dd;
-                double2 xv = xio[g];
-                xv.x += phi * dd.x; xv.y += phi * dd.y;           // x = x + phi d
-                xio[g] = xv;
-                const double2 vr = make_double2((vx + (ub.x * inv_beta) * sr) - beta * vh.x,
-                                                (vy + (ub.y * inv_beta) * sr) - beta * vh.y);   // v = B'u - beta v
-                ls.v[g] = vr;
-                acc += vr.x * vr.x + vr.y * vr.y;
-            }
-        }
-    }
-    if (MODE == DC_LSQR_INIT || MODE == DC_LSQR_ITER) {
-        const double tot = block_sum(acc, red);
-        if (tid == 0) ls.pv[(size_t)b * ls.nblk_h + blockIdx.x] = tot;
+        for (int k2 = 0; k2 < R2; ++k2) dst[g0 + k1 + R1 * k2] = make_double2(out[k2].x * sc, -out[k2].y * sc);
     }
 }
 
@@ -464,100 +301,57 @@ __global__ __launch_bounds__(NT) void k_prepare_z(LsqrDev ls, size_t n, const do
 
 template <int R1, int R2>
 int launch_fwd_t(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src,
-                 const double2* zsrc, double2* tmp, double2* y_out, double* pdiag, const double2* chat, double rr) {
+                 double2* tmp, double2* y_out, double* pdiag, const double2* chat, double rr) {
     constexpr int L = Cfg<R1, R2>::L;
     dim3 gh(op.s * op.M / L, B), gw(op.N, B), blk(NT);
     hipStream_t st = ctx->stream;
+    k_fwd_h<R1, R2><<<gh, blk, 0, st>>>(op, src, tmp);
     switch (mode) {
-        case DC_LSQR_INIT:
-            k_fwd_h<R1, R2, DC_LSQR_INIT><<<gh, blk, 0, st>>>(op, ls, src, zsrc, tmp);
-            k_fwd_w<R1, R2, DC_LSQR_INIT><<<gw, blk, 0, st>>>(op, ls, tmp, nullptr, nullptr, nullptr, 0.0);
-            break;
-        case DC_LSQR_ITER:
-            k_fwd_h<R1, R2, DC_LSQR_ITER><<<gh, blk, 0, st>>>(op, ls, nullptr, nullptr, tmp);
-            k_fwd_w<R1, R2, DC_LSQR_ITER><<<gw, blk, 0, st>>>(op, ls, tmp, nullptr, nullptr, nullptr, 0.0);
-            break;
-        case DC_DIAG:
-            k_fwd_h<R1, R2, DC_PLAIN><<<gh, blk, 0, st>>>(op, ls, src, nullptr, tmp);
-            k_fwd_w<R1, R2, DC_DIAG><<<gw, blk, 0, st>>>(op, ls, tmp, nullptr, pdiag, nullptr, 0.0);
-            break;
-        case DC_SPECTRUM:
-            k_fwd_h<R1, R2, DC_PLAIN><<<gh, blk, 0, st>>>(op, ls, src, nullptr, tmp);
-            k_fwd_w<R1, R2, DC_SPECTRUM><<<gw, blk, 0, st>>>(op, ls, tmp, y_out, nullptr, nullptr, 0.0);
-            break;
-        case DC_DIRECT:
-            k_fwd_h<R1, R2, DC_PLAIN><<<gh, blk, 0, st>>>(op, ls, src, nullptr, tmp);
-            k_fwd_w<R1, R2, DC_DIRECT><<<gw, blk, 0, st>>>(op, ls, tmp, y_out, nullptr, chat, rr);
-            break;
-        default:
-            k_fwd_h<R1, R2, DC_PLAIN><<<gh, blk, 0, st>>>(op, ls, src, nullptr, tmp);
-            k_fwd_w<R1, R2, DC_PLAIN><<<gw, blk, 0, st>>>(op, ls, tmp, y_out, nullptr, nullptr, 0.0);
-            break;
+        case DC_FWD_H_ONLY: break;
+        case DC_DIAG: k_fwd_w<R1, R2, DC_DIAG><<<gw, blk, 0, st>>>(op, ls, tmp, nullptr, pdiag, nullptr, 0.0); break;
+        case DC_SPECTRUM: k_fwd_w<R1, R2, DC_SPECTRUM><<<gw, blk, 0, st>>>(op, ls, tmp, y_out, nullptr, nullptr, 0.0); break;
+        case DC_DIRECT: k_fwd_w<R1, R2, DC_DIRECT><<<gw, blk, 0, st>>>(op, ls, tmp, y_out, nullptr, chat, rr); break;
+        default: k_fwd_w<R1, R2, DC_PLAIN><<<gw, blk, 0, st>>>(op, ls, tmp, y_out, nullptr, nullptr, 0.0); break;
     }
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
 
 template <int R1, int R2>
-int launch_adj_t(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* y_in,
-                 double2* tmp, double2* dst, double2* xio, bool skip_w) {
+int launch_adj_t(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst, bool skip_w) {
     constexpr int L = Cfg<R1, R2>::L;
     dim3 gh(op.s * op.M / L, B), gw(op.N, B), blk(NT);
     hipStream_t st = ctx->stream;
-    switch (mode) {
-        case DC_LSQR_INIT:
-            k_adj_w<R1, R2, DC_LSQR_INIT><<<gw, blk, 0, st>>>(op, ls, nullptr, tmp);
-            k_adj_h<R1, R2, DC_LSQR_INIT><<<gh, blk, 0, st>>>(op, ls, tmp, nullptr, nullptr);
-            break;
-        case DC_LSQR_ITER:
-            k_adj_w<R1, R2, DC_LSQR_ITER><<<gw, blk, 0, st>>>(op, ls, nullptr, tmp);
-            k_adj_h<R1, R2, DC_LSQR_ITER><<<gh, blk, 0, st>>>(op, ls, tmp, nullptr, xio);
-            break;
-        default:
-            if (!skip_w) k_adj_w<R1, R2, DC_PLAIN><<<gw, blk, 0, st>>>(op, ls, y_in, tmp);
-            k_adj_h<R1, R2, DC_PLAIN><<<gh, blk, 0, st>>>(op, ls, tmp, dst, nullptr);
-            break;
-    }
+    if (!skip_w) k_adj_w<R1, R2><<<gw, blk, 0, st>>>(op, y_in, tmp);
+    k_adj_h<R1, R2><<<gh, blk, 0, st>>>(op, tmp, dst);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
 
 }  // namespace
 
-bool dc_size_supported(int N) { return N == 224 || N == 256 || N == 128 || N == 64 || N == 32; }
-
-int dc_nblk_h(int N, int M, int s) {
-    int L = 16;
-    if (N == 256) L = Cfg<16, 16>::L;
-    else if (N == 224) L = Cfg<16, 14>::L;
-    else if (N == 128) L = Cfg<16, 8>::L;
-    else if (N == 64) L = Cfg<8, 8>::L;
-    else if (N == 32) L = Cfg<8, 4>::L;
-    return s * M / L;
-}
+bool dc_size_supported(int N) { return N == 224 || N == 128 || N == 64 || N == 32; }
 
 #define DC_DISPATCH(N_, CALL)                                  \
     switch (N_) {                                              \
         case 224: return CALL(16, 14);                         \
-        case 256: return CALL(16, 16);                         \
         case 128: return CALL(16, 8);                          \
         case 64: return CALL(8, 8);                            \
         case 32: return CALL(8, 4);                            \
         default:                                               \
-            qmri_set_error(ctx, "unsupported grid size N=%d (supported: 32, 64, 128, 224, 256)", N_); \
+            qmri_set_error(ctx, "unsupported grid size N=%d (supported: 32, 64, 128, 224)", N_); \
             return QMRI_ERR_UNSUPPORTED;                       \
     }
 
-int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src,
-                  const double2* zsrc, double2* tmp, double2* y_out, double* pdiag) {
-#define CALL_F(a, b) launch_fwd_t<a, b>(ctx, op, ls, mode, B, src, zsrc, tmp, y_out, pdiag, nullptr, 0.0)
+int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src, double2* tmp,
+                  double2* y_out, double* pdiag) {
+#define CALL_F(a, b) launch_fwd_t<a, b>(ctx, op, ls, mode, B, src, tmp, y_out, pdiag, nullptr, 0.0)
     DC_DISPATCH(op.N, CALL_F)
 #undef CALL_F
 }
 
-int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* y_in,
-                  double2* tmp, double2* dst, double2* x_inout) {
-#define CALL_A(a, b) launch_adj_t<a, b>(ctx, op, ls, mode, B, y_in, tmp, dst, x_inout, false)
+int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst) {
+#define CALL_A(a, b) launch_adj_t<a, b>(ctx, op, B, y_in, tmp, dst, false)
     DC_DISPATCH(op.N, CALL_A)
 #undef CALL_A
 }
@@ -566,9 +360,9 @@ int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, co
                      double2* tmp, double2* x_out) {
     LsqrDev ls{};
     // tmp holds the h-pass output, then (in place, row by row) the conjugate-domain w-pass output of k_fwd_w
-#define CALL_D(a, b) (launch_fwd_t<a, b>(ctx, op, ls, DC_DIRECT, B, z, nullptr, tmp, tmp, nullptr, chat, r) != QMRI_OK \
-                          ? (int)QMRI_ERR_HIP                                                                            \
-                          : launch_adj_t<a, b>(ctx, op, ls, DC_PLAIN, B, nullptr, tmp, x_out, nullptr, true))
+#define CALL_D(a, b) (launch_fwd_t<a, b>(ctx, op, ls, DC_DIRECT, B, z, tmp, tmp, nullptr, chat, r) != QMRI_OK \
+                          ? (int)QMRI_ERR_HIP                                                                   \
+                          : launch_adj_t<a, b>(ctx, op, B, nullptr, tmp, x_out, true))
     DC_DISPATCH(op.N, CALL_D)
 #undef CALL_D
 }

@@ -69,12 +69,12 @@ struct LsqrState {
     int32_t iter, done, flag, pad;
 };
 
-enum { DC_PLAIN = 0, DC_LSQR_INIT = 1, DC_LSQR_ITER = 2, DC_DIAG = 3, DC_DIRECT = 4, DC_SPECTRUM = 5 };
+enum { DC_PLAIN = 0, DC_FWD_H_ONLY = 1, DC_DIAG = 3, DC_DIRECT = 4, DC_SPECTRUM = 5 };
 
 struct LsqrDev {
     LsqrState* st;           // [B]
-    double* pu[2];           // [B][npu] partial sums of |u|^2   (npu = nblk_h + N)
-    double* pv;              // [B][nblk_h] partial sums of |v|^2
+    double* pu[2];           // [B][npu] partial sums of |u|^2   (npu = 2N: image-domain slices, then k-rows), by iteration parity
+    double* pv[2];           // [B][nblk_h] partial sums of |v|^2, by iteration parity
     double* pz;              // [B][nblk_z] partial sums of |z|^2
     double2* ut;             // [B][m]  u(1:m) in k-sorted order (raw, unnormalised)
     double2* ub;             // [B][n]  u(m+1:end)
@@ -82,10 +82,12 @@ struct LsqrDev {
     double2* d;              // [B][n]
     double2* yk;             // [B][m]  y in k-sorted order
     int npu, nblk_h, nblk_z;
+    int ucap, vcap;          // LDS plan of k_lsqr_w: samples of one k-row staged at once; doubles reserved for V
     double sr;               // sqrt(r)
     double tol;              // cg_tol
     int maxit;
     int ii;                  // LSQR iteration (1-based; 0 during initialisation)
+    unsigned long long* stamps;   // diagnostic (QMRI_LSQR_STAMPS=1): [2 kernels][512 blocks][8] wall_clock64 phase stamps, else null
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -173,6 +175,7 @@ struct qmri_ctx {
     int prof_level = 0;
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool lsqr_lds_attr[4] = {false, false, false, false};   // >64 KB dynamic LDS allowed for k_lsqr_w (per grid size)
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
 };
 
@@ -182,13 +185,15 @@ OpDev qmri_opdev(const qmri_ctx* ctx);
 // kernel launchers (dc_kernels.hip)
 // ---------------------------------------------------------------------------------------------------
 bool dc_size_supported(int N);
-int dc_nblk_h(int N, int M, int s);     // blocks of the h-pass kernels (= partial sums per slice)
+int dc_lsqr_nblk_h(int M, int s);       // blocks of k_lsqr_h (= partial sums of |v|^2 per slice)
+bool dc_lsqr_plan(int N, int T, int s, int maxrow, int* ucap, int* vcap);   // LDS plan of k_lsqr_w; false: V does not fit
 // forward:  src [B][n] -> (mode-dependent) ; tmp workspace [B][n]
-int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B,
-                  const double2* src, const double2* zsrc, double2* tmp, double2* y_out, double* pdiag);
-// adjoint:  (mode-dependent source) -> dst [B][n]
-int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B,
-                  const double2* y_in, double2* tmp, double2* dst, double2* x_inout);
+int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src, double2* tmp,
+                  double2* y_out, double* pdiag);
+int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst);
+// one LSQR step (lsqr_kernels.hip): init = b - B*x0, v = B'u ; otherwise iteration ls.ii
+int dc_launch_lsqr(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, bool init, int B, const double2* x0,
+                   const double2* z, double2* tmp, double2* xio);
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
                      double2* tmp, double2* x_out);
 // y (ABI order) -> k-sorted order, plus ||y||^2 into state

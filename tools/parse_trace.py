@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
-"""Group a rocprofv3 kernel_trace.csv by (kernel, grid) and print mean/min durations in microseconds."""
-import collections
-import csv
-import glob
-import sys
+"""Per-kernel summary of a rocprofv3 --kernel-trace run (either the *_kernel_trace.csv or the rocpd *_results.db)."""
+import csv, re, sqlite3, sys
+from collections import defaultdict
 
-paths = sys.argv[1:] or glob.glob("gpurun_out/**/*kernel_trace.csv", recursive=True)
-for p in paths:
-    g = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
-        name = r["Kernel_Name"]
-        short = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:40]
-        key = (short, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"])
-        g[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
-    print(p)
-    tot = sum(sum(v) for v in g.values())
-    for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
-        print(f"  {k[0]:40s} grid=({k[1]},{k[2]},{k[3]}) vgpr={k[4]}+{k[5]} lds={k[6]:>6s} n={len(v):4d} avg={sum(v)/len(v):8.1f} min={min(v):8.1f} share={100*sum(v)/tot:5.1f}%")
+
+def short(n):
+    n = re.sub(r'^void\s+', '', n)
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'\(.*$', '', n)
+    return n[:64]
+
+
+def main(p):
+    acc = defaultdict(lambda: [0, 0.0])
+    if p.endswith('.db'):
+        c = sqlite3.connect(p)
+        for n, s, e in c.execute('select name, start, end from kernels'):
+            a = acc[short(n)]; a[0] += 1; a[1] += e - s
+    else:
+        for r in csv.DictReader(open(p)):
+            a = acc[short(r['Kernel_Name'])]; a[0] += 1; a[1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    tot = sum(v[1] for v in acc.values())
+    print(f"{'kernel':64s} {'calls':>6s} {'avg us':>9s} {'total ms':>9s} {'%':>6s}")
+    for n, (k, s) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        print(f"{n:64s} {k:6d} {s / k / 1e3:9.2f} {s / 1e6:9.2f} {100 * s / tot:6.1f}")
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
