@@ -69,7 +69,7 @@ static void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 void qmri_free_operator(qmri_ctx* ctx) {
     OpHost& o = ctx->op;
-    void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
+    void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_grp, o.d_gptr, o.d_gkw, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
                      o.ls.st, o.ls.pu[0], o.ls.pu[1], o.ls.pv[0], o.ls.pv[1], o.ls.pz, o.ls.ut, o.ls.ub, o.ls.v, o.ls.d, o.ls.yk, o.ls.stamps,
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
     for (void* p : ptrs) free_dev(p);
@@ -190,6 +190,7 @@ OpDev qmri_opdev(const qmri_ctx* ctx) {
     d.N = o.N; d.M = o.M; d.s = o.s; d.T = o.T; d.m = o.m;
     d.Vt = o.d_Vt; d.ent = o.d_ent; d.perm = o.d_perm; d.kptr = o.d_kptr; d.tw = o.d_tw;
     d.kslot = o.d_kslot; d.ginv = o.d_ginv;
+    d.grp = o.d_grp; d.gptr = o.d_gptr; d.gkw = o.d_gkw;
     return d;
 }
 
@@ -272,10 +273,37 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_HIP(ctx, hipMemcpy(o.d_kslot, kslot.data(), (size_t)NM * sizeof(int32_t), hipMemcpyHostToDevice));
 
     LsqrDev& ls = o.ls;
-    int maxrow = 0;
-    for (int kh = 0; kh < N; ++kh) maxrow = std::max(maxrow, o.kptr_h[(kh + 1) * M] - o.kptr_h[kh * M]);
+    // scatter groups of the LSQR w-pass kernel: every sampled k location of a row, split into runs of <= DC_GCAP samples
+    int maxrow = 0, maxgroups = 0;
+    std::vector<KGroup> grp;
+    std::vector<int32_t> gptr(N + 1, 0), gkw((size_t)N * (M + 1), 0);
+    for (int kh = 0; kh < N; ++kh) {
+        const int r0 = o.kptr_h[kh * M];
+        maxrow = std::max(maxrow, o.kptr_h[(kh + 1) * M] - r0);
+        gptr[kh] = (int32_t)grp.size();
+        for (int kw = 0; kw < M; ++kw) {
+            gkw[(size_t)kh * (M + 1) + kw] = (int32_t)grp.size() - gptr[kh];
+            for (int e = o.kptr_h[kh * M + kw]; e < o.kptr_h[kh * M + kw + 1]; e += DC_GCAP) {
+                KGroup g;
+                g.kw = (uint16_t)kw; g.b = (uint16_t)(e - r0);
+                g.e = (uint16_t)(std::min(e + DC_GCAP, o.kptr_h[kh * M + kw + 1]) - r0); g.pad = 0;
+                grp.push_back(g);
+            }
+        }
+        gkw[(size_t)kh * (M + 1) + M] = (int32_t)grp.size() - gptr[kh];
+        maxgroups = std::max(maxgroups, (int)grp.size() - gptr[kh]);
+    }
+    gptr[N] = (int32_t)grp.size();
+    if (maxrow > 65535) { qmri_set_error(ctx, "a k-space row holds %d samples; at most 65535 are supported", maxrow); return QMRI_ERR_UNSUPPORTED; }
+    QMRI_TRY(dev_alloc(ctx, &o.d_grp, grp.size()));
+    QMRI_TRY(dev_alloc(ctx, &o.d_gptr, gptr.size()));
+    QMRI_TRY(dev_alloc(ctx, &o.d_gkw, gkw.size()));
+    QMRI_HIP(ctx, hipMemcpy(o.d_grp, grp.data(), grp.size() * sizeof(KGroup), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_gptr, gptr.data(), gptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipMemcpy(o.d_gkw, gkw.data(), gkw.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     ls.nblk_h = dc_lsqr_nblk_h(M, s);
-    if (!dc_lsqr_plan(N, T, s, maxrow, &ls.ucap, &ls.vcap)) {
+    ls.gcap = std::max(maxgroups, 1);
+    if (!dc_lsqr_plan(N, T, s, maxrow, ls.gcap, &ls.ucap, &ls.vcap)) {
         qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
         return QMRI_ERR_UNSUPPORTED;
     }
@@ -293,7 +321,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &ls.pz, B * ls.nblk_z));
     ls.stamps = nullptr;
     if (const char* e = getenv("QMRI_LSQR_STAMPS")) {
-        if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ls.stamps, (size_t)2 * 512 * 8)); QMRI_HIP(ctx, hipMemset(ls.stamps, 0, 2 * 512 * 8 * 8)); }
+        if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ls.stamps, (size_t)2 * 512 * 16)); QMRI_HIP(ctx, hipMemset(ls.stamps, 0, 2 * 512 * 16 * 8)); }
     }
     QMRI_TRY(dev_alloc(ctx, &ls.ut, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &ls.ub, B * n));
@@ -500,11 +528,11 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
     return QMRI_OK;
 }
 
-// diagnostic: phase stamps of the most recent LSQR launches (see lsqr_kernels.hip); out holds 2*512*8 values
+// diagnostic: phase stamps of the most recent LSQR launches (see lsqr_kernels.hip); out holds 2*512*16 values
 extern "C" int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out) {
     if (!ctx || !ctx->op.ls.stamps) return QMRI_ERR_STATE;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    QMRI_HIP(ctx, hipMemcpy(out, ctx->op.ls.stamps, (size_t)2 * 512 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    QMRI_HIP(ctx, hipMemcpy(out, ctx->op.ls.stamps, (size_t)2 * 512 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QMRI_OK;
 }
 

@@ -33,14 +33,14 @@ namespace {
 
 constexpr int NTW = 512;         // threads of k_lsqr_w
 constexpr int NE_PRE = 5;        // samples per thread of k_lsqr_w requested up front (5 * 512 = 2560 >= the busiest spiral row)
-constexpr int SL = 8;            // lanes sharing one scatter item (one k location, all channels)
+constexpr int SL = 8;            // lanes sharing one scatter group (<= DC_GCAP samples of one k location, all channels)
 constexpr int LH = 8;            // lines per k_lsqr_h block
 
 // phase stamps of the last launch (slice 0), 100 MHz constant clock; costs one scalar branch when disabled
 #define LSQR_STAMP(KID, k)                                                                       \
     do {                                                                                         \
         if (ls.stamps && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 512)                \
-            ls.stamps[((KID)*512 + blockIdx.x) * 8 + (k)] = wall_clock64();                      \
+            ls.stamps[((KID)*512 + blockIdx.x) * 16 + (k)] = wall_clock64();                      \
     } while (0)
 
 // Canonical sum of n partials, computed by one wave: 64 strided columns, then a shuffle tree.  Every block of both
@@ -96,10 +96,11 @@ __device__ __forceinline__ double2 ub_update(double2 v, double2 ub, double sr, d
 }
 
 // dynamic LDS of k_lsqr_w, in bytes, for a staging capacity of ucap samples
-template <int R1, int R2> constexpr size_t lsqr_w_lds(int ucap, int vcap) {
-    return (size_t)DC_MAXS * Plan<R1, R2>::LINE * 16 + (size_t)ucap * 16 + (size_t)Plan<R1, R2>::N * 16 + (size_t)vcap * 8 +
-           2 * (NTW / 64) * 8 + ((Plan<R1, R2>::N + 4) & ~3) * 4 + (size_t)ucap * 2;
+template <int R1, int R2> constexpr size_t lsqr_w_lds(int ucap, int vcap, int gcap) {
+    return (size_t)DC_MAXS * Plan<R1, R2>::LINE * 16 + (size_t)ucap * 16 + (size_t)Plan<R1, R2>::N * 16 +
+           (size_t)gcap * DC_MAXS * 16 + (size_t)vcap * 8 + 2 * (NTW / 64) * 8 + ((Plan<R1, R2>::N + 4) & ~3) * 4 + (size_t)ucap * 2;
 }
+constexpr int NG_PRE = 2;        // scatter groups per 8 lanes requested up front (2 * 512 / 8 = 128 groups)
 constexpr int NV_PRE = 4;        // V values per thread requested up front (4 * 512 = 2048 >= T*s of the reference: 200 * 10)
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -119,10 +120,11 @@ __global__ __launch_bounds__(NTW) void k_lsqr_w(OpDev op, LsqrDev ls, const doub
     cd* lds = (cd*)smem;                                   // s channel lines of the row
     double2* ulds = (double2*)(lds + DC_MAXS * P::LINE);   // the row's new u(1:m), k-sorted
     cd* twl = (cd*)(ulds + ucap);                          // twiddles
-    double* vlds = (double*)(twl + N);                     // V(t, c)
+    cd* part = twl + N;                                    // per scatter group: sum over its samples, all channels
+    double* vlds = (double*)(part + ls.gcap * DC_MAXS);    // V(t, c)
     double* red = vlds + vcap;
-    int* kl = (int*)(red + 2 * (NTW / 64));                // kptr of the row
-    unsigned short* tlds = (unsigned short*)(kl + ((N + 4) & ~3));   // frame of each staged sample
+    int* gl = (int*)(red + 2 * (NTW / 64));                // first scatter group of each kw of the row
+    unsigned short* tlds = (unsigned short*)(gl + ((N + 4) & ~3));   // frame of each staged sample
     constexpr int M = N;                                   // square grids only (checked by qmri_set_operator)
     const int tid = threadIdx.x, b = blockIdx.y, kh = blockIdx.x, s = op.s, sM = s * M;
     const size_t n = (size_t)s * N * M;
@@ -147,7 +149,11 @@ __global__ __launch_bounds__(NTW) void k_lsqr_w(OpDev op, LsqrDev ls, const doub
 #pragma unroll
     for (int q = 0; q < NV_PRE; ++q) { const int i = tid + NTW * q; rv[q] = op.Vt[(i < op.T * s) ? i : 0]; }
     const cd rtw = op.tw[(tid < N) ? tid : 0];
-    const int rk = op.kptr[kh * M + ((tid <= M) ? tid : 0)];
+    const int rk = op.gkw[kh * (M + 1) + ((tid <= M) ? tid : 0)];
+    const int gbase = op.gptr[kh], ng = op.gptr[kh + 1] - gbase;
+    KGroup rg[NG_PRE];
+#pragma unroll
+    for (int q = 0; q < NG_PRE; ++q) { const int g = (tid + NTW * q) / SL; rg[q] = op.grp[(g < ng) ? gbase + g : 0]; }
     const int hi0 = (r0 + ucap < r1) ? r0 + ucap : r1;     // end of the first (normally the only) chunk of samples
     KEntry ren[NE_PRE];
     double2 rut[NE_PRE];
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(NTW) void k_lsqr_w(OpDev op, LsqrDev ls, const doub
     for (int q = 0; q < NV_PRE; ++q) { const int i = tid + NTW * q; if (i < vcap) vlds[i] = rv[q]; }
     for (int i = tid + NTW * NV_PRE; i < op.T * s; i += NTW) vlds[i] = op.Vt[i];
     if (tid < N) twl[tid] = rtw;
-    if (tid <= M) kl[tid] = rk;
+    if (tid <= M) gl[tid] = rk;
     double alpha = 0.0, inv_alpha = 1.0, inv_bprev = 1.0;
     const double sr = ls.sr;
     lds_barrier();
@@ -248,9 +254,40 @@ __global__ __launch_bounds__(NTW) void k_lsqr_w(OpDev op, LsqrDev ls, const doub
     }
     LSQR_STAMP(0, 4);
 
-    // ---- scatter-combine: SL lanes per k location add its samples (frame order, interleaved over the lanes) for all
-    // channels from LDS and combine in a fixed tree; atomics-free.  The gather is complete, so the lines are reused.
-    constexpr int NQT = (N * SL + NTW - 1) / NTW;
+    // ---- scatter-combine.  SL lanes per group (<= DC_GCAP samples of one k location) add their samples for all channels
+    // from LDS and combine in a fixed tree; a k location's groups are then added in order.  Atomics-free, fixed order.
+    auto group_sum = [&](const KGroup g, int sub, int lo_rel, int hi_rel, cd* dst, bool first) {
+        double xr[DC_MAXS], xi[DC_MAXS];
+#pragma unroll
+        for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
+        double2 u[DC_GCAP / SL];
+        int t[DC_GCAP / SL];
+#pragma unroll
+        for (int j = 0; j < DC_GCAP / SL; ++j) {           // all of the lane's samples in flight at once
+            const int e = g.b + sub + SL * j;
+            const bool ok = e < g.e && e >= lo_rel && e < hi_rel;
+            const int ec = ok ? e - lo_rel : 0;
+            u[j] = ulds[ec]; t[j] = tlds[ec];
+            if (!ok) u[j] = make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < DC_GCAP / SL; ++j) {
+#pragma unroll
+            for (int c = 0; c < DC_MAXS; ++c) {
+                const double v = vlds[t[j] * s + c];       // (c >= s reads a neighbour: finite garbage into unused sums)
+                xr[c] += v * u[j].x; xi[c] += v * u[j].y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group8_sum(xr[c]); xi[c] = group8_sum(xi[c]); }
+        if (sub == 0) {
+#pragma unroll
+            for (int c = 0; c < DC_MAXS; ++c) {
+                if (first) dst[c] = mk(xr[c], xi[c]);
+                else { const cd o = dst[c]; dst[c] = mk(o.x + xr[c], o.y + xi[c]); }
+            }
+        }
+    };
     for (int ch = 0; ch < nch; ++ch) {
         const int lo = r0 + ch * ucap, hi = (lo + ucap < r1) ? lo + ucap : r1;
         if (nch > 1) {
@@ -258,42 +295,22 @@ __global__ __launch_bounds__(NTW) void k_lsqr_w(OpDev op, LsqrDev ls, const doub
             for (int i = tid; i < hi - lo; i += NTW) { ulds[i] = ls.ut[mb + lo + i]; tlds[i] = op.ent[lo + i].t; }
         }
         lds_barrier();                                     // staged samples visible
-        for (int q = 0; q < NQT; ++q) {
-            const int tau = tid + NTW * q, kwq = tau / SL, sub = tau - kwq * SL;
-            const bool valid = kwq < M;
-            const int kw = valid ? kwq : 0;
-            int a0 = kl[kw], a1 = kl[kw + 1];
-            a0 = (a0 > lo) ? a0 : lo; a1 = (a1 < hi) ? a1 : hi;
-            if (!valid) a1 = a0;
-            double xr[DC_MAXS], xi[DC_MAXS];
+        LSQR_STAMP(0, 8);
 #pragma unroll
-            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
-            for (int e = a0 - lo + sub; e < a1 - lo; e += SL) {
-                const double2 u = ulds[e];
-                const int t = tlds[e];
-#pragma unroll
-                for (int c = 0; c < DC_MAXS; ++c) {
-                    const double v = vlds[t * s + c];      // (c >= s reads a neighbour: finite garbage into unused sums)
-                    xr[c] += v * u.x; xi[c] += v * u.y;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group8_sum(xr[c]); xi[c] = group8_sum(xi[c]); }
-            if (valid && sub == 0) {
-#pragma unroll
-                for (int c = 0; c < DC_MAXS; ++c) {
-                    if (c < s) {
-                        cd* dst = lds + c * P::LINE + kw;  // conjugate: inverse transform by conj-FFT-conj
-                        if (ch == 0) *dst = mk(xr[c], -xi[c]);
-                        else { const cd o = *dst; *dst = mk(o.x + xr[c], o.y - xi[c]); }
-                    }
-                }
-            }
+        for (int q = 0; q < NG_PRE; ++q) {
+            const int g = (tid + NTW * q) / SL;
+            if (g < ng) group_sum(rg[q], tid & (SL - 1), lo - r0, hi - r0, part + g * DC_MAXS, ch == 0);
+            LSQR_STAMP(0, 9 + q);
         }
+        for (int g = (tid + NTW * NG_PRE) / SL; g < ng; g += NTW / SL)
+            group_sum(op.grp[gbase + g], tid & (SL - 1), lo - r0, hi - r0, part + g * DC_MAXS, ch == 0);
     }
-    if (nch == 0) {                                        // never-sampled row
-        lds_barrier();
-        for (int i = tid; i < sM; i += NTW) { const int c = i / M, w = i - c * M; lds[c * P::LINE + w] = mk(0.0, 0.0); }
+    lds_barrier();                                         // group sums complete; every gather read of the lines is done
+    for (int i = tid; i < sM; i += NTW) {
+        const int kw = i / s, c = i - kw * s;
+        double xr = 0.0, xi = 0.0;
+        if (nch > 0) for (int g = gl[kw]; g < gl[kw + 1]; ++g) { const cd p = part[g * DC_MAXS + c]; xr += p.x; xi += p.y; }
+        lds[c * P::LINE + kw] = mk(xr, -xi);               // conjugate: inverse transform by conj-FFT-conj
     }
     LSQR_STAMP(0, 5);
     block_sum2_t<NTW>(acc_b, acc_t, red);
@@ -478,7 +495,7 @@ int launch_lsqr_t(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, bool init, 
                   const double2* z, double2* tmp, double2* xio) {
     dim3 gh(op.s * op.M / LH, B), gw(op.N, B);
     hipStream_t st = ctx->stream;
-    const size_t wlds = lsqr_w_lds<R1, R2>(ls.ucap, ls.vcap);
+    const size_t wlds = lsqr_w_lds<R1, R2>(ls.ucap, ls.vcap, ls.gcap);
     bool& attr_set = ctx->lsqr_lds_attr[R1 == 16 ? (R2 == 14 ? 0 : 1) : (R2 == 8 ? 2 : 3)];   // > 64 KB of dynamic LDS must be allowed once
     if (!attr_set) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_lsqr_w<R1, R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -502,11 +519,11 @@ int dc_lsqr_nblk_h(int M, int s) { return s * M / LH; }
 
 // LDS plan of k_lsqr_w: V (T*s doubles, padded) always lives in LDS; the staging area takes the busiest k-row if it
 // fits in what is left of the 160 KB, else rows are processed in chunks.  Returns false if V itself cannot fit.
-bool dc_lsqr_plan(int N, int T, int s, int maxrow, int* ucap_out, int* vcap_out) {
+bool dc_lsqr_plan(int N, int T, int s, int maxrow, int maxgroups, int* ucap_out, int* vcap_out) {
     const int vcap = ((T * s + DC_MAXS + 15) / 16) * 16;
     int ucap = ((std::max(maxrow, 1) + NTW - 1) / NTW) * NTW;
     if (const char* e = getenv("QMRI_LSQR_UCAP")) { const int v = atoi(e); if (v >= NTW && v % NTW == 0) ucap = std::min(ucap, v); }   // test hook
-    const size_t fixed = (size_t)DC_MAXS * (N + 32) * 16 + (size_t)N * 16 + (size_t)vcap * 8 + 128 + (size_t)(N + 4) * 4;
+    const size_t fixed = (size_t)DC_MAXS * (N + 32) * 16 + (size_t)N * 16 + (size_t)maxgroups * DC_MAXS * 16 + (size_t)vcap * 8 + 128 + (size_t)(N + 4) * 4;
     const size_t budget = 160 * 1024 - 1024;
     if (fixed + (size_t)NTW * 18 > budget) return false;
     while ((size_t)ucap * 18 + fixed > budget) ucap -= NTW;

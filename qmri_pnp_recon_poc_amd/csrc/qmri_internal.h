@@ -46,6 +46,10 @@ struct KEntry {          // one sample of the k-sorted measurement list
     uint16_t t;          // frame
 };
 
+// scatter work unit of k_lsqr_w: up to DC_GCAP consecutive samples of one k location, offsets relative to the row start
+struct KGroup { uint16_t kw, b, e, pad; };
+constexpr int DC_GCAP = 32;
+
 struct OpDev {
     int N, M, s, T, m;
     const double* Vt;        // [T][s]  V(t,c), frame-major
@@ -55,6 +59,9 @@ struct OpDev {
     const double2* tw;       // [N]     exp(-2*pi*i*j/N)
     const int32_t* kslot;    // [N*M]   DIRECT solver: slot of k' among sampled locations or -1
     const double* ginv;      // [nsampled][s*s] (G_k + r I)^-1, symmetric, row-major
+    const KGroup* grp;       // scatter groups, row after row
+    const int32_t* gptr;     // [N+1]   first group of each k-row
+    const int32_t* gkw;      // [N][M+1] per row: first group (relative to the row's) of each kw
 };
 
 // LSQR (PnP_ADMM.m:102) device state, one per slice
@@ -82,7 +89,7 @@ struct LsqrDev {
     double2* d;              // [B][n]
     double2* yk;             // [B][m]  y in k-sorted order
     int npu, nblk_h, nblk_z;
-    int ucap, vcap;          // LDS plan of k_lsqr_w: samples of one k-row staged at once; doubles reserved for V
+    int ucap, vcap, gcap;    // LDS plan of k_lsqr_w: samples of one k-row staged at once; doubles for V; scatter groups per row
     double sr;               // sqrt(r)
     double tol;              // cg_tol
     int maxit;
@@ -136,6 +143,7 @@ struct OpHost {
     int N = 0, M = 0, s = 0, T = 0, m = 0, maxB = 0, nsampled = 0;
     double* d_Vt = nullptr; KEntry* d_ent = nullptr; int32_t* d_perm = nullptr; int32_t* d_kptr = nullptr;
     double2* d_tw = nullptr; int32_t* d_kslot = nullptr; double* d_ginv = nullptr;
+    KGroup* d_grp = nullptr; int32_t* d_gptr = nullptr; int32_t* d_gkw = nullptr;
     double ginv_r = -1.0;
     std::vector<double> V;              // T x s column-major (host copy)
     std::vector<int32_t> frame_ptr, kidx, kptr_h, perm_h;
@@ -186,7 +194,7 @@ OpDev qmri_opdev(const qmri_ctx* ctx);
 // ---------------------------------------------------------------------------------------------------
 bool dc_size_supported(int N);
 int dc_lsqr_nblk_h(int M, int s);       // blocks of k_lsqr_h (= partial sums of |v|^2 per slice)
-bool dc_lsqr_plan(int N, int T, int s, int maxrow, int* ucap, int* vcap);   // LDS plan of k_lsqr_w; false: V does not fit
+bool dc_lsqr_plan(int N, int T, int s, int maxrow, int maxgroups, int* ucap, int* vcap);   // LDS plan of k_lsqr_w; false: V does not fit
 // forward:  src [B][n] -> (mode-dependent) ; tmp workspace [B][n]
 int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src, double2* tmp,
                   double2* y_out, double* pdiag);

@@ -16,17 +16,18 @@ x0 = eng.adjoint(y)
 x, it, flag = eng.xupdate(y, x0 * 0.9, 0.05, 1e-4, int(sys.argv[1]) if len(sys.argv) > 1 else 6, x0=x0)
 lib = load()
 lib.qmri_debug_lsqr_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-buf = np.zeros((2, 512, 8), np.uint64)
+buf = np.zeros((2, 512, 16), np.uint64)
 assert lib.qmri_debug_lsqr_stamps(eng.h, buf.ctypes.data) == 0
 print('lsqr iters', it, 'flag', flag)
-for kid, name, nb, nst in ((0, 'k_lsqr_w', 224, 7), (1, 'k_lsqr_h', 280, 5)):
-    s = buf[kid, :nb, :nst].astype(np.int64)
+for kid, name, nb, order in ((0, 'k_lsqr_w', 224, [0, 1, 2, 3, 4, 8, 9, 10, 5, 6]), (1, 'k_lsqr_h', 280, [0, 1, 2, 3, 4])):
+    s = buf[kid, :nb][:, order].astype(np.int64)
+    nst = len(order)
     t0 = s[:, 0].min()
     rel = (s - t0) / 100.0                     # us
     print(name, 'blocks', nb, ' kernel span %.1f us' % rel[:, -1].max())
     print('  start: min %.1f max %.1f' % (rel[:, 0].min(), rel[:, 0].max()))
     d = np.diff(rel, axis=1)
     for k in range(nst - 1):
-        print('  phase %d->%d : mean %.2f  max %.2f (block %d)' % (k, k + 1, d[:, k].mean(), d[:, k].max(), d[:, k].argmax()))
+        print('  phase %2d->%2d : mean %.2f  max %.2f (block %d)' % (order[k], order[k + 1], d[:, k].mean(), d[:, k].max(), d[:, k].argmax()))
     tot = rel[:, -1] - rel[:, 0]
     print('  block total: mean %.1f max %.1f (block %d)' % (tot.mean(), tot.max(), tot.argmax()))
