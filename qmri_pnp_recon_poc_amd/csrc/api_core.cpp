@@ -69,8 +69,11 @@ static void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 void qmri_free_operator(qmri_ctx* ctx) {
     OpHost& o = ctx->op;
-    void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_grp, o.d_gptr, o.d_gkw, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
-                     o.ls.st, o.ls.pu[0], o.ls.pu[1], o.ls.pv[0], o.ls.pv[1], o.ls.pz, o.ls.ut, o.ls.ub, o.ls.v, o.ls.d, o.ls.yk, o.ls.stamps,
+    void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
+                     o.ls.st, o.ls.pz, o.ls.yk,
+                     (void*)o.ks.bslot, (void*)o.ks.sptr, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.gptr, (void*)o.ks.sgrp,
+                     o.ks.pu[0], o.ks.pu[1], o.ks.pv[0], o.ks.pv[1], o.ks.pinit, o.ks.pR, o.ks.cx, o.ks.cv, o.ks.cd, o.ks.cub,
+                     o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.stamps,
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
     for (void* p : ptrs) free_dev(p);
     if (o.h_state) (void)hipHostFree(o.h_state);
@@ -190,7 +193,6 @@ OpDev qmri_opdev(const qmri_ctx* ctx) {
     d.N = o.N; d.M = o.M; d.s = o.s; d.T = o.T; d.m = o.m;
     d.Vt = o.d_Vt; d.ent = o.d_ent; d.perm = o.d_perm; d.kptr = o.d_kptr; d.tw = o.d_tw;
     d.kslot = o.d_kslot; d.ginv = o.d_ginv;
-    d.grp = o.d_grp; d.gptr = o.d_gptr; d.gkw = o.d_gkw;
     return d;
 }
 
@@ -273,60 +275,89 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_HIP(ctx, hipMemcpy(o.d_kslot, kslot.data(), (size_t)NM * sizeof(int32_t), hipMemcpyHostToDevice));
 
     LsqrDev& ls = o.ls;
-    // scatter groups of the LSQR w-pass kernel: every sampled k location of a row, split into runs of <= DC_GCAP samples
-    int maxrow = 0, maxgroups = 0;
-    std::vector<KGroup> grp;
-    std::vector<int32_t> gptr(N + 1, 0), gkw((size_t)N * (M + 1), 0);
-    for (int kh = 0; kh < N; ++kh) {
-        const int r0 = o.kptr_h[kh * M];
-        maxrow = std::max(maxrow, o.kptr_h[(kh + 1) * M] - r0);
-        gptr[kh] = (int32_t)grp.size();
-        for (int kw = 0; kw < M; ++kw) {
-            gkw[(size_t)kh * (M + 1) + kw] = (int32_t)grp.size() - gptr[kh];
-            for (int e = o.kptr_h[kh * M + kw]; e < o.kptr_h[kh * M + kw + 1]; e += DC_GCAP) {
-                KGroup g;
-                g.kw = (uint16_t)kw; g.b = (uint16_t)(e - r0);
-                g.e = (uint16_t)(std::min(e + DC_GCAP, o.kptr_h[kh * M + kw + 1]) - r0); g.pad = 0;
-                grp.push_back(g);
+    // ---- k-space LSQR plan (kslsqr_kernels.hip): the sampled k locations ("slots", k' order) are cut into work units of
+    // similar sample count, each unit's samples into scatter groups of <= DC_GCAP samples of one slot
+    KsDev& ks = o.ks;
+    {
+        const int ns = o.nsampled;
+        std::vector<int32_t> sptr(ns + 1), sgrp(ns + 1), bslot, gptr;
+        std::vector<KSample> es(m);
+        std::vector<KsGroup> grp;
+        {
+            int j = 0;
+            for (int kp = 0; kp < NM; ++kp) if (kslot[kp] >= 0) sptr[j++] = o.kptr_h[kp];
+            sptr[ns] = m;
+        }
+        const int target = std::max(1, (m + 255) / 256);
+        int j = 0;
+        while (j < ns) {
+            const int first = j, e0 = sptr[j];
+            int ngr = 0;
+            bslot.push_back(first);
+            gptr.push_back((int32_t)grp.size());
+            while (j < ns) {
+                const int cnt = sptr[j + 1] - sptr[j], gj = (cnt + DC_GCAP - 1) / DC_GCAP;
+                if (cnt > KS_ECAP || cnt > 65535) { qmri_set_error(ctx, "a k location is sampled %d times; at most %d are supported", cnt, KS_ECAP); return QMRI_ERR_UNSUPPORTED; }
+                const int have = sptr[j] - e0;
+                if (j > first && (j - first >= KS_SCAP || have + cnt > KS_ECAP || ngr + gj > KS_GCAPB || have + cnt / 2 > target)) break;
+                sgrp[j] = (int32_t)grp.size();
+                for (int e = sptr[j]; e < sptr[j + 1]; e += DC_GCAP) {
+                    KsGroup g;
+                    g.ls = (uint16_t)(j - first); g.b = (uint16_t)(e - e0); g.e = (uint16_t)(std::min(e + DC_GCAP, sptr[j + 1]) - e0); g.pad = 0;
+                    grp.push_back(g);
+                }
+                for (int e = sptr[j]; e < sptr[j + 1]; ++e) { es[e].ls = (uint16_t)(j - first); es[e].t = o.ent_h[e].t; }
+                ngr += gj;
+                ++j;
             }
         }
-        gkw[(size_t)kh * (M + 1) + M] = (int32_t)grp.size() - gptr[kh];
-        maxgroups = std::max(maxgroups, (int)grp.size() - gptr[kh]);
+        bslot.push_back(ns);
+        gptr.push_back((int32_t)grp.size());
+        sgrp[ns] = (int32_t)grp.size();
+        ks.ns = ns; ks.G = (int)bslot.size() - 1;
+        ks.vcap = ((T * s + 10 + 15) / 16) * 16;       // (+10: the channel loops of the kernels are unrolled to 10)
+        if ((size_t)ks.vcap * 8 + (size_t)s * M * 16 > 96 * 1024) {
+            qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
+            return QMRI_ERR_UNSUPPORTED;
+        }
+        int32_t* p32; KSample* pes; KsGroup* pg;
+#define KS_UPLOAD(ptr, field, vec, T_)                                                                 \
+        QMRI_TRY(dev_alloc(ctx, &ptr, (vec).size()));                                                  \
+        QMRI_HIP(ctx, hipMemcpy(ptr, (vec).data(), (vec).size() * sizeof(T_), hipMemcpyHostToDevice)); \
+        ks.field = ptr;
+        KS_UPLOAD(p32, bslot, bslot, int32_t)
+        KS_UPLOAD(p32, sptr, sptr, int32_t)
+        KS_UPLOAD(p32, gptr, gptr, int32_t)
+        KS_UPLOAD(p32, sgrp, sgrp, int32_t)
+        KS_UPLOAD(pes, es, es, KSample)
+        KS_UPLOAD(pg, grp, grp, KsGroup)
+#undef KS_UPLOAD
+        ctx->ks_lds_attr[0] = ctx->ks_lds_attr[1] = false;
     }
-    gptr[N] = (int32_t)grp.size();
-    if (maxrow > 65535) { qmri_set_error(ctx, "a k-space row holds %d samples; at most 65535 are supported", maxrow); return QMRI_ERR_UNSUPPORTED; }
-    QMRI_TRY(dev_alloc(ctx, &o.d_grp, grp.size()));
-    QMRI_TRY(dev_alloc(ctx, &o.d_gptr, gptr.size()));
-    QMRI_TRY(dev_alloc(ctx, &o.d_gkw, gkw.size()));
-    QMRI_HIP(ctx, hipMemcpy(o.d_grp, grp.data(), grp.size() * sizeof(KGroup), hipMemcpyHostToDevice));
-    QMRI_HIP(ctx, hipMemcpy(o.d_gptr, gptr.data(), gptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    QMRI_HIP(ctx, hipMemcpy(o.d_gkw, gkw.data(), gkw.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    ls.nblk_h = dc_lsqr_nblk_h(M, s);
-    ls.gcap = std::max(maxgroups, 1);
-    if (!dc_lsqr_plan(N, T, s, maxrow, ls.gcap, &ls.ucap, &ls.vcap)) {
-        qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
-        return QMRI_ERR_UNSUPPORTED;
-    }
-    ls.npu = 2 * N;
     ls.nblk_z = 256;
     QMRI_TRY(dev_alloc(ctx, &o.d_tmp, B * n));
     QMRI_TRY(dev_alloc(ctx, &o.d_xa, B * n));
     QMRI_TRY(dev_alloc(ctx, &o.d_xb, B * n));
     QMRI_TRY(dev_alloc(ctx, &o.d_ya, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &ls.st, B));
-    QMRI_TRY(dev_alloc(ctx, &ls.pu[0], B * ls.npu));
-    QMRI_TRY(dev_alloc(ctx, &ls.pu[1], B * ls.npu));
-    QMRI_TRY(dev_alloc(ctx, &ls.pv[0], B * ls.nblk_h));
-    QMRI_TRY(dev_alloc(ctx, &ls.pv[1], B * ls.nblk_h));
     QMRI_TRY(dev_alloc(ctx, &ls.pz, B * ls.nblk_z));
-    ls.stamps = nullptr;
-    if (const char* e = getenv("QMRI_LSQR_STAMPS")) {
-        if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ls.stamps, (size_t)2 * 512 * 16)); QMRI_HIP(ctx, hipMemset(ls.stamps, 0, 2 * 512 * 16 * 8)); }
+    for (int par = 0; par < 2; ++par) {
+        QMRI_TRY(dev_alloc(ctx, &ks.pu[par], B * 2 * ks.G));
+        QMRI_TRY(dev_alloc(ctx, &ks.pv[par], B * ks.G));
     }
-    QMRI_TRY(dev_alloc(ctx, &ls.ut, B * (size_t)m));
-    QMRI_TRY(dev_alloc(ctx, &ls.ub, B * n));
-    QMRI_TRY(dev_alloc(ctx, &ls.v, B * n));
-    QMRI_TRY(dev_alloc(ctx, &ls.d, B * n));
+    QMRI_TRY(dev_alloc(ctx, &ks.pinit, B * 2 * N));
+    QMRI_TRY(dev_alloc(ctx, &ks.pR, B * N));
+    QMRI_TRY(dev_alloc(ctx, &ks.cx, B * ks.ns * s));
+    QMRI_TRY(dev_alloc(ctx, &ks.cv, B * ks.ns * s));
+    QMRI_TRY(dev_alloc(ctx, &ks.cd, B * ks.ns * s));
+    QMRI_TRY(dev_alloc(ctx, &ks.cub, B * ks.ns * s));
+    QMRI_TRY(dev_alloc(ctx, &ks.ut, B * (size_t)m));
+    QMRI_TRY(dev_alloc(ctx, &ks.xhat, B * n));
+    QMRI_TRY(dev_alloc(ctx, &ks.zhat, B * n));
+    ks.stamps = nullptr;
+    if (const char* e = getenv("QMRI_LSQR_STAMPS")) {
+        if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ks.stamps, (size_t)2 * 512 * 16)); QMRI_HIP(ctx, hipMemset(ks.stamps, 0, 2 * 512 * 16 * 8)); }
+    }
     QMRI_TRY(dev_alloc(ctx, &ls.yk, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &o.d_x, B * n));
     QMRI_TRY(dev_alloc(ctx, &o.d_u, B * n));
@@ -338,6 +369,8 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &o.d_pd, B * ((size_t)N + 2 * ls.nblk_z)));
     QMRI_HIP(ctx, hipMemset(ls.st, 0, B * sizeof(LsqrState)));
     QMRI_HIP(ctx, hipHostMalloc((void**)&o.h_state, B * sizeof(LsqrState), hipHostMallocDefault));
+    ks.st = ls.st; ks.pz = ls.pz; ks.nblk_z = ls.nblk_z; ks.yk = ls.yk; ks.pdiag = nullptr;
+    o.xhat_valid = false;
     o.ginv_r = -1.0;
     o.ready = true;
     return QMRI_OK;
@@ -455,33 +488,39 @@ int qmri_prepare_direct(qmri_ctx* ctx, double r) {
     return QMRI_OK;
 }
 
-// LSQR on B slices; requires ls.yk / ny2 (dc_launch_sort_y) and ls.pz (dc_launch_prepare_z) to be current.
+// LSQR on B slices, iterated in k-space (kslsqr_kernels.hip).  Requires ls.yk / ny2 (dc_launch_sort_y) and ls.pz
+// (dc_launch_prepare_z) to be current.  d_x holds x0 on entry and the solution on return; when o.xhat_valid the spectrum of
+// x0 is taken from the previous solve instead of being recomputed.  pdiag (or null) receives [B][N] partials of ||y - A x||^2.
 int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
-                  int32_t* iters_out, int32_t* flag_out) {
+                  int32_t* iters_out, int32_t* flag_out, double* pdiag) {
     OpHost& o = ctx->op;
     const OpDev op = qmri_opdev(ctx);
-    LsqrDev ls = o.ls;
-    ls.sr = std::sqrt(r); ls.tol = tol; ls.maxit = maxit; ls.ii = 0;
-    QMRI_TRY(dc_launch_fwd(ctx, op, ls, DC_FWD_H_ONLY, B, d_x, o.d_tmp, nullptr, nullptr));
-    QMRI_TRY(dc_launch_lsqr(ctx, op, ls, true, B, d_x, d_z, o.d_tmp, d_x));
+    KsDev ks = o.ks;
+    ks.sr = std::sqrt(r); ks.tol = tol; ks.maxit = maxit; ks.ii = 0; ks.pdiag = pdiag;
+    if (!o.xhat_valid) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_x, o.d_tmp, ks.xhat, nullptr));
+    QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_z, o.d_tmp, ks.zhat, nullptr));
+    QMRI_TRY(ks_launch_init(ctx, op, ks, B));
     int launched = 0;
     int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
     bool all_done = false;
     while (launched < maxit && !all_done) {
         const int nthis = std::min(chunk, maxit - launched);
         for (int k = 0; k < nthis; ++k) {
-            ls.ii = launched + k + 1;
-            QMRI_TRY(dc_launch_lsqr(ctx, op, ls, false, B, nullptr, nullptr, o.d_tmp, d_x));
+            ks.ii = launched + k + 1;
+            QMRI_TRY(ks_launch_iter(ctx, op, ks, B));
         }
         launched += nthis;
-        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ls.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
+        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ks.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
         all_done = true;
         for (int b = 0; b < B; ++b) all_done = all_done && o.h_state[b].done;
         chunk = 2;
     }
+    QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));
+    QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
+    o.xhat_valid = true;
     if (maxit <= 0) {
-        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ls.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
+        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ks.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     int worst = 0;
@@ -511,7 +550,8 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
         // ||z||^2 partials: reuse prepare_z with u = 0
         QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, n * sizeof(double2), ctx->stream));
         QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, 1, o.d_z, o.d_u, o.d_vv));
-        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out));
+        o.xhat_valid = false;
+        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out, nullptr));
     } else if (solver == QMRI_SOLVER_DIRECT) {
         QMRI_TRY(qmri_prepare_direct(ctx, r));
         QMRI_TRY(dc_launch_adj(ctx, op, 1, o.d_ya, o.d_tmp, o.d_xa));
@@ -530,9 +570,9 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
 
 // diagnostic: phase stamps of the most recent LSQR launches (see lsqr_kernels.hip); out holds 2*512*16 values
 extern "C" int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out) {
-    if (!ctx || !ctx->op.ls.stamps) return QMRI_ERR_STATE;
+    if (!ctx || !ctx->op.ks.stamps) return QMRI_ERR_STATE;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    QMRI_HIP(ctx, hipMemcpy(out, ctx->op.ls.stamps, (size_t)2 * 512 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    QMRI_HIP(ctx, hipMemcpy(out, ctx->op.ks.stamps, (size_t)2 * 512 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QMRI_OK;
 }
 

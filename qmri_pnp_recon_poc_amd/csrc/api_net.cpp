@@ -13,7 +13,7 @@
 void qmri_free_operator(qmri_ctx* ctx);
 int qmri_prepare_direct(qmri_ctx* ctx, double r);
 int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
-                  int32_t* iters_out, int32_t* flag_out);
+                  int32_t* iters_out, int32_t* flag_out, double* pdiag);
 
 // ---------------------------------------------------------------------------------------------------
 // denoiser
@@ -310,12 +310,15 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         QMRI_HIP(ctx, hipMalloc((void**)&o.d_diag, (size_t)B * std::max(prm->iters, 1) * 2 * sizeof(double)));
     }
     std::vector<int32_t> it_b(B);
+    o.xhat_valid = false;                                  // x was just set: its spectrum is not known yet
+    const bool diag = prm->want_diag && diag_out;
     for (int it = 0; it < prm->iters; ++it) {
         // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
         tm.start();
         QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, B, o.d_vv, o.d_u, o.d_z));
         if (prm->solver == QMRI_SOLVER_LSQR) {
-            QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr));
+            QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr,
+                                   diag ? o.d_pd : nullptr));          // (the data-fidelity partials come with the solve)
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
         } else {
             QMRI_TRY(dc_launch_direct(ctx, op, B, o.d_z, o.d_chat, prm->gamma, o.d_tmp, o.d_x));
@@ -324,7 +327,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_xupdate);
         if (prm->want_diag && diag_out) {                                                                    // PnP_ADMM.m:106-109
             tm.start();
-            QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_DIAG, B, o.d_x, o.d_tmp, nullptr, o.d_pd));
+            if (prm->solver != QMRI_SOLVER_LSQR) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_DIAG, B, o.d_x, o.d_tmp, nullptr, o.d_pd));
             QMRI_TRY(ew_launch_diag(ctx, op, o.ls, B, o.d_x, (const double2*)d_gt, o.d_pd, o.d_diag, prm->iters, it));
             tm.stop(ctx->prof.ms_diag);
         }

@@ -94,4 +94,41 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
     a = ra; b = rb;
 }
 
+// Canonical sum of n partials, computed by one wave: 64 strided columns, then a shuffle tree.  Every block of both
+// kernels calls this with the same arrays, so alpha and beta carry the same bits everywhere.  Result valid in lane 0.
+__device__ __forceinline__ double wave_sum(const double* __restrict__ p, int n) {
+    const int lane = threadIdx.x & 63;
+    double r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int i = lane + 64 * q; r[q] = p[(i < n) ? i : 0]; }      // all in flight together
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += (lane + 64 * q < n) ? r[q] : 0.0;
+    for (int i = lane + 512; i < n; i += 64) a += p[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    return a;
+}
+
+// lane exchange inside groups of 8 lanes on the VALU (DPP), no LDS traffic
+template <int CTRL> __device__ __forceinline__ double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;   // lane i <-> 7-i ; quad_perm [1,0,3,2] ; [2,3,0,1]
+// a[0..7] of an aligned group of 8 lanes -> ((a0+a7)+(a1+a6)) + ((a2+a5)+(a3+a4)) in lane 0 of the group (fixed tree)
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_get<DPP_HALF_MIRROR>(v);
+    v += dpp_get<DPP_XOR1>(v);
+    v += dpp_get<DPP_XOR2>(v);
+    return v;
+}
+
+// u(m+1:end) update, shared by both kernels so that they produce the same bits:  sqrt(r) v - alpha (u / beta_prev)
+__device__ __forceinline__ double2 ub_update(double2 v, double2 ub, double sr, double alpha, double inv_bprev) {
+    return make_double2(__fma_rn(v.x, sr, -(alpha * (ub.x * inv_bprev))), __fma_rn(v.y, sr, -(alpha * (ub.y * inv_bprev))));
+}
+
 }  // namespace dcdev

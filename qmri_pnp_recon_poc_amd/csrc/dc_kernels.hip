@@ -356,6 +356,12 @@ int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, do
 #undef CALL_A
 }
 
+int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, double2* dst) {
+#define CALL_H(a, b) launch_adj_t<a, b>(ctx, op, B, nullptr, const_cast<double2*>(tmp), dst, true)
+    DC_DISPATCH(op.N, CALL_H)
+#undef CALL_H
+}
+
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
                      double2* tmp, double2* x_out) {
     LsqrDev ls{};

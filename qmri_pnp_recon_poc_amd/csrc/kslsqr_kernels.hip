@@ -1,0 +1,521 @@
+// kslsqr_kernels.hip -- the LSQR x-update of PnP-ADMM, iterated in k-space on the sampled locations only (gfx950).
+//
+// Reference semantics (file:line relative to the reference root):
+//   lsqr call  PnP_ADMM.m:102      x = lsqr(@afun, [y; sqrt(r) z], cg_tol, cg_iter, [], [], x0)
+//   afun       PnP_ADMM.m:153-171  B = [A; sqrt(r) I],  A = F.forward, A' = F.adjoint (main_recon_tsmis_FFT.m:228-229)
+//   (MathWorks lsqr restated from its documentation, as in oracle/orc_lsqr.c)
+//
+// A = P*U with U the unitary 2-D DFT (fft2/sqrt(NM)) and P the sample-and-combine-with-V operator, which only
+// couples the s channels of ONE k location.  Substituting xhat = U x turns B into [P; sqrt(r) I]: the same Krylov
+// iteration (same alpha, beta, rho, phi, same stopping tests, iterates related by the unitary U, i.e. equal up to
+// rounding) but without a single transform inside the loop.  Two further facts shrink it:
+//   * every k location is independent apart from the two norms per iteration (alpha = ||v||, beta = ||u||);
+//   * on a never-sampled k the operator is the scalar sqrt(r), so v, u(m+1:end), d and x - x0 stay multiples of
+//     zhat - xhat0 there: four scalars (ua, ub, uc, ue) and one number R = sum |zhat - xhat0|^2 carry 78 % of
+//     k-space (spiral mask) exactly.
+// The vectors of the iteration therefore live on the sampled locations ("slots"): ns*s complex numbers (1.8 MB at
+// 224 x 224 x 10 with the spiral mask), which stay in L2 for the whole solve.
+//
+//   k_ks_init_a  (block per k-row)  residual b - B*x0 in k-space: u(1:m) = y - P xhat0, u(m+1:end) = sqrt(r)(zhat - xhat0)
+//   k_ks_b<INIT> (block per work unit) beta0, v = B'u / beta0, d = 0
+//   k_ks_a       u = B v - alpha u          (needs alpha -> after k_ks_b)
+//   k_ks_b       scalars + stopping tests, d, x, v = B'u - beta v   (needs beta -> after k_ks_a)
+//   k_ks_final_w (block per k-row)  xhat = compact x on sampled k, xhat0 + ue (zhat - xhat0) elsewhere; ||y - P xhat||^2;
+//                                   inverse w-pass (the h-pass is k_adj_h of dc_kernels.hip)
+// Two launches per LSQR iteration; the two transforms per x-update (zhat in, x out) are outside the loop.
+// Norms are per-block partial sums combined by wave_sum (one fixed order for every consumer): run-to-run reproducible,
+// and every block takes the same convergence decision without a host round trip.
+#include <algorithm>
+#include <cstdlib>
+#include "dc_device.h"
+
+using namespace dcdev;
+
+namespace {
+
+constexpr int KT = 256;          // threads of every kernel in this file
+constexpr int SL = 8;            // lanes sharing one scatter group
+constexpr int NEQ = (KS_SCAP * DC_MAXS + KT - 1) / KT;   // (slot, channel) elements per thread
+constexpr int NSQ = KS_ECAP / KT;                          // samples per thread
+constexpr int NGQ = KS_GCAPB * SL / KT;                    // scatter groups per 8 lanes
+constexpr int NVQ = 8;                                     // V values per thread requested up front (8 * 256 = 2048)
+
+#define KS_STAMP(KID, k)                                                                         \
+    do {                                                                                         \
+        if (ks.stamps && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 512)                \
+            ks.stamps[((KID)*512 + blockIdx.x) * 16 + (k)] = wall_clock64();                     \
+    } while (0)
+
+__device__ __forceinline__ void load_v(const OpDev& op, double* rv) {
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) { const int i = threadIdx.x + KT * q; rv[q] = op.Vt[(i < op.T * op.s) ? i : 0]; }
+}
+__device__ __forceinline__ void store_v(const OpDev& op, const double* rv, double* vlds) {
+#pragma unroll
+    for (int q = 0; q < NVQ; ++q) { const int i = threadIdx.x + KT * q; if (i < op.T * op.s) vlds[i] = rv[q]; }
+    for (int i = threadIdx.x + KT * NVQ; i < op.T * op.s; i += KT) vlds[i] = op.Vt[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_ks_init_a : one block per k-row kh.  xhat0 / zhat rows -> compact x, u(m+1:end) on the sampled k; R on the rest;
+// u(1:m) = y - P xhat0 for the row's samples.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, kh = blockIdx.x, b = blockIdx.y, s = op.s, N = op.N, M = op.M, sM = s * M;
+    cd* lines = (cd*)smem;                                 // [c][kw] xhat0 of the row
+    double* vlds = (double*)(lines + sM);
+    __shared__ double red[3 * KT / 64];
+    const size_t n = (size_t)s * N * M;
+    const double sr = ks.sr;
+    double rv[NVQ];
+    load_v(op, rv);
+    double accS = 0.0, accR = 0.0;
+    for (int i = tid; i < sM; i += KT) {
+        const int c = i / M, kw = i - c * M;
+        const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
+        const double2 xv = ks.xhat[g], zv = ks.zhat[g];
+        lines[i] = xv;
+        const int slot = op.kslot[kh * M + kw];
+        if (slot >= 0) {
+            const size_t ci = ((size_t)b * ks.ns + slot) * s + c;
+            const double2 ub = make_double2(zv.x * sr - xv.x * sr, zv.y * sr - xv.y * sr);   // sqrt(r) z - sqrt(r) x0
+            ks.cx[ci] = xv;
+            ks.cub[ci] = ub;
+            accS += ub.x * ub.x + ub.y * ub.y;
+        } else {
+            const double dx = zv.x - xv.x, dy = zv.y - xv.y;
+            accR += dx * dx + dy * dy;
+        }
+    }
+    store_v(op, rv, vlds);
+    lds_barrier();
+    const size_t mb = (size_t)b * op.m;
+    double accT = 0.0;
+    for (int e = op.kptr[kh * M] + tid; e < op.kptr[(kh + 1) * M]; e += KT) {
+        const KEntry en = op.ent[e];
+        double re = 0.0, im = 0.0;
+        for (int c = 0; c < s; ++c) {
+            const double v = vlds[en.t * s + c];
+            const cd X = lines[c * M + en.kw];
+            re += v * X.x; im += v * X.y;
+        }
+        const double2 yv = ks.yk[mb + e];
+        const double2 u = make_double2(yv.x - re, yv.y - im);   // u(1:m) = y - A x0
+        ks.ut[mb + e] = u;
+        accT += u.x * u.x + u.y * u.y;
+    }
+    block_sum2(accS, accT, red);
+    const double r = block_sum(accR, red);
+    if (tid == 0) {
+        ks.pinit[(size_t)b * 2 * N + kh] = accS;
+        ks.pinit[(size_t)b * 2 * N + N + kh] = accT;
+        ks.pR[(size_t)b * N + kh] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_ks_a : u = B v - alpha (u / beta_prev) on one work unit (a run of slots and their samples).
+// v is stored un-normalised; 1/alpha is applied on the fly.  u(m+1:end) is only normed here (k_ks_b stores it).
+// partial sums: pu[ii&1][g] = |u(m+1:end)|^2 ,  pu[ii&1][G + g] = |u(1:m)|^2
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KT, 2) void k_ks_a(OpDev op, KsDev ks) {
+    __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]
+    __shared__ double red[2 * KT / 64];
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* vlds = (double*)smem;
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, s = op.s;
+    LsqrState* st = ks.st + b;
+    KS_STAMP(0, 0);
+    const int done = st->done;
+    const int s0 = ks.bslot[g], s1 = ks.bslot[g + 1], ne = (s1 - s0) * s;
+    const int e0 = ks.sptr[s0], nsamp = ks.sptr[s1] - e0;
+    const size_t cb = ((size_t)b * ks.ns + s0) * s, mb = (size_t)b * op.m + e0;
+    double2 rcv[NEQ], rub[NEQ];
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) {                        // (clamped, not predicated: the loads stay branch-free and in flight)
+        const int i = (tid + KT * q < ne) ? tid + KT * q : 0;
+        rcv[q] = ks.cv[cb + i]; rub[q] = ks.cub[cb + i];
+    }
+    KSample res[NSQ];
+    double2 rut[NSQ];
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+        const int j = (tid + KT * q < nsamp) ? tid + KT * q : 0;
+        res[q] = ks.es[e0 + j]; rut[q] = ks.ut[mb + j];
+    }
+    double rv[NVQ];
+    load_v(op, rv);
+    const LsqrScalars* O = &st->sc[(ks.ii - 1) & 1];
+    const double oua = O->ua, obeta = O->beta, R = st->R;
+    if (done) return;
+    if (tid < 64) {
+        const double pa = wave_sum(ks.pv[(ks.ii - 1) & 1] + (size_t)b * ks.G, ks.G);
+        if (tid == 0) red[0] = pa;
+    }
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) { const int i = tid + KT * q; if (i < ne) vl[i] = rcv[q]; }
+    store_v(op, rv, vlds);
+    lds_barrier();
+    const double alpha = sqrt(red[0] + (oua * oua) * R);
+    const double inv_alpha = 1.0 / alpha, inv_bprev = 1.0 / obeta, sr = ks.sr;
+    KS_STAMP(0, 1);
+    double acc_b = 0.0, acc_t = 0.0;
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) {
+        if (tid + KT * q < ne) {
+            const double2 ub = ub_update(make_double2(rcv[q].x * inv_alpha, rcv[q].y * inv_alpha), rub[q], sr, alpha, inv_bprev);
+            acc_b += ub.x * ub.x + ub.y * ub.y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+        const int j = tid + KT * q;
+        if (j < nsamp) {
+            const cd* vrow = vl + res[q].ls * s;
+            const double* Vt = vlds + res[q].t * s;
+            double re = 0.0, im = 0.0;
+            for (int c = 0; c < s; ++c) { re += Vt[c] * vrow[c].x; im += Vt[c] * vrow[c].y; }
+            double2 u;
+            u.x = re * inv_alpha - alpha * (rut[q].x * inv_bprev);     // A v - alpha (u / beta_prev)
+            u.y = im * inv_alpha - alpha * (rut[q].y * inv_bprev);
+            ks.ut[mb + j] = u;
+            acc_t += u.x * u.x + u.y * u.y;
+        }
+    }
+    KS_STAMP(0, 2);
+    block_sum2(acc_b, acc_t, red);
+    if (tid == 0) {
+        double* pu = ks.pu[ks.ii & 1] + (size_t)b * 2 * ks.G;
+        pu[g] = acc_b;
+        pu[ks.G + g] = acc_t;
+    }
+    KS_STAMP(0, 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_ks_b : scalars (every block, identical bits), then on one work unit
+//   INIT : v = B'u / beta0 ; d = 0                     ITER : d = (v - thet d)/rho ; x += phi d ; v = B'u/beta - beta v
+// B'u on a slot = sum over its samples of V(t,c) u(t,k)  +  sqrt(r) u(m+1:end).
+// partial sums: pv[ii&1][g] = |v|^2 of the unit
+// ---------------------------------------------------------------------------------------------------------------
+template <bool INIT>
+__global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
+    __shared__ double2 ulds[KS_ECAP];
+    __shared__ cd part[KS_GCAPB * DC_MAXS];
+    __shared__ unsigned short tlds[KS_ECAP];
+    __shared__ int sgl[KS_SCAP + 1];
+    __shared__ double red[2 * KT / 64];
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* vlds = (double*)smem;
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, s = op.s;
+    LsqrState* st = ks.st + b;
+    KS_STAMP(1, 0);
+    const int done = INIT ? 0 : st->done;
+    const int s0 = ks.bslot[g], s1 = ks.bslot[g + 1], nsl = s1 - s0, ne = nsl * s;
+    const int e0 = ks.sptr[s0], nsamp = ks.sptr[s1] - e0;
+    const int g0 = ks.gptr[g], ng = ks.gptr[g + 1] - g0;
+    const size_t cb = ((size_t)b * ks.ns + s0) * s, mb = (size_t)b * op.m + e0;
+    double2 rcv[NEQ], rub[NEQ], rd[NEQ], rx[NEQ];
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) {
+        const int i = (tid + KT * q < ne) ? tid + KT * q : 0;
+        rub[q] = ks.cub[cb + i];
+        if (!INIT) { rcv[q] = ks.cv[cb + i]; rd[q] = ks.cd[cb + i]; rx[q] = ks.cx[cb + i]; }
+    }
+    KSample res[NSQ];
+    double2 rut[NSQ];
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+        const int j = (tid + KT * q < nsamp) ? tid + KT * q : 0;
+        res[q] = ks.es[e0 + j]; rut[q] = ks.ut[mb + j];
+    }
+    KsGroup rg[NGQ];
+#pragma unroll
+    for (int q = 0; q < NGQ; ++q) { const int gi = (tid + KT * q) / SL; rg[q] = ks.grp[g0 + ((gi < ng) ? gi : 0)]; }
+    const int rsg = ks.sgrp[s0 + ((tid <= nsl) ? tid : 0)] - g0;
+    double rv[NVQ];
+    load_v(op, rv);
+    if (done) return;
+    if (tid < 64) {
+        double pa, pb, pc = 0.0;
+        if (INIT) {
+            pa = wave_sum(ks.pinit + (size_t)b * 2 * op.N, 2 * op.N);
+            pb = wave_sum(ks.pR + (size_t)b * op.N, op.N);
+            pc = wave_sum(ks.pz + (size_t)b * ks.nblk_z, ks.nblk_z);
+        } else {
+            pa = wave_sum(ks.pv[(ks.ii - 1) & 1] + (size_t)b * ks.G, ks.G);
+            pb = wave_sum(ks.pu[ks.ii & 1] + (size_t)b * 2 * ks.G, 2 * ks.G);
+        }
+        if (tid == 0) { red[0] = pa; red[1] = pb; red[2] = pc; }
+    }
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) { const int j = tid + KT * q; if (j < nsamp) { ulds[j] = rut[q]; tlds[j] = res[q].t; } }
+    if (tid <= nsl) sgl[tid] = rsg;
+    store_v(op, rv, vlds);
+    lds_barrier();
+    const double pa = red[0], pb = red[1], pc = red[2];
+
+    double inv_beta = 1.0, beta = 0.0, thet = 0.0, inv_rho = 1.0, phi = 0.0, alpha = 0.0, inv_alpha = 1.0, inv_bprev = 1.0;
+    const double sr = ks.sr;
+    const bool writer = g == 0 && tid == 0;
+    if (INIT) {
+        const double R = pb;
+        const double beta0 = sqrt(pa + (sr * sr) * R);
+        const double n2b = sqrt(st->ny2 + sr * sr * pc);
+        const bool fin = (beta0 == 0.0 || n2b == 0.0);       // x0 already exact, or b = 0
+        if (writer) {
+            LsqrScalars S;
+            S.c = 1.0; S.s = 0.0; S.phibar = beta0; S.normr = beta0; S.norma = 0.0; S.factor = beta0;
+            S.thet = 0.0; S.rho = 1.0; S.phi = 0.0; S.beta = beta0; S.alpha = 0.0;
+            S.ua = fin ? 0.0 : (sr * (1.0 / beta0)) * sr;     // v = sqrt(r) u(m+1:end) / beta0 on the never-sampled k
+            S.ub = sr; S.uc = 0.0; S.ue = 0.0;
+            st->sc[0] = S;
+            st->R = R;
+            st->ue_final = 0.0;
+            st->n2b = n2b;
+            st->tolb = ks.tol * n2b;
+            st->iter = fin ? 0 : ks.maxit;
+            st->flag = fin ? 0 : 1;
+            st->done = fin ? 1 : 0;
+        }
+        if (fin) return;
+        inv_beta = 1.0 / beta0;
+    } else {
+        const LsqrScalars O = st->sc[(ks.ii - 1) & 1];
+        const double R = st->R;
+        alpha = sqrt(pa + (O.ua * O.ua) * R);
+        inv_alpha = 1.0 / alpha;
+        inv_bprev = 1.0 / O.beta;
+        const double ua_n = O.ua * inv_alpha;                                           // v = v/alpha
+        const double ub_n = __fma_rn(ua_n, sr, -(alpha * (O.ub * inv_bprev)));          // as ub_update
+        beta = sqrt(pb + (ub_n * ub_n) * R);
+        LsqrScalars S;
+        const double normar = alpha * O.factor;
+        S.norma = sqrt(O.norma * O.norma + alpha * alpha + beta * beta);
+        S.thet = -O.s * alpha;
+        const double rhot = O.c * alpha;
+        S.rho = sqrt(rhot * rhot + beta * beta);
+        S.c = rhot / S.rho;
+        S.s = -beta / S.rho;
+        S.phi = S.c * O.phibar;
+        S.phibar = S.s * O.phibar;
+        S.beta = beta; S.alpha = alpha;
+        bool conv = false;
+        if (normar == 0.0) conv = true;                                   // all-zero correction
+        if (normar / (S.norma * O.normr) <= ks.tol) conv = true;         // min ||b - Bx|| test
+        if (O.normr <= st->tolb) conv = true;                             // Bx = b test
+        S.normr = fabs(S.s) * O.normr;
+        S.factor = fabs(S.s * S.phi);
+        inv_beta = 1.0 / beta; thet = S.thet; inv_rho = 1.0 / S.rho; phi = S.phi;
+        S.uc = (ua_n - thet * O.uc) * inv_rho;                            // d = (v - thet d)/rho
+        S.ue = O.ue + phi * S.uc;                                         // x = x + phi d
+        S.ua = ((ub_n * inv_beta) * sr) - beta * ua_n;                    // v = B'u/beta - beta v
+        S.ub = ub_n;
+        if (writer) {
+            st->sc[ks.ii & 1] = S;
+            if (conv) { st->done = 1; st->flag = 0; st->iter = ks.ii - 1; }
+            else st->ue_final = S.ue;
+        }
+        if (conv) return;
+    }
+    KS_STAMP(1, 1);
+
+    // ---- sum_t V(t,c) u(t,k) per group: SL lanes share a group's samples (interleaved), all channels, fixed tree
+#pragma unroll
+    for (int q = 0; q < NGQ; ++q) {
+        const int gi = (tid + KT * q) / SL, sub = tid & (SL - 1);
+        if (gi < ng) {
+            const KsGroup gr = rg[q];
+            double xr[DC_MAXS], xi[DC_MAXS];
+#pragma unroll
+            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
+            double2 u[DC_GCAP / SL];
+            int t[DC_GCAP / SL];
+#pragma unroll
+            for (int j = 0; j < DC_GCAP / SL; ++j) {       // all of the lane's samples in flight at once
+                const int e = gr.b + sub + SL * j;
+                const bool ok = e < gr.e;
+                u[j] = ulds[ok ? e : 0]; t[j] = tlds[ok ? e : 0];
+                if (!ok) u[j] = make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < DC_GCAP / SL; ++j) {
+#pragma unroll
+                for (int c = 0; c < DC_MAXS; ++c) {
+                    const double v = vlds[t[j] * s + c];   // (c >= s reads a neighbour: finite garbage into unused sums)
+                    xr[c] += v * u[j].x; xi[c] += v * u[j].y;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group8_sum(xr[c]); xi[c] = group8_sum(xi[c]); }
+            if (sub == 0) {
+#pragma unroll
+                for (int c = 0; c < DC_MAXS; ++c) part[gi * DC_MAXS + c] = mk(xr[c], xi[c]);
+            }
+        }
+    }
+    lds_barrier();
+    KS_STAMP(1, 2);
+
+    // ---- vector updates on the unit's (slot, channel) elements
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) {
+        const int i = tid + KT * q;
+        if (i < ne) {
+            const int ls = i / s, c = i - ls * s;
+            double qx = 0.0, qy = 0.0;
+            for (int gi = sgl[ls]; gi < sgl[ls + 1]; ++gi) { const cd p = part[gi * DC_MAXS + c]; qx += p.x; qy += p.y; }
+            const double vx = qx * inv_beta, vy = qy * inv_beta;
+            double2 ub = rub[q];
+            double2 vr;
+            if (INIT) {
+                // v = B'*u = A'*u(1:m) + sqrt(r) u(m+1:end)       PnP_ADMM.m:164-167
+                vr = make_double2(vx + (ub.x * inv_beta) * sr, vy + (ub.y * inv_beta) * sr);
+                ks.cd[cb + i] = make_double2(0.0, 0.0);
+            } else {
+                const double2 vh = make_double2(rcv[q].x * inv_alpha, rcv[q].y * inv_alpha);   // v = v/alpha
+                ub = ub_update(vh, ub, sr, alpha, inv_bprev);                                     // u(m+1:end), as normed in k_ks_a
+                ks.cub[cb + i] = ub;
+                double2 dd = rd[q];
+                dd.x = (vh.x - thet * dd.x) * inv_rho;            // d = (v - thet d)/rho
+                dd.y = (vh.y - thet * dd.y) * inv_rho;
+                ks.cd[cb + i] = dd;
+                double2 xv = rx[q];
+                xv.x += phi * dd.x; xv.y += phi * dd.y;           // x = x + phi d
+                ks.cx[cb + i] = xv;
+                vr = make_double2((vx + (ub.x * inv_beta) * sr) - beta * vh.x,
+                                  (vy + (ub.y * inv_beta) * sr) - beta * vh.y);   // v = B'u - beta v
+            }
+            ks.cv[cb + i] = vr;
+            acc += vr.x * vr.x + vr.y * vr.y;
+        }
+    }
+    KS_STAMP(1, 3);
+    const double tot = block_sum(acc, red);
+    if (tid == 0) ks.pv[ks.ii & 1][(size_t)b * ks.G + g] = tot;
+    KS_STAMP(1, 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_ks_final_w : one block per k-row kh.  Assemble xhat (kept for the next x-update's warm start), ||y - P xhat||^2 of the
+// row's samples (PnP_ADMM.m:106), then the conj-domain inverse w-pass into tmp (k_adj_h finishes the transform).
+// ---------------------------------------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* __restrict__ tmp) {
+    typedef Plan<R1, R2> P;
+    constexpr int N = P::N, M = N;
+    __shared__ cd lds[DC_MAXS * P::LINE];
+    __shared__ double red[KT / 64];
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* vlds = (double*)smem;
+    const int tid = threadIdx.x, kh = blockIdx.x, b = blockIdx.y, s = op.s, sM = s * M;
+    const size_t n = (size_t)s * N * M;
+    const double ue = ks.st[b].ue_final;
+    double rv[NVQ];
+    load_v(op, rv);
+    for (int i = tid; i < sM; i += KT) {
+        const int c = i / M, kw = i - c * M;
+        const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
+        const int slot = op.kslot[kh * M + kw];
+        double2 val;
+        if (slot >= 0) {
+            val = ks.cx[((size_t)b * ks.ns + slot) * s + c];
+        } else {
+            const double2 xv = ks.xhat[g], zv = ks.zhat[g];
+            val = make_double2(xv.x + ue * (zv.x - xv.x), xv.y + ue * (zv.y - xv.y));
+        }
+        ks.xhat[g] = val;
+        lds[c * P::LINE + kw] = val;
+    }
+    store_v(op, rv, vlds);
+    lds_barrier();
+    if (ks.pdiag) {
+        const size_t mb = (size_t)b * op.m;
+        double acc = 0.0;
+        for (int e = op.kptr[kh * M] + tid; e < op.kptr[(kh + 1) * M]; e += KT) {
+            const KEntry en = op.ent[e];
+            double re = 0.0, im = 0.0;
+            for (int c = 0; c < s; ++c) {
+                const double v = vlds[en.t * s + c];
+                const cd X = lds[c * P::LINE + en.kw];
+                re += v * X.x; im += v * X.y;
+            }
+            const double2 yv = ks.yk[mb + e];
+            const double dx = yv.x - re, dy = yv.y - im;
+            acc += dx * dx + dy * dy;
+        }
+        const double tot = block_sum(acc, red);
+        if (tid == 0) ks.pdiag[(size_t)b * N + kh] = tot;
+    }
+    lds_barrier();
+    for (int i = tid; i < sM; i += KT) {                   // conjugate: inverse transform by conj-FFT-conj
+        const int c = i / M, kw = i - c * M;
+        const cd v = lds[c * P::LINE + kw];
+        lds[c * P::LINE + kw] = mk(v.x, -v.y);
+    }
+    cd out[R2];
+    int line2, k1;
+    if (fft_lds<R1, R2, false>(lds, s, op.tw, out, line2, k1)) {
+        double2* dst = tmp + (size_t)b * n + ((size_t)line2 * N + kh) * M;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) dst[k1 + R1 * k2] = out[k2];
+    }
+}
+
+int allow_big_lds(qmri_ctx* ctx, const void* fn) {
+    QMRI_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    return QMRI_OK;
+}
+
+template <int R1, int R2>
+int launch_final_t(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp) {
+    if (!ctx->ks_lds_attr[1]) { QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_final_w<R1, R2>)); ctx->ks_lds_attr[1] = true; }
+    k_ks_final_w<R1, R2><<<dim3(op.N, B), dim3(KT), (size_t)ks.vcap * 8, ctx->stream>>>(op, ks, tmp);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
+}  // namespace
+
+static int ks_attrs(qmri_ctx* ctx) {
+    if (ctx->ks_lds_attr[0]) return QMRI_OK;
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_a));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<true>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<false>));
+    ctx->ks_lds_attr[0] = true;
+    return QMRI_OK;
+}
+
+// residual + first Golub-Kahan vectors; ks.xhat / ks.zhat hold the unitary spectra of x0 and z
+int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
+    QMRI_TRY(ks_attrs(ctx));
+    const size_t vb = (size_t)ks.vcap * 8;
+    k_ks_init_a<<<dim3(op.N, B), dim3(KT), (size_t)op.s * op.M * 16 + vb, ctx->stream>>>(op, ks);
+    k_ks_b<true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
+// LSQR iteration ks.ii (1-based)
+int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
+    const size_t vb = (size_t)ks.vcap * 8;
+    k_ks_a<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+    k_ks_b<false><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
+int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp) {
+    switch (op.N) {
+        case 224: return launch_final_t<16, 14>(ctx, op, ks, B, tmp);
+        case 128: return launch_final_t<16, 8>(ctx, op, ks, B, tmp);
+        case 64: return launch_final_t<8, 8>(ctx, op, ks, B, tmp);
+        case 32: return launch_final_t<8, 4>(ctx, op, ks, B, tmp);
+        default:
+            qmri_set_error(ctx, "unsupported grid size N=%d (supported: 32, 64, 128, 224)", op.N);
+            return QMRI_ERR_UNSUPPORTED;
+    }
+}

@@ -46,9 +46,7 @@ struct KEntry {          // one sample of the k-sorted measurement list
     uint16_t t;          // frame
 };
 
-// scatter work unit of k_lsqr_w: up to DC_GCAP consecutive samples of one k location, offsets relative to the row start
-struct KGroup { uint16_t kw, b, e, pad; };
-constexpr int DC_GCAP = 32;
+constexpr int DC_GCAP = 32;          // samples per scatter group of the k-space LSQR
 
 struct OpDev {
     int N, M, s, T, m;
@@ -59,20 +57,52 @@ struct OpDev {
     const double2* tw;       // [N]     exp(-2*pi*i*j/N)
     const int32_t* kslot;    // [N*M]   DIRECT solver: slot of k' among sampled locations or -1
     const double* ginv;      // [nsampled][s*s] (G_k + r I)^-1, symmetric, row-major
-    const KGroup* grp;       // scatter groups, row after row
-    const int32_t* gptr;     // [N+1]   first group of each k-row
-    const int32_t* gkw;      // [N][M+1] per row: first group (relative to the row's) of each kw
+};
+
+// ---------------------------------------------------------------------------------------------------
+// k-space LSQR (kslsqr_kernels.hip): work partition over the sampled k locations ("slots", k' order)
+// ---------------------------------------------------------------------------------------------------
+struct KSample { uint16_t ls, t; };              // slot of a sample relative to its block's first slot; frame
+struct KsGroup { uint16_t ls, b, e, pad; };      // <= DC_GCAP samples of one slot; b, e relative to the block's first sample
+constexpr int KS_SCAP = 64;                      // slots per block
+constexpr int KS_ECAP = 1024;                    // samples per block
+constexpr int KS_GCAPB = 96;                     // groups per block  (>= KS_ECAP / DC_GCAP + KS_SCAP)
+struct LsqrState;
+struct KsDev {
+    int ns, G;                                   // sampled k locations; blocks of the iteration kernels
+    const int32_t* bslot;                        // [G+1]  first slot of each block
+    const int32_t* sptr;                         // [ns+1] first sample of each slot (k-sorted sample order)
+    const KSample* es;                           // [m]
+    const KsGroup* grp;                          // scatter groups, block after block
+    const int32_t* gptr;                         // [G+1]  first group of each block
+    const int32_t* sgrp;                         // [ns+1] first group of each slot
+    LsqrState* st;                               // [B]
+    double* pu[2];                               // [B][2G] partial |u|^2 (image part, then samples), by iteration parity
+    double* pv[2];                               // [B][G]  partial |v|^2
+    double* pinit;                               // [B][2N] partial |u|^2 of the initial residual, per k-row
+    double* pR;                                  // [B][N]  partial R
+    const double* pz; int nblk_z;                // [B][nblk_z] partial |z|^2
+    double2* cx; double2* cv; double2* cd; double2* cub;   // [B][ns*s] x, v (not normalised), d, u(m+1:end) on the sampled k
+    double2* ut; const double2* yk;              // [B][m]
+    double2* xhat; double2* zhat;                // [B][n] unitary spectra, layout [c][kh][kw]
+    double* pdiag;                               // [B][N] partial ||y - A x||^2 or null
+    double sr, tol;
+    int maxit, ii, vcap;
+    unsigned long long* stamps;
 };
 
 // LSQR (PnP_ADMM.m:102) device state, one per slice
 struct LsqrScalars {
     double c, s, phibar, normr, norma, factor;   // recurrences; normar = alpha * factor
     double thet, rho, phi, beta, alpha;          // values A2 needs for the current iteration
+    double ua, ub, uc, ue;                       // k-space solver: v, u(m+1:end), d, x - x0 on the never-sampled k, as multiples of (zhat - xhat0)
 };
 struct LsqrState {
     LsqrScalars sc[2];       // ping-pong by iteration parity
     double n2b, tolb;
     double ny2;              // ||y||^2
+    double R;                // k-space solver: sum over never-sampled k of |zhat - xhat0|^2
+    double ue_final;         // k-space solver: ue after the last x update
     int32_t iter, done, flag, pad;
 };
 
@@ -80,21 +110,9 @@ enum { DC_PLAIN = 0, DC_FWD_H_ONLY = 1, DC_DIAG = 3, DC_DIRECT = 4, DC_SPECTRUM 
 
 struct LsqrDev {
     LsqrState* st;           // [B]
-    double* pu[2];           // [B][npu] partial sums of |u|^2   (npu = 2N: image-domain slices, then k-rows), by iteration parity
-    double* pv[2];           // [B][nblk_h] partial sums of |v|^2, by iteration parity
     double* pz;              // [B][nblk_z] partial sums of |z|^2
-    double2* ut;             // [B][m]  u(1:m) in k-sorted order (raw, unnormalised)
-    double2* ub;             // [B][n]  u(m+1:end)
-    double2* v;              // [B][n]
-    double2* d;              // [B][n]
     double2* yk;             // [B][m]  y in k-sorted order
-    int npu, nblk_h, nblk_z;
-    int ucap, vcap, gcap;    // LDS plan of k_lsqr_w: samples of one k-row staged at once; doubles for V; scatter groups per row
-    double sr;               // sqrt(r)
-    double tol;              // cg_tol
-    int maxit;
-    int ii;                  // LSQR iteration (1-based; 0 during initialisation)
-    unsigned long long* stamps;   // diagnostic (QMRI_LSQR_STAMPS=1): [2 kernels][512 blocks][8] wall_clock64 phase stamps, else null
+    int nblk_z;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -143,7 +161,8 @@ struct OpHost {
     int N = 0, M = 0, s = 0, T = 0, m = 0, maxB = 0, nsampled = 0;
     double* d_Vt = nullptr; KEntry* d_ent = nullptr; int32_t* d_perm = nullptr; int32_t* d_kptr = nullptr;
     double2* d_tw = nullptr; int32_t* d_kslot = nullptr; double* d_ginv = nullptr;
-    KGroup* d_grp = nullptr; int32_t* d_gptr = nullptr; int32_t* d_gkw = nullptr;
+    KsDev ks{};                         // k-space LSQR plan + state (device pointers owned here)
+    bool xhat_valid = false;            // ks.xhat holds the spectrum of d_x
     double ginv_r = -1.0;
     std::vector<double> V;              // T x s column-major (host copy)
     std::vector<int32_t> frame_ptr, kidx, kptr_h, perm_h;
@@ -183,7 +202,7 @@ struct qmri_ctx {
     int prof_level = 0;
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool lsqr_lds_attr[4] = {false, false, false, false};   // >64 KB dynamic LDS allowed for k_lsqr_w (per grid size)
+    bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
 };
 
@@ -193,15 +212,15 @@ OpDev qmri_opdev(const qmri_ctx* ctx);
 // kernel launchers (dc_kernels.hip)
 // ---------------------------------------------------------------------------------------------------
 bool dc_size_supported(int N);
-int dc_lsqr_nblk_h(int M, int s);       // blocks of k_lsqr_h (= partial sums of |v|^2 per slice)
-bool dc_lsqr_plan(int N, int T, int s, int maxrow, int maxgroups, int* ucap, int* vcap);   // LDS plan of k_lsqr_w; false: V does not fit
 // forward:  src [B][n] -> (mode-dependent) ; tmp workspace [B][n]
 int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src, double2* tmp,
                   double2* y_out, double* pdiag);
 int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst);
-// one LSQR step (lsqr_kernels.hip): init = b - B*x0, v = B'u ; otherwise iteration ls.ii
-int dc_launch_lsqr(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, bool init, int B, const double2* x0,
-                   const double2* z, double2* tmp, double2* xio);
+int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, double2* dst);   // inverse h-pass only
+// k-space LSQR (kslsqr_kernels.hip)
+int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
+int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
+int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);   // tmp <- conj-domain inverse w-pass of xhat
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
                      double2* tmp, double2* x_out);
 // y (ABI order) -> k-sorted order, plus ||y||^2 into state

@@ -19,7 +19,8 @@ lib.qmri_debug_lsqr_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 buf = np.zeros((2, 512, 16), np.uint64)
 assert lib.qmri_debug_lsqr_stamps(eng.h, buf.ctypes.data) == 0
 print('lsqr iters', it, 'flag', flag)
-for kid, name, nb, order in ((0, 'k_lsqr_w', 224, [0, 1, 2, 3, 4, 8, 9, 10, 5, 6]), (1, 'k_lsqr_h', 280, [0, 1, 2, 3, 4])):
+for kid, name, order in ((0, 'k_ks_a', [0, 1, 2, 3]), (1, 'k_ks_b', [0, 1, 2, 3, 4])):
+    nb = int((buf[kid, :, 0] != 0).sum())
     s = buf[kid, :nb][:, order].astype(np.int64)
     nst = len(order)
     t0 = s[:, 0].min()
