@@ -37,7 +37,7 @@ extern "C" size_t qmri_net_nparams(const qmri_net_desc* d) {
 
 void qmri_free_net(qmri_ctx* ctx) {
     NetPlan& p = ctx->net;
-    for (ConvLayer& L : p.layers) { if (L.wp) (void)hipFree(L.wp); if (L.d_tab) (void)hipFree(L.d_tab); }
+    for (ConvLayer& L : p.layers) { if (L.wp) (void)hipFree(L.wp); if (L.d_tab) (void)hipFree(L.d_tab); if (L.wp6) (void)hipFree(L.wp6); }
     for (float* b : p.allocs) if (b) (void)hipFree(b);
     if (p.d_counter) (void)hipFree(p.d_counter);
     if (p.d_stamps) (void)hipFree(p.d_stamps);
@@ -64,6 +64,13 @@ static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const floa
     hipError_t e = hipMalloc((void**)&L.wp, packed.size() * sizeof(float));
     if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
     QMRI_HIP(ctx, hipMemcpy(L.wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (kind == CONV_3X3) {                                // the same weights for the bf16 x 6 kernel
+        std::vector<uint16_t> p6;
+        conv6_plan_pack(L, w, p6);
+        e = hipMalloc(&L.wp6, p6.size() * sizeof(uint16_t));
+        if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+        QMRI_HIP(ctx, hipMemcpy(L.wp6, p6.data(), p6.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     const int taps = (kind == CONV_3X3) ? 9 : 4;
     w += (size_t)Cin * Cout * taps;
     ctx->net.layers.push_back(L);

@@ -128,6 +128,8 @@ struct ConvLayer {
     size_t wp_floats;
     void* d_tab;             // tile table {cout tile, ow0, oh0, batch} for (tab_B, tab_MT)
     int tab_B, tab_MT;
+    void* wp6 = nullptr;     // 3x3 layers: weights split into bf16 triples, MFMA A-fragment order (conv6_kernels.hip)
+    int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks, 64-row output tiles of wp6
 };
 
 // activation tensor in HBM: [B][Cal][W+2][H+2] fp32, h fastest, permanent zero halo, channels >= C are zero
@@ -202,6 +204,7 @@ struct qmri_ctx {
     int prof_level = 0;
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool conv6_attr[2] = {false, false};   // dynamic LDS size of k_conv6 allowed
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
 };
@@ -244,6 +247,11 @@ int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, dou
 int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                 const PTensor* add2, int relu_out);
 int conv_cin_pad(ConvKind kind, int Cin);
+// bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
+bool conv6_enabled();
+void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
+int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
+                 const PTensor* add2, int relu_out);
 size_t conv_pack_weights(const ConvLayer& L, const float* w_src, std::vector<float>& packed);
 void conv_plan_layer(ConvLayer& L, ConvKind kind, int Cin, int Cout);
 
