@@ -40,11 +40,32 @@ struct Conv6Args {
     int in_hp, in_plane; long in_bs;          // padded row pitch, plane size, batch stride (elements)
     int out_hp, out_plane; long out_bs, add1_bs, add2_bs;
     int nchunk, n_ct, tiles_h, tiles_w, relu_out;
+    int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
+    unsigned long long* stamps;   // diagnostic (QMRI_CONV_STAMPS): [16 workgroups][2 roles][128] barrier-arrival times, 100 MHz clock
 };
 
+// Workgroup tile = 64 output channels x (TH x TW) pixels.  A wave owns MW cout tiles (32 rows) x NCT pixel blocks of
+// 8h x 4w (stacked in h); wave_map gives its first pixel block and first cout tile.
 template <int CFG> struct Cfg6;
-template <> struct Cfg6<0> { static constexpr int TH = 16, TW = 8, MW = 2; };   // 64 cout x 128 px: waves = 2 x 2 pixel blocks, 64 cout each
-template <> struct Cfg6<1> { static constexpr int TH = 8, TW = 8, MW = 1; };    // 64 cout x 64 px: waves = 2 cout halves x 2 pixel blocks
+template <> struct Cfg6<0> {     // 256 px, waves side by side in w, 64 cout x 64 px each
+    static constexpr int TH = 16, TW = 16, MW = 2, NCT = 2;
+    static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 0; pbw = 4 * wave; m0 = 0; }
+};
+template <> struct Cfg6<1> {     // 128 px, waves 2 x 2, 64 cout x 32 px each
+    static constexpr int TH = 16, TW = 8, MW = 2, NCT = 1;
+    static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 8 * (wave & 1); pbw = 4 * (wave >> 1); m0 = 0; }
+};
+template <> struct Cfg6<2> {     // 64 px, waves = 2 cout halves x 2 pixel blocks, 32 cout x 32 px each
+    static constexpr int TH = 8, TW = 8, MW = 1, NCT = 1;
+    static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 0; pbw = 4 * (wave >> 1); m0 = wave & 1; }
+};
+constexpr int NABUF = 2;         // LDS buffers of A (one step each)
+
+#define C6_STAMP(role, k)                                                                        \
+    do {                                                                                         \
+        if (A.stamps && A.detail && (threadIdx.x & 255) == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && (k) < 128)   \
+            A.stamps[((blockIdx.x / 13) * 4 + (role)) * 128 + (k)] = wall_clock64();            \
+    } while (0)
 
 __device__ __forceinline__ void lds_barrier6() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -53,6 +74,31 @@ __device__ __forceinline__ void lds_barrier6() {
 }
 
 __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
+// Loader waves request their operands with inline-asm loads and wait with hand-counted s_waitcnt: hipcc's own counter
+// insertion drains vmcnt almost completely at the loop header, which exposes a full memory latency per step.  A loader
+// wave issues no other vector-memory instruction, loads complete in issue order, and every wait names the registers it
+// releases ("+v"), so no consumer can be scheduled above it.
+// (scalar base + 32-bit per-lane byte offset: the offsets are loop invariant, the base advances per step)
+__device__ __forceinline__ void gload4(u32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gload1(float& dst, unsigned off, const void* base) { asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], float (&b)[1][8]) {
+    asm volatile("s_waitcnt vmcnt(%13)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
+                   "+v"(b[0][4]), "+v"(b[0][5]), "+v"(b[0][6]), "+v"(b[0][7])
+                 : "n"(N)
+                 : "memory");
+}
+
+// wave-uniform pointer, guaranteed to live in SGPRs (the "s" operands of the loads above)
+template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    // v_readfirstlane writes an SGPR from the VALU; a VMEM instruction reading it needs 5 wait states, which the hazard
+    // recognizer cannot provide for operands of inline asm
+    asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
+    return (const T*)(((unsigned long long)hi << 32) | lo);
+}
 
 // x = x0 + x1 + x2 exactly (bf16 pieces); two values packed per dword, low half = first
 __device__ __forceinline__ void split_pair(float xa, float xb, unsigned& p0, unsigned& p1, unsigned& p2) {
@@ -69,15 +115,24 @@ __device__ __forceinline__ void split_pair(float xa, float xb, unsigned& p0, uns
 template <int CFG>
 __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
     typedef Cfg6<CFG> C;
-    constexpr int TH = C::TH, TW = C::TW, MW = C::MW;
-    constexpr int IH = TH + 2, IW = TW + 2, NPX = IH * IW;         // input tile with halo
-    constexpr int NBI = 2 * NPX;                                    // loader items of one chunk of B: (k-half, pixel)
+    constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT;
+    constexpr int IH = TH + 2, IW = TW + 2;                         // input tile with halo
+    constexpr int IHP = ((IH + 7) / 16) * 16 + 8;                   // its LDS row pitch, = 8 mod 16 entries: conflict-free ds_read_b128 of 8h x 4w blocks
+    constexpr int NPX = IHP * IW;                                   // LDS entries per (split, k-half) plane
+    constexpr int NLP = IH * IW;                                    // pixels actually loaded
+    static_assert(IHP >= IH, "row pitch");
+    constexpr int NBI = 2 * NLP;                                    // loader items of one chunk of B: (k-half, pixel)
     constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);          // ... per loader thread and step (a chunk is spread over its 3 steps)
     constexpr int NAQ = (AST + NLD6 - 1) / NLD6;                    // uint4 of A per loader thread and step
+    static_assert(NAQ == 5 && NBQ == 1, "gwait() is written for 5 + 8 loads per step");
+    constexpr int NLOAD = NAQ + 8 * NBQ;                            // vector-memory loads a loader thread issues per step
     extern __shared__ __align__(16) unsigned char smem[];
-    uint4* Abuf = (uint4*)smem;                                     // [2][AST]
-    uint4* Bbuf = Abuf + 2 * AST;                                   // [2][3 splits][2 k-halves][NPX]  (8 channels = 16 B per entry)
+    uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
+    constexpr int PXT = TH * TW, PP = PXT + 2;                      // output tile in LDS: [64 cout][PP], aliases the B buffers
+    uint4* Bbuf = Abuf + NABUF * AST;                                   // [2][3 splits][2 k-halves][NPX]  (8 channels = 16 B per entry)
 
+    float* ot = (float*)Bbuf;
+    static_assert(64 * PP * 4 <= 2 * 3 * 2 * NPX * 16, "output tile must fit the B buffers");
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
@@ -90,149 +145,209 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
     if (tid >= NT6 - NLD6) {
         // ------------------------------------------------------------------ loaders
         const int lt = tid - (NT6 - NLD6);
+        __builtin_amdgcn_s_setprio(2);                             // requests first: the MFMA waves have work queued anyway
         const uint4* wsrc = A.wp + (size_t)ct * A.nchunk * 3 * AST;               // steps of this cout tile are contiguous
         const float* isrc = A.in + (size_t)b * A.in_bs + (size_t)ow0 * A.in_hp + oh0;   // halo origin = padded (oh0, ow0)
-        u32x4 ra0[NAQ], ra1[NAQ];
-        float rb0[NBQ][8], rb1[NBQ][8];
+        unsigned aoff[NAQ], boff[3][8];                            // loop-invariant byte offsets of this thread's requests
+#pragma unroll
+        for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            int item = part * (NBQ * NLD6) + lt;
+            if (item >= NBI) item = 0;
+            const int h2 = item / NLP, px = item - h2 * NLP;
+            const int dw = px / IH, dh = px - dw * IH;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) boff[part][j] = (unsigned)((((size_t)(h2 * 8 + j)) * A.in_plane + dw * A.in_hp + dh) * 4);
+        }
+        u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
+        float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
         // Schedule.  Barrier g precedes compute step g.  Abuf[(g+1)&1] is free once step g-1 is over, i.e. after barrier g:
         // iteration g (between barriers g and g+1) stores A(g+1).  Bbuf[(c+1)&1] is free once chunk c-1 is over, i.e. after
         // barrier 3c: iterations 3c, 3c+1, 3c+2 store the three parts of B(c+1).  What an iteration stores was requested
-        // one iteration earlier into the other register set, so a request has a whole step to arrive.
+        // two iterations earlier (three register sets in rotation), so a request has two whole steps to arrive.
         // (Requests past the end are clamped, not skipped: branch-free code lets the compiler count vmcnt exactly.)
 #define LOAD_A(g_, ra_)                                                                                          \
         {                                                                                                        \
-            const uint4* ws = wsrc + (size_t)(((g_) < nsteps) ? (g_) : nsteps - 1) * AST;                        \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; ra_[q] = __builtin_bit_cast(u32x4, ws[(i < AST) ? i : 0]); } \
+            const uint4* ws = uniform_ptr(wsrc + (size_t)(((g_) < nsteps) ? (g_) : nsteps - 1) * AST);           \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) gload4(ra_[q], aoff[q], ws);                                        \
         }
-#define STORE_A(g_, ra_)                                                                                         \
-        if ((g_) < nsteps) {                                                                                     \
-            uint4* ad = Abuf + ((g_) & 1) * AST;                                                                 \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; if (i < AST) ad[i] = __builtin_bit_cast(uint4, ra_[q]); } \
+#define STORE_A(g_, ra_)       /* (past the end: a free buffer receives the clamped request; surplus threads repeat entry 0) */ \
+        {                                                                                                        \
+            uint4* ad = Abuf + ((g_) % NABUF) * AST;                                                             \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; ad[(i < AST) ? i : 0] = __builtin_bit_cast(uint4, ra_[q]); } \
         }
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
             const int cc = ((c_) < A.nchunk) ? (c_) : A.nchunk - 1;                                              \
+            const float* bs_ = uniform_ptr(isrc + (size_t)cc * CK * A.in_plane);                                 \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) gload1(rb_[0][j], boff[part_][j], bs_);                \
+        }
+#define STORE_B(c_, part_, rb_)                                                                                  \
+        {                                                                                                        \
+            uint4* bd = Bbuf + ((c_) & 1) * (3 * 2 * NPX);                                                       \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                                    \
                 int item = (part_) * (NBQ * NLD6) + lt + NLD6 * q;                                               \
                 if (item >= NBI) item = 0;                                                                       \
-                const int h2 = item / NPX, px = item - h2 * NPX;                                                 \
-                const int dw = px / IH, dh = px - dw * IH;                                                       \
-                const float* p = isrc + (size_t)(cc * CK + h2 * 8) * A.in_plane + dw * A.in_hp + dh;             \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) rb_[q][j] = p[(size_t)j * A.in_plane];             \
-            }                                                                                                    \
-        }
-#define STORE_B(c_, part_, rb_)                                                                                  \
-        if ((c_) < A.nchunk) {                                                                                   \
-            uint4* bd = Bbuf + ((c_) & 1) * (3 * 2 * NPX);                                                       \
-            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                                    \
-                const int item = (part_) * (NBQ * NLD6) + lt + NLD6 * q;                                         \
-                if (item < NBI) {                                                                                \
+                {                                                                                                \
+                    const int h2 = item / NLP, px = item - h2 * NLP;                                             \
+                    const int dw = px / IH, dh = px - dw * IH;                                                   \
+                    const int e = h2 * NPX + dw * IHP + dh;                                                      \
                     uint4 s0, s1, s2;                                                                            \
                     split_pair(rb_[q][0], rb_[q][1], s0.x, s1.x, s2.x);                                          \
                     split_pair(rb_[q][2], rb_[q][3], s0.y, s1.y, s2.y);                                          \
                     split_pair(rb_[q][4], rb_[q][5], s0.z, s1.z, s2.z);                                          \
                     split_pair(rb_[q][6], rb_[q][7], s0.w, s1.w, s2.w);                                          \
-                    bd[item] = s0;               /* item = h2*NPX + px ; split planes are 2*NPX apart */           \
-                    bd[2 * NPX + item] = s1;                                                                     \
-                    bd[4 * NPX + item] = s2;                                                                     \
+                    bd[e] = s0;                  /* split planes are 2*NPX entries apart */                       \
+                    bd[2 * NPX + e] = s1;                                                                        \
+                    bd[4 * NPX + e] = s2;                                                                        \
                 }                                                                                                \
             }                                                                                                    \
         }
-        // prologue: B(chunk 0) in three parts, A(0); then the requests for iteration 0's stores
-        for (int part = 0; part < 3; ++part) { LOAD_B(0, part, rb0) STORE_B(0, part, rb0) }
-        LOAD_A(0, ra0) STORE_A(0, ra0)
-        LOAD_A(1, ra1) LOAD_B(1, 0, rb1)
+        // prologue: B(chunk 0) in three parts, A(0); then the requests for the stores of iterations 0 and 1
+        for (int part = 0; part < 3; ++part) { LOAD_B(0, part, rb0) LOAD_A(0, ra0) gwait<0>(ra0, rb0); STORE_B(0, part, rb0) }
+        STORE_A(0, ra0)
+        LOAD_A(1, ra1) LOAD_B(1, 0, rb1)                            // stored by iteration 0
+        LOAD_A(2, ra2) LOAD_B(1, 1, rb2)                            // stored by iteration 1
+        C6_STAMP(1, 0);
         lds_barrier6();                                             // barrier 0: step 0 may start
-        for (int g = 0; g < nsteps; g += 2) {
-            {   // iteration g: set 1 holds A(g+1), B(chunk(g)+1, part g%3); request iteration g+1's stores into set 0
-                const int c = g / 3, part = g - 3 * c;
-                const int c1 = (g + 1) / 3, part1 = (g + 1) - 3 * c1;
-                LOAD_A(g + 2, ra0) LOAD_B(c1 + 1, part1, rb0)
-                STORE_A(g + 1, ra1) STORE_B(c + 1, part, rb1)
-                lds_barrier6();
-            }
-            if (g + 1 < nsteps) {
-                const int c = (g + 1) / 3, part = (g + 1) - 3 * c;
-                const int c1 = (g + 2) / 3, part1 = (g + 2) - 3 * c1;
-                LOAD_A(g + 3, ra1) LOAD_B(c1 + 1, part1, rb1)
-                STORE_A(g + 2, ra0) STORE_B(c + 1, part, rb0)
-                lds_barrier6();
-            }
+        // iteration g stores A(g+1) and part g%3 of B(g/3+1) from set (g+1)%3 and requests what iteration g+2 stores,
+        // A(g+3) and part (g+2)%3 of B((g+2)/3+1), into set g%3 (whose content iteration g-1 stored).  At the wait the
+        // requests of this and of the previous iteration may stay in flight: vmcnt(2*NLOAD).
+#define ITER(k_, rs_a, rs_b, rq_a, rq_b)   /* iteration g + k_, g = 3*c0 */                                       \
+        {                                                                                                        \
+            constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
+            LOAD_A(g + (k_) + 3, rq_a) LOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                       \
+            C6_STAMP(2, g + (k_) + 1);                                                                           \
+            gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
+            C6_STAMP(3, g + (k_) + 1);                                                                           \
+            STORE_A(g + (k_) + 1, rs_a) STORE_B(c0 + 1, part_, rs_b)                                             \
+            C6_STAMP(1, g + (k_) + 1);                                                                           \
+            lds_barrier6();                                                                                      \
         }
+        for (int g = 0, c0 = 0; g < nsteps; g += 3, ++c0) {
+            ITER(0, ra1, rb1, ra0, rb0)
+            ITER(1, ra2, rb2, ra1, rb1)
+            ITER(2, ra0, rb0, ra2, rb2)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (clamped requests past the end are still in flight)
+#undef ITER
 #undef LOAD_A
 #undef STORE_A
 #undef LOAD_B
 #undef STORE_B
-        return;
-    }
-
+    } else {
     // ---------------------------------------------------------------------- MFMA waves
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h2 = lane >> 5;
-    // pixel block (8h x 4w) and cout half of this wave
-    const int pb = (CFG == 0) ? wave : (wave >> 1);
-    const int pbh = (CFG == 0) ? (pb & 1) * 8 : 0, pbw = (CFG == 0) ? (pb >> 1) * 4 : pb * 4;
-    const int m0 = (CFG == 0) ? 0 : (wave & 1);                     // first cout tile (of the workgroup's two) of this wave
-    const int pxl = (pbw + (li >> 3)) * IH + pbh + (li & 7);        // halo-tile pixel of this lane at tap (0,0)
-    f32x16 acc[MW];
+    int pbh, pbw, m0;
+    C::wave_map(wave, pbh, pbw, m0);
+    const int pxl = (pbw + (li >> 3)) * IHP + pbh + (li & 7);       // LDS entry of this lane's pixel at tap (0,0), pixel block 0
+    f32x16 acc[MW][NCT];
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int n = 0; n < NCT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 63) * 2] = wall_clock64();
+    C6_STAMP(0, 0);
     lds_barrier6();                                                 // barrier 0
     for (int g = 0; g < nsteps; ++g) {
-        const int c = g / 3, part = g - 3 * c;
-        const uint4* ab = Abuf + (g & 1) * AST;
-        const uint4* bb = Bbuf + (c & 1) * (3 * 2 * NPX) + h2 * NPX + pxl;
+        const int c = g / 3, part = g - 3 * c;                      // part = kh ; the step's three taps are kw = 0, 1, 2
+        const uint4* ab = Abuf + (g % NABUF) * AST + lane;
+        const uint4* bb = Bbuf + (c & 1) * (3 * 2 * NPX) + h2 * NPX + pxl + part;
+        // fragments of tap t+1 are requested before the MFMAs of tap t (register double buffer)
+        bf16x8 bf[2][NCT][3], af[2][MW][3];
+        auto frags = [&](int t, int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) bf[set][n][sp] = __builtin_bit_cast(bf16x8, bb[sp * 2 * NPX + t * IHP + 8 * n]);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) af[set][m][sp] = __builtin_bit_cast(bf16x8, ab[((t * 2 + (m0 + m)) * 3 + sp) * 64]);
+        };
+        frags(0, 0);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const int tap = part * 3 + t;                           // tap = kh*3 + kw ; part = kh
-            const int toff = t * IH + part;                         // kw = t, kh = part
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, bb[toff]);
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, bb[2 * NPX + toff]);
-            const bf16x8 b2 = __builtin_bit_cast(bf16x8, bb[4 * NPX + toff]);
-            (void)tap;
+            const int cur = t & 1;
+            if (t < 2) frags(t + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);              // keep the requests above the MFMAs they overlap with
 #pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const uint4* af = ab + ((t * 2 + (m0 + m)) * 3) * 64 + lane;
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[0]);
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[64]);
-                const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[128]);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
-            }
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < NCT; ++n) {
+                    f32x16 a_ = acc[m][n];                          // smallest terms first
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][2], bf[cur][n][0], a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][2], a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bf[cur][n][1], a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bf[cur][n][0], a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][1], a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][0], a_, 0, 0, 0);
+                    acc[m][n] = a_;
+                }
         }
+        C6_STAMP(0, g + 1);
         lds_barrier6();                                             // barrier g+1
     }
+    C6_STAMP(0, nsteps + 1);
 
-    // ---- epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int oh = oh0 + pbh + (li & 7), ow = ow0 + pbw + (li >> 3);
-    if (oh < A.H && ow < A.W) {
-        const size_t po = (size_t)(ow + 1) * A.out_hp + (oh + 1);
+    // ---- accumulators -> LDS tile ot[cout][pixel] (the B buffers are free now).  C/D layout: col = lane&31 (pixel),
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) {
+    for (int n = 0; n < NCT; ++n)
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = ct * 64 + (m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                if (co < A.Cout) {
-                    const size_t o = (size_t)co * A.out_plane + po;
-                    float v = acc[m][r];
-                    if (A.add1) v += A.add1[(size_t)b * A.add1_bs + o];
-                    if (A.add2) v += A.add2[(size_t)b * A.add2_bs + o];
-                    if (A.relu_out) v = fmaxf(v, 0.f);
-                    A.out[(size_t)b * A.out_bs + o] = v;
-                }
+                const int co = (m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = acc[m][n][r];
             }
+    }   // MFMA waves
+
+    // ---- all eight waves: residual adds, ReLU, stores; consecutive threads walk h, so every request is a run of TH floats.
+    // The residual operands are requested before the barrier that publishes the LDS tile: one memory latency, overlapped.
+    {
+        const bool has1 = A.add1 != nullptr, has2 = A.add2 != nullptr;
+        constexpr int NE = 64 * PXT, EQ = NE / NT6;                 // tile elements; elements per thread
+        static_assert(NE % NT6 == 0, "epilogue");
+        unsigned off[EQ];                                           // element offset inside one image (fits 32 bits), ~0u = outside
+        float r1[EQ], r2[EQ];
+#pragma unroll
+        for (int k = 0; k < EQ; ++k) {
+            const int e = k * NT6 + tid;
+            const int co = e / PXT, rem = e - co * PXT, w = rem / TH, h = rem - w * TH;
+            const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
+            const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
+            off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
+            r1[k] = 0.f; r2[k] = 0.f;
+        }
+        if (has1) {                                                 // (uniform branches around batches of loads: all in flight together)
+#pragma unroll
+            for (int k = 0; k < EQ; ++k) r1[k] = A.add1[(size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 0u)];
+        }
+        if (has2) {
+#pragma unroll
+            for (int k = 0; k < EQ; ++k) r2[k] = A.add2[(size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 0u)];
+        }
+        lds_barrier6();                                             // the output tile is complete
+#pragma unroll
+        for (int k = 0; k < EQ; ++k) {
+            const int e = k * NT6 + tid;
+            const int co = e / PXT, rem = e - co * PXT;
+            float x = (ot[co * PP + rem] + r1[k]) + r2[k];
+            if (A.relu_out) x = fmaxf(x, 0.f);
+            if (off[k] != ~0u) A.out[(size_t)b * A.out_bs + off[k]] = x;
         }
     }
+    C6_STAMP(0, nsteps + 2);
+    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 63) * 2 + 1] = wall_clock64();
 }
 
 template <int CFG> constexpr size_t conv6_lds() {
-    return (size_t)(2 * AST + 2 * 3 * 2 * (Cfg6<CFG>::TH + 2) * (Cfg6<CFG>::TW + 2)) * 16;
+    return (size_t)(NABUF * AST + 2 * 3 * 2 * (((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 2)) * 16;
 }
 
 template <int CFG>
@@ -250,6 +365,11 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.nchunk = L.nchunk6; A.n_ct = L.n_ct6;
     A.tiles_h = (in.H + C::TH - 1) / C::TH; A.tiles_w = (in.W + C::TW - 1) / C::TW;
     A.relu_out = relu_out;
+    A.stamps = (unsigned long long*)ctx->net.d_stamps;
+    static int launch_counter = 0;
+    static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
+    A.launch_idx = launch_counter++;
+    A.detail = (stamp_launch < 0 || A.launch_idx == stamp_launch) ? 1 : 0;
     if (!ctx->conv6_attr[CFG]) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>()));
         ctx->conv6_attr[CFG] = true;
@@ -306,8 +426,9 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
 
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out) {
-    // wide pixel tiles while they still give every CU a workgroup; the small feature maps take the 64-pixel tile
-    const long wide = (long)L.n_ct6 * ((in.H + 15) / 16) * ((in.W + 7) / 8) * B;
-    if (wide >= 192 && in.H % 16 == 0) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
-    return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
+    // the largest pixel tile that still gives most CUs a workgroup (one workgroup per CU is the design point)
+    auto ntiles = [&](int th, int tw) { return (long)L.n_ct6 * ((in.H + th - 1) / th) * ((in.W + tw - 1) / tw) * B; };
+    if (in.H % 16 == 0 && in.W % 16 == 0 && ntiles(16, 16) >= 160) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
+    if (in.H % 16 == 0 && ntiles(16, 8) >= 160) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
+    return launch6<2>(ctx, L, B, in, out, add1, add2, relu_out);
 }

@@ -393,7 +393,8 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
     A.add2_bs = add2 ? (long)add2->Cal * add2->plane() : 0;
     A.nch = L.cin_pad / G_::CC; A.ntiles = ntiles; A.relu_out = relu_out;
     A.counter = ctx->net.d_counter;
-    A.stamps = (unsigned long long*)ctx->net.d_stamps;
+    static const bool stamps6 = getenv("QMRI_CONV_STAMP_LAUNCH") != nullptr;   // the buffer then belongs to k_conv6
+    A.stamps = stamps6 ? nullptr : (unsigned long long*)ctx->net.d_stamps;
     // persistent grid: exactly as many workgroups as are resident at once (measured occupancy x CU count)
     static int occ[2] = {0, 0}, ncu = 0;
     if (!ncu) {

@@ -204,7 +204,7 @@ struct qmri_ctx {
     int prof_level = 0;
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool conv6_attr[2] = {false, false};   // dynamic LDS size of k_conv6 allowed
+    bool conv6_attr[3] = {false, false, false};   // dynamic LDS size of k_conv6 allowed
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
 };

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Audit the gfx950 ISA of k_conv6's loader waves: between an inline-asm global_load and the counted s_waitcnt that
+releases it, no instruction may touch the load's destination registers (the compiler does not know they are in flight).
+Usage: tools/audit_conv6_isa.py  (compiles conv6_kernels.hip to assembly with hipcc; CPU only)"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'qmri_pnp_recon_poc_amd', 'csrc', 'conv6_kernels.hip')
+
+
+def regs(tok):
+    out = []
+    for m in re.finditer(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', tok):
+        if m.group(1): out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+        else: out.append(int(m.group(3)))
+    return out
+
+
+def sgpr_hazards(lines, name):
+    """VALU write of an SGPR (v_readfirstlane) followed by an inline-asm VMEM read of it needs 5 wait states."""
+    bad = 0
+    real = [(i, l.strip()) for i, l in enumerate(lines) if l.strip() and not l.strip().startswith(';') and not l.strip().startswith('.')]
+    for k, (i, t) in enumerate(real):
+        if not t.startswith('global_load') or ' s[' not in t: continue
+        m = re.search(r's\[(\d+):(\d+)\]', t)
+        if not m: continue
+        need = {int(m.group(1)), int(m.group(2))}
+        slots = 0
+        for j in range(k - 1, max(k - 12, -1), -1):
+            u = real[j][1]
+            if slots >= 5: break
+            w = re.match(r'v_readfirstlane_b32 s(\d+),', u)
+            if w and int(w.group(1)) in need:
+                bad += 1
+                print('  SGPR HAZARD %s line %d: %s  (written at line %d, %d wait states)' % (name, i + 1, t, real[j][0] + 1, slots))
+                break
+            n = re.match(r's_nop (\d+)', u)
+            slots += (int(n.group(1)) + 1) if n else 1
+    return bad
+
+
+def audit(lines, name):
+    inasm = False
+    pending = []          # list of (line, [regs]) in issue order
+    bad = nload = scratch = 0
+    for i, l in enumerate(lines):
+        t = l.strip()
+        if t.startswith(';;#ASMSTART'): inasm = True; continue
+        if t.startswith(';;#ASMEND'): inasm = False; continue
+        if not t or t.startswith(';') or t.startswith('.'): continue
+        if 'scratch_' in t: scratch += 1
+        if inasm and t.startswith('global_load'):
+            pending.append((i, regs(t.split()[1].rstrip(','))))
+            nload += 1
+            continue
+        if inasm and t.startswith('s_waitcnt vmcnt'):
+            n = int(re.search(r'vmcnt\((\d+)\)', t).group(1))
+            pending = pending[-n:] if n > 0 else []
+            continue
+        if t.startswith('s_') or t.startswith('.LBB'): continue
+        used = set(regs(' '.join(t.split()[1:])))
+        for ln, rr in pending:
+            if used & set(rr):
+                bad += 1
+                if bad <= 10: print('  HAZARD %s line %d: %s   (load at line %d)' % (name, i + 1, t, ln + 1))
+    sg = sgpr_hazards(lines, name)
+    print('%s: %d asm loads, %d hazards, %d SGPR hazards, %d scratch instructions' % (name, nload, bad, sg, scratch))
+    return bad + scratch + sg
+
+
+def main():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'c6.s')
+        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-S', '--cuda-device-only', SRC, '-o', out])
+        text = open(out).read().split('\n')
+    total = 0
+    cur, name = [], None
+    for l in text:
+        m = re.match(r'^(_ZN\S*k_conv6\S*):', l)
+        if m:
+            name, cur = m.group(1)[:40], []
+        if name is not None:
+            cur.append(l)
+            if l.startswith('.Lfunc_end'):
+                total += audit(cur, name)
+                name = None
+    sys.exit(1 if total else 0)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Barrier-arrival timeline of k_conv6 (QMRI_CONV_STAMPS=1) for the last conv launch of a UNetRes forward.  GPU only."""
+import ctypes as C
+import os
+import sys
+
+os.environ['QMRI_CONV_STAMPS'] = '1'
+os.environ.setdefault('QMRI_CONV_STAMP_LAUNCH', '-1')
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
+
+eng = E.Engine(0)
+eng.set_denoiser(synth.structured_weights(seed=2, eps=0.02), 224, 224, max_batch=1)
+x = synth.uniform01(9001, 224 * 224 * 10).reshape(224, 224, 10)
+for _ in range(2):
+    y = eng.denoise(x)
+buf = np.zeros((4096 * 11,), np.uint64)
+eng.L.qmri_debug_conv_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+assert eng.L.qmri_debug_conv_stamps(eng.h, buf.ctypes.data, 0) == 0
+s = buf[:8 * 4 * 128].reshape(8, 4, 128).astype(np.int64)
+tmin = min(int(s[wg, 0][0]) for wg in range(8) if s[wg, 0][0] > 0)
+for wg in range(8):
+    m = s[wg, 0]; n = int((m > 0).sum())
+    print('WG %3d: first stamp +%.2f us, loop end +%.2f, epilogue end +%.2f' % (wg * 13, (m[0] - tmin) / 100.0, (m[13] - tmin) / 100.0, (m[14] - tmin) / 100.0))
+for wg in (0,):
+    m, l, w0, w1 = s[wg, 0], s[wg, 1], s[wg, 2], s[wg, 3]
+    t0 = min(m[0], l[0])
+    print('WG', wg * 13)
+    print('  barrier  mfma_arrive  load_arrive | loader: issued-loads  data-arrived  (us)')
+    for k in range(14):
+        print('  %2d  %7.2f  %7.2f | %7.2f  %7.2f' % (k, (m[k] - t0) / 100.0, (l[k] - t0) / 100.0, (w0[k] - t0) / 100.0, (w1[k] - t0) / 100.0))
+
+seq = buf[8192:8192 + 128].reshape(64, 2).astype(np.int64)
+order = np.argsort(seq[:, 0])
+prev = None
+print('last 3x3 launches (WG 0): in-kernel span and gap to the previous launch, us')
+for i in order:
+    a, b = seq[i]
+    if a == 0: continue
+    print('  span %.2f   gap %s' % ((b - a) / 100.0, '%.2f' % ((a - prev) / 100.0) if prev else '-'))
+    prev = b
