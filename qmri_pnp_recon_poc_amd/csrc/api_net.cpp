@@ -41,6 +41,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     for (float* b : p.allocs) if (b) (void)hipFree(b);
     if (p.d_counter) (void)hipFree(p.d_counter);
     if (p.d_stamps) (void)hipFree(p.d_stamps);
+    if (p.d_c6part) (void)hipFree(p.d_c6part);
     p = NetPlan();
 }
 

@@ -40,6 +40,8 @@ struct Conv6Args {
     int in_hp, in_plane; long in_bs;          // padded row pitch, plane size, batch stride (elements)
     int out_hp, out_plane; long out_bs, add1_bs, add2_bs;
     int nchunk, n_ct, tiles_h, tiles_w, relu_out;
+    int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
+    long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
     unsigned long long* stamps;   // diagnostic (QMRI_CONV_STAMPS): [16 workgroups][2 roles][128] barrier-arrival times, 100 MHz clock
 };
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
     int bid = blockIdx.x;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
     const int th = bid % A.tiles_h; bid /= A.tiles_h;
-    const int tw = bid % A.tiles_w;
-    const int b = bid / A.tiles_w;
+    const int tw = bid % A.tiles_w; bid /= A.tiles_w;
+    const int ks = bid % A.ksplit;                                  // K slice of this workgroup (split-K layers)
+    const int b = bid / A.ksplit;
     const int oh0 = th * TH, ow0 = tw * TW;
     const int nsteps = 3 * A.nchunk;
 
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
         // ------------------------------------------------------------------ loaders
         const int lt = tid - (NT6 - NLD6);
         __builtin_amdgcn_s_setprio(2);                             // requests first: the MFMA waves have work queued anyway
-        const uint4* wsrc = A.wp + (size_t)ct * A.nchunk * 3 * AST;               // steps of this cout tile are contiguous
-        const float* isrc = A.in + (size_t)b * A.in_bs + (size_t)ow0 * A.in_hp + oh0;   // halo origin = padded (oh0, ow0)
+        const uint4* wsrc = A.wp + ((size_t)ct * A.nchunk_all + (size_t)ks * A.nchunk) * 3 * AST;   // steps of a cout tile are contiguous
+        const float* isrc = A.in + (size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0;   // halo origin = padded (oh0, ow0)
         unsigned aoff[NAQ], boff[3][8];                            // loop-invariant byte offsets of this thread's requests
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
@@ -217,7 +220,9 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
 #define ITER(k_, rs_a, rs_b, rq_a, rq_b)   /* iteration g + k_, g = 3*c0 */                                       \
         {                                                                                                        \
             constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
+            __builtin_amdgcn_s_setprio(2);         /* requests first ... */                                       \
             LOAD_A(g + (k_) + 3, rq_a) LOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                       \
+            __builtin_amdgcn_s_setprio(0);         /* ... the split arithmetic only in the MFMA waves' issue gaps */ \
             C6_STAMP(2, g + (k_) + 1);                                                                           \
             gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
             C6_STAMP(3, g + (k_) + 1);                                                                           \
@@ -290,6 +295,8 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
                 }
         }
         C6_STAMP(0, g + 1);
+        if (A.stamps && A.detail && tid == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && g + 65 < 128)
+            A.stamps[((blockIdx.x / 13) * 4 + 0) * 128 + g + 65] = __builtin_readcyclecounter();
         lds_barrier6();                                             // barrier g+1
     }
     C6_STAMP(0, nsteps + 1);
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
             const int co = e / PXT, rem = e - co * PXT;
             float x = (ot[co * PP + rem] + r1[k]) + r2[k];
             if (A.relu_out) x = fmaxf(x, 0.f);
-            if (off[k] != ~0u) A.out[(size_t)b * A.out_bs + off[k]] = x;
+            if (off[k] != ~0u) A.out[(size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]] = x;
         }
     }
     C6_STAMP(0, nsteps + 2);
@@ -352,7 +359,7 @@ template <int CFG> constexpr size_t conv6_lds() {
 
 template <int CFG>
 int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
-            const PTensor* add2, int relu_out) {
+            const PTensor* add2, int relu_out, int ksplit = 1, float* partial = nullptr, long out_ks = 0) {
     typedef Cfg6<CFG> C;
     Conv6Args A;
     A.in = in.p; A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.p;
@@ -362,7 +369,8 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.out_hp = out.H + 2; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.add1_bs = add1 ? (long)add1->Cal * add1->plane() : 0;
     A.add2_bs = add2 ? (long)add2->Cal * add2->plane() : 0;
-    A.nchunk = L.nchunk6; A.n_ct = L.n_ct6;
+    A.nchunk = L.nchunk6 / ksplit; A.nchunk_all = L.nchunk6; A.ksplit = ksplit; A.out_ks = out_ks; A.n_ct = L.n_ct6;
+    if (partial) { A.out = partial; A.add1 = A.add2 = nullptr; relu_out = 0; }   // raw partial sums; k_conv6_reduce finishes the layer
     A.tiles_h = (in.H + C::TH - 1) / C::TH; A.tiles_w = (in.W + C::TW - 1) / C::TW;
     A.relu_out = relu_out;
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
@@ -374,10 +382,31 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>()));
         ctx->conv6_attr[CFG] = true;
     }
-    const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;
+    const int grid = A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
     k_conv6<CFG><<<dim3(grid), dim3(NT6), conv6_lds<CFG>(), ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
+}
+
+// split-K layers: out = relu(sum_k partial_k + add1 + add2), partial sums added in slice order
+__global__ __launch_bounds__(256) void k_conv6_reduce(const float* __restrict__ part, int ksplit, long out_ks, float* __restrict__ out,
+                                                        const float* __restrict__ add1, const float* __restrict__ add2, long add1_bs,
+                                                        long add2_bs, long out_bs, int Cout, int H, int W, int hp, int plane, int relu,
+                                                        long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int h = (int)(i % H);
+    long r = i / H;
+    const int w = (int)(r % W); r /= W;
+    const int c = (int)(r % Cout);
+    const long b = r / Cout;
+    const long o = (long)c * plane + (long)(w + 1) * hp + (h + 1);
+    float v = 0.f;
+    for (int k = 0; k < ksplit; ++k) v += part[(long)k * out_ks + b * out_bs + o];
+    if (add1) v += add1[b * add1_bs + o];
+    if (add2) v += add2[b * add2_bs + o];
+    if (relu) v = fmaxf(v, 0.f);
+    out[b * out_bs + o] = v;
 }
 
 inline uint16_t host_bf16(float x) {                               // round to nearest even, as v_cvt_pk_bf16_f32
@@ -430,5 +459,31 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     auto ntiles = [&](int th, int tw) { return (long)L.n_ct6 * ((in.H + th - 1) / th) * ((in.W + tw - 1) / tw) * B; };
     if (in.H % 16 == 0 && in.W % 16 == 0 && ntiles(16, 16) >= 160) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
     if (in.H % 16 == 0 && ntiles(16, 8) >= 160) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
+    // Small feature maps with many channels (the 28 x 28 x 512 level): a 64-pixel tile would re-read the layer's weights
+    // once per tile (16 x 14 MB); instead keep the 256-pixel tile and split K over workgroups, then add the partial
+    // outputs in slice order (deterministic) in a second, elementwise kernel.
+    static const bool splitk_on = !(getenv("QMRI_CONV_SPLITK") && atoi(getenv("QMRI_CONV_SPLITK")) == 0);
+    if (splitk_on && in.H <= 32 && L.nchunk6 >= 16) {
+        int ksplit = 1;
+        while (ksplit * 2 * ntiles(16, 16) <= 256 && L.nchunk6 % (ksplit * 2) == 0 && L.nchunk6 / (ksplit * 2) >= 4) ksplit *= 2;
+        if (ksplit > 1) {
+            const long out_ks = (long)B * out.Cal * out.plane();
+            const size_t need = (size_t)ksplit * out_ks + 8192;
+            NetPlan& net = ctx->net;
+            if (net.c6part_floats < need) {
+                if (net.d_c6part) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); QMRI_HIP(ctx, hipFree(net.d_c6part)); net.d_c6part = nullptr; }
+                QMRI_HIP(ctx, hipMalloc((void**)&net.d_c6part, need * sizeof(float)));
+                net.c6part_floats = need;
+            }
+            QMRI_TRY(launch6<0>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            const long total = (long)B * L.Cout * in.H * in.W;
+            k_conv6_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+                net.d_c6part, ksplit, out_ks, out.p, add1 ? add1->p : nullptr, add2 ? add2->p : nullptr,
+                add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(),
+                L.Cout, in.H, in.W, out.H + 2, (int)out.plane(), relu_out, total);
+            QMRI_HIP(ctx, hipGetLastError());
+            return QMRI_OK;
+        }
+    }
     return launch6<2>(ctx, L, B, in, out, add1, add2, relu_out);
 }

@@ -151,6 +151,8 @@ struct NetPlan {
     std::vector<float*> allocs;
     unsigned* d_counter = nullptr;   // tile-queue counter of the persistent conv kernels
     unsigned counter_base = 0;       // host mirror of its value after the launches issued so far
+    float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
+    size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
     bool ready = false;
 };

@@ -32,6 +32,10 @@ for wg in (0,):
     for k in range(14):
         print('  %2d  %7.2f  %7.2f | %7.2f  %7.2f' % (k, (m[k] - t0) / 100.0, (l[k] - t0) / 100.0, (w0[k] - t0) / 100.0, (w1[k] - t0) / 100.0))
 
+m = s[0, 0]
+cyc = m[65:65 + 12]
+print('core cycles per step (WG 0):', ' '.join(str(int(cyc[i + 1] - cyc[i])) for i in range(11)))
+print('wall us per step          :', ' '.join('%.2f' % ((m[i + 2] - m[i + 1]) / 100.0) for i in range(11)))
 seq = buf[8192:8192 + 128].reshape(64, 2).astype(np.int64)
 order = np.argsort(seq[:, 0])
 prev = None
