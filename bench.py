@@ -12,8 +12,11 @@ one GPU and reconstructs its own slice (slices are independent: weak scaling, no
 timed region starts.  Data and weights are synthetic (seeded; the reference ships neither).
 
 The JSON line also carries
-  roofline     -- the dominant kernel (conv3x3 on the f32 MFMA): algorithmic FLOP per launch / mean launch duration
-                  measured live with HIP events on the launch stream, against the 157.3 TFLOP/s f32-MFMA peak
+  roofline     -- the dominant kernel (k_conv6: conv3x3 as implicit GEMM on v_mfma_f32_32x32x16_bf16, every fp32 operand
+                  split exactly into three bf16 pieces, six MFMA products per fp32-equivalent product): MFMA FLOP executed
+                  per launch (6 x the algorithmic 2*Cout*Cin*9*H*W) / mean launch duration measured live with HIP events on
+                  the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak; `fp32_equivalent_tflops` is the
+                  algorithmic rate
   cpu_baseline -- the CPU oracle (a C/OpenMP restatement of the shipped algorithm, `kind: port`) timed on this
                   box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 `--workload slices` instead times whole slices (100 ADMM iterations + dictionary match) over a per-GPU batch.
@@ -30,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16, 32 cycles)
+SPLIT_PRODUCTS = 6                    # bf16 x bf16 MFMA products per fp32-equivalent product (conv6_kernels.hip)
 CONV3X3_FLOP = 2 * 64 * 64 * 9 * 224 * 224      # 3 699 376 128: identical at all four UNetRes levels
 DENOISER_FLOP = 213_253_619_712                 # SURVEY.md section 8d (10-channel UNetRes at 224 x 224)
 
@@ -162,11 +167,20 @@ def main():
         eng.profile_enable(0)
         if pr["n_conv3x3"] > 0:
             avg_s = pr["ms_conv3x3"] / pr["n_conv3x3"] * 1e-3
-            ach = CONV3X3_FLOP * B / avg_s / 1e12
-            roof = {"kernel": "k_conv<3x3> (implicit-GEMM conv3x3 on v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                    "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
-                    "flop_per_launch": CONV3X3_FLOP * B}
+            f32_path = bool(int(os.environ.get("QMRI_CONV_F32", "0")))
+            if f32_path:
+                ach = CONV3X3_FLOP * B / avg_s / 1e12
+                roof = {"kernel": "k_conv<3x3> (implicit-GEMM conv3x3 on v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                        "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
+                        "flop_per_launch": CONV3X3_FLOP * B}
+            else:
+                ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
+                roof = {"kernel": "k_conv6 (implicit-GEMM conv3x3 on v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate)",
+                        "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                        "launches_timed": int(pr["n_conv3x3"]), "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B,
+                        "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3), "fp32_equivalent_flop_per_launch": CONV3X3_FLOP * B}
         # stage split of one short run (profile level 1 synchronises per stage; not part of the timed region)
         if args.workload == "admm":
             eng.profile_enable(1)
@@ -202,7 +216,9 @@ def main():
         if args.workload == "admm":
             metric, unit = "ADMM iters/sec (224x224x10 TSMI, spiral mask)", "ADMM iters/s"
             cfg = {"workload": "cut3 224x224x10 single slice per GPU, spiral mask S=771 T=200, PnP-ADMM + 10-channel UNetRes (DRUNet) denoiser",
-                   "solver": args.solver, "admm_iters": args.steps, "dc_dtype": "f64", "parallelism": f"slice-parallel x{world} (no collective)"}
+                   "solver": args.solver, "admm_iters": args.steps, "dc_dtype": "f64",
+                   "denoiser_arith": "f32 results: 3x3 convs as 3-way bf16 split x 6 MFMA products with f32 accumulation, 2x2 convs on the f32 MFMA",
+                   "parallelism": f"slice-parallel x{world} (no collective)"}
             ms_per_step = dt / max(args.steps, 1) * 1e3
         else:
             metric, unit = "slices/sec (120-slice synthetic batch: 100 ADMM iterations + dictionary match per slice)", "slices/s"

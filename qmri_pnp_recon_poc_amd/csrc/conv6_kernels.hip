@@ -208,8 +208,16 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
             }                                                                                                    \
         }
         // prologue: B(chunk 0) in three parts, A(0); then the requests for the stores of iterations 0 and 1
-        for (int part = 0; part < 3; ++part) { LOAD_B(0, part, rb0) LOAD_A(0, ra0) gwait<0>(ra0, rb0); STORE_B(0, part, rb0) }
-        STORE_A(0, ra0)
+        // (all of the first chunk is requested at once -- one memory latency, not three)
+        LOAD_A(0, ra0) LOAD_B(0, 0, rb0)
+        LOAD_A(0, ra1) LOAD_B(0, 1, rb1)
+        LOAD_A(0, ra2) LOAD_B(0, 2, rb2)
+        gwait<2 * NLOAD>(ra0, rb0);
+        STORE_A(0, ra0) STORE_B(0, 0, rb0)
+        gwait<NLOAD>(ra1, rb1);
+        STORE_B(0, 1, rb1)
+        gwait<0>(ra2, rb2);
+        STORE_B(0, 2, rb2)
         LOAD_A(1, ra1) LOAD_B(1, 0, rb1)                            // stored by iteration 0
         LOAD_A(2, ra2) LOAD_B(1, 1, rb2)                            // stored by iteration 1
         C6_STAMP(1, 0);

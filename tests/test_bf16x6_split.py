@@ -1,0 +1,28 @@
+"""CPU model of the operand splitting used by the 3x3 conv kernel (conv6_kernels.hip): the three-way bf16 split is
+exact and six piece products reproduce an fp32 product sum to fp32 accumulation accuracy."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import bf16x6_check as m  # noqa: E402
+
+
+def test_split_is_exact():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(4096) * s for s in (1e-6, 1e-3, 1.0, 1e3)]).astype(np.float32)
+    a0, a1, a2 = m.split3(x)
+    assert np.all(a0.astype(np.float64) + a1.astype(np.float64) + a2.astype(np.float64) == x.astype(np.float64))
+    for a in (a0, a1, a2):                                     # every piece is a bf16 value
+        assert np.all((a.view(np.uint32) & 0xFFFF) == 0)
+
+
+def test_six_products_match_fp32_accuracy():
+    rng = np.random.default_rng(2)
+    A = (rng.standard_normal((64, 576)) * 0.05).astype(np.float32)
+    B = np.maximum(rng.standard_normal((576, 128)), 0).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    e6, e32, e3 = m.rel(m.six_product(A, B), ref), m.rel(m.mm32(A, B), ref), m.rel(m.three_product(A, B), ref)
+    assert e6 < 5e-7 and e6 < 2.0 * e32 + 1e-7                 # as accurate as an fp32 matmul
+    assert e3 > 10 * e6                                         # the three-product shortcut is not
