@@ -49,6 +49,7 @@ void qmri_free_net(qmri_ctx* ctx) {
 // kernels only ever write channels < C and plane interiors), plus slack for tiles that overhang the image
 static int alloc_tensor(qmri_ctx* ctx, PTensor& t, int C, int Cal, int H, int W, size_t B) {
     t.C = C; t.Cal = std::max(C, Cal); t.H = H; t.W = W;
+    t.h0 = 32; t.hp = ((t.h0 + H + 1 + 31) / 32) * 32;
     const size_t count = B * t.batch_stride() + 8192;
     hipError_t e = hipMalloc((void**)&t.p, count * sizeof(float));
     if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(float), hipGetErrorString(e)); return QMRI_ERR_NOMEM; }

@@ -27,6 +27,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (register arrays of HIP's uint4 struct are not promoted out of scratch)
 
 constexpr int NT6 = 512;         // threads per workgroup: 4 MFMA waves + 4 loader waves
@@ -40,6 +41,7 @@ struct Conv6Args {
     int in_hp, in_plane; long in_bs;          // padded row pitch, plane size, batch stride (elements)
     int out_hp, out_plane; long out_bs, add1_bs, add2_bs;
     int nchunk, n_ct, tiles_h, tiles_w, relu_out;
+    int vec4;                     // epilogue may use aligned float4 accesses (H % 4 == 0 and line-aligned tensors)
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
     constexpr int NLOAD = NAQ + 8 * NBQ;                            // vector-memory loads a loader thread issues per step
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
-    constexpr int PXT = TH * TW, PP = PXT + 2;                      // output tile in LDS: [64 cout][PP], aliases the B buffers
+    constexpr int PXT = TH * TW, PP = PXT + 4;                      // output tile in LDS: [64 cout][PP], aliases the B buffers
     uint4* Bbuf = Abuf + NABUF * AST;                                   // [2][3 splits][2 k-halves][NPX]  (8 channels = 16 B per entry)
 
     float* ot = (float*)Bbuf;
@@ -322,39 +324,73 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
             }
     }   // MFMA waves
 
-    // ---- all eight waves: residual adds, ReLU, stores; consecutive threads walk h, so every request is a run of TH floats.
-    // The residual operands are requested before the barrier that publishes the LDS tile: one memory latency, overlapped.
+    // ---- all eight waves: residual adds, ReLU, stores.  Interior rows start on a 128-byte line (PTensor), tiles on a multiple
+    // of 8 in h: with H % 4 == 0 every group of four consecutive h is one aligned float4.  The residual operands are requested
+    // before the barrier that publishes the LDS tile: one memory latency, overlapped.
     {
         const bool has1 = A.add1 != nullptr, has2 = A.add2 != nullptr;
-        constexpr int NE = 64 * PXT, EQ = NE / NT6;                 // tile elements; elements per thread
-        static_assert(NE % NT6 == 0, "epilogue");
-        unsigned off[EQ];                                           // element offset inside one image (fits 32 bits), ~0u = outside
-        float r1[EQ], r2[EQ];
+        if (A.vec4) {
+            constexpr int NG = 64 * PXT / 4, GQ = NG / NT6;         // float4 groups of the tile; per thread
+            static_assert(NG % NT6 == 0 && TH % 4 == 0, "epilogue");
+            unsigned off[GQ];                                       // element offset inside one image (fits 32 bits), ~0u = outside
+            f32x4 r1[GQ], r2[GQ];
 #pragma unroll
-        for (int k = 0; k < EQ; ++k) {
-            const int e = k * NT6 + tid;
-            const int co = e / PXT, rem = e - co * PXT, w = rem / TH, h = rem - w * TH;
-            const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
-            const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
-            off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
-            r1[k] = 0.f; r2[k] = 0.f;
-        }
-        if (has1) {                                                 // (uniform branches around batches of loads: all in flight together)
+            for (int k = 0; k < GQ; ++k) {
+                const int e = k * NT6 + tid;
+                const int co = e / (PXT / 4), rem = e - co * (PXT / 4), w = rem / (TH / 4), h = 4 * (rem - w * (TH / 4));
+                const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
+                const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
+                off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
+                r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
+            }
+            if (has1) {                                             // (uniform branches around batches of loads: all in flight together)
 #pragma unroll
-            for (int k = 0; k < EQ; ++k) r1[k] = A.add1[(size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 0u)];
-        }
-        if (has2) {
+                for (int k = 0; k < GQ; ++k) r1[k] = *(const f32x4*)(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 1u));
+            }
+            if (has2) {
 #pragma unroll
-            for (int k = 0; k < EQ; ++k) r2[k] = A.add2[(size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 0u)];
-        }
-        lds_barrier6();                                             // the output tile is complete
+                for (int k = 0; k < GQ; ++k) r2[k] = *(const f32x4*)(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 1u));
+            }
+            lds_barrier6();                                         // the output tile is complete
 #pragma unroll
-        for (int k = 0; k < EQ; ++k) {
-            const int e = k * NT6 + tid;
-            const int co = e / PXT, rem = e - co * PXT;
-            float x = (ot[co * PP + rem] + r1[k]) + r2[k];
-            if (A.relu_out) x = fmaxf(x, 0.f);
-            if (off[k] != ~0u) A.out[(size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]] = x;
+            for (int k = 0; k < GQ; ++k) {
+                const int e = k * NT6 + tid;
+                const int co = e / (PXT / 4), rem = e - co * (PXT / 4);
+                f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
+                if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+                if (off[k] != ~0u) *(f32x4*)(A.out + (size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]) = x;
+            }
+        } else {
+            constexpr int NE = 64 * PXT, EQ = NE / NT6;             // tile elements; elements per thread
+            static_assert(NE % NT6 == 0, "epilogue");
+            unsigned off[EQ];
+            float r1[EQ], r2[EQ];
+#pragma unroll
+            for (int k = 0; k < EQ; ++k) {
+                const int e = k * NT6 + tid;
+                const int co = e / PXT, rem = e - co * PXT, w = rem / TH, h = rem - w * TH;
+                const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
+                const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
+                off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
+                r1[k] = 0.f; r2[k] = 0.f;
+            }
+            if (has1) {
+#pragma unroll
+                for (int k = 0; k < EQ; ++k) r1[k] = A.add1[(size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 0u)];
+            }
+            if (has2) {
+#pragma unroll
+                for (int k = 0; k < EQ; ++k) r2[k] = A.add2[(size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 0u)];
+            }
+            lds_barrier6();                                         // the output tile is complete
+#pragma unroll
+            for (int k = 0; k < EQ; ++k) {
+                const int e = k * NT6 + tid;
+                const int co = e / PXT, rem = e - co * PXT;
+                float x = (ot[co * PP + rem] + r1[k]) + r2[k];
+                if (A.relu_out) x = fmaxf(x, 0.f);
+                if (off[k] != ~0u) A.out[(size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]] = x;
+            }
         }
     }
     C6_STAMP(0, nsteps + 2);
@@ -370,17 +406,19 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
             const PTensor* add2, int relu_out, int ksplit = 1, float* partial = nullptr, long out_ks = 0) {
     typedef Cfg6<CFG> C;
     Conv6Args A;
-    A.in = in.p; A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.p;
-    A.add1 = add1 ? add1->p : nullptr; A.add2 = add2 ? add2->p : nullptr;
+    A.in = in.base1(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.base1();
+    A.add1 = add1 ? add1->base1() : nullptr; A.add2 = add2 ? add2->base1() : nullptr;
     A.Cout = L.Cout; A.W = in.W; A.H = in.H;
-    A.in_hp = in.H + 2; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
-    A.out_hp = out.H + 2; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
+    A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
+    A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.add1_bs = add1 ? (long)add1->Cal * add1->plane() : 0;
     A.add2_bs = add2 ? (long)add2->Cal * add2->plane() : 0;
     A.nchunk = L.nchunk6 / ksplit; A.nchunk_all = L.nchunk6; A.ksplit = ksplit; A.out_ks = out_ks; A.n_ct = L.n_ct6;
-    if (partial) { A.out = partial; A.add1 = A.add2 = nullptr; relu_out = 0; }   // raw partial sums; k_conv6_reduce finishes the layer
+    if (partial) { A.out = partial + (out.h0 - 1); A.add1 = A.add2 = nullptr; relu_out = 0; }   // raw partial sums; k_conv6_reduce finishes the layer
     A.tiles_h = (in.H + C::TH - 1) / C::TH; A.tiles_w = (in.W + C::TW - 1) / C::TW;
     A.relu_out = relu_out;
+    A.vec4 = (in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
+              (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp))) ? 1 : 0;
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
     static int launch_counter = 0;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
@@ -486,9 +524,9 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             QMRI_TRY(launch6<0>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
             const long total = (long)B * L.Cout * in.H * in.W;
             k_conv6_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-                net.d_c6part, ksplit, out_ks, out.p, add1 ? add1->p : nullptr, add2 ? add2->p : nullptr,
+                net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.base1(), add1 ? add1->base1() : nullptr, add2 ? add2->base1() : nullptr,
                 add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(),
-                L.Cout, in.H, in.W, out.H + 2, (int)out.plane(), relu_out, total);
+                L.Cout, in.H, in.W, out.hp, (int)out.plane(), relu_out, total);
             QMRI_HIP(ctx, hipGetLastError());
             return QMRI_OK;
         }

@@ -383,12 +383,12 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         L.tab_B = B; L.tab_MT = MT;
     }
     ConvArgs A;
-    A.in = in.p; A.wp = reinterpret_cast<const float4*>(L.wp); A.out = out.p;
-    A.add1 = add1 ? add1->p : nullptr; A.add2 = add2 ? add2->p : nullptr;
+    A.in = in.base1(); A.wp = reinterpret_cast<const float4*>(L.wp); A.out = out.base1();
+    A.add1 = add1 ? add1->base1() : nullptr; A.add2 = add2 ? add2->base1() : nullptr;
     A.tab = reinterpret_cast<const int4*>(L.d_tab);
     A.Cout = L.Cout; A.W = W; A.H = H; A.OW = OW; A.OH = OH;
-    A.in_hp = in.H + 2; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
-    A.out_hp = out.H + 2; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
+    A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
+    A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.add1_bs = add1 ? (long)add1->Cal * add1->plane() : 0;
     A.add2_bs = add2 ? (long)add2->Cal * add2->plane() : 0;
     A.nch = L.cin_pad / G_::CC; A.ntiles = ntiles; A.relu_out = relu_out;

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(NT) void k_real_to_complex(size_t count, const doub
 int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H, int s, int multi_level, double noise_std,
                                const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32) {
     k_minmax<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, x, u, mm);
-    k_normalise<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, plane, H, s, multi_level, noise_std, x, u, mm, nblk, norm, in32.p,
-                                                             in32.H + 2, (int)in32.plane(), in32.batch_stride());
+    k_normalise<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, plane, H, s, multi_level, noise_std, x, u, mm, nblk, norm, in32.base1(),
+                                                             in32.hp, (int)in32.plane(), in32.batch_stride());
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -207,7 +207,7 @@ int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H,
 int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H, const PTensor& out32, const PTensor& in32,
                                int residual_noise, const double* norm, const double2* x, double2* u, double2* v) {
     k_unnormalise_dual<<<dim3((unsigned)((n + NT - 1) / NT), B), dim3(NT), 0, ctx->stream>>>(
-        n, plane, H, out32.H + 2, (int)out32.plane(), out32.batch_stride(), in32.batch_stride(), out32.p, in32.p, residual_noise, norm,
+        n, plane, H, out32.hp, (int)out32.plane(), out32.batch_stride(), in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, norm,
         x, u, v);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
@@ -228,9 +228,9 @@ int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, i
     const size_t count = (size_t)C * H * W;
     dim3 grid((unsigned)((count + NT - 1) / NT), B), blk(NT);
     if (src_is_double)
-        k_pack<double><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.H + 2, (int)dst.plane(), dst.batch_stride(), (const double*)src, dst.p);
+        k_pack<double><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.hp, (int)dst.plane(), dst.batch_stride(), (const double*)src, dst.base1());
     else
-        k_pack<float><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.H + 2, (int)dst.plane(), dst.batch_stride(), (const float*)src, dst.p);
+        k_pack<float><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.hp, (int)dst.plane(), dst.batch_stride(), (const float*)src, dst.base1());
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -240,11 +240,11 @@ int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& o
     const size_t count = (size_t)C * H * W;
     dim3 grid((unsigned)((count + NT - 1) / NT), B), blk(NT);
     if (dst_is_double)
-        k_unpack<double><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.H + 2, (int)out32.plane(), out32.batch_stride(),
-                                                       in32.batch_stride(), out32.p, in32.p, residual_noise, (double*)dst);
+        k_unpack<double><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.hp, (int)out32.plane(), out32.batch_stride(),
+                                                       in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, (double*)dst);
     else
-        k_unpack<float><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.H + 2, (int)out32.plane(), out32.batch_stride(),
-                                                      in32.batch_stride(), out32.p, in32.p, residual_noise, (float*)dst);
+        k_unpack<float><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.hp, (int)out32.plane(), out32.batch_stride(),
+                                                      in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, (float*)dst);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }

@@ -132,11 +132,16 @@ struct ConvLayer {
     int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks, 64-row output tiles of wp6
 };
 
-// activation tensor in HBM: [B][Cal][W+2][H+2] fp32, h fastest, permanent zero halo, channels >= C are zero
+// activation tensor in HBM: [B][Cal][W+2][hp] fp32, h fastest, permanent zero halo, channels >= C are zero.
+// A row holds h0 - 1 unused floats, the top halo, the H interior values (starting at float h0), the bottom halo and padding
+// up to the pitch hp; h0 and hp are multiples of 32, so every interior row starts on a 128-byte line.  Kernels address the
+// tensor through base1(), relative to which the interior starts at +1 as in a plain [W+2][H+2] layout with pitch hp.
 struct PTensor {
     float* p = nullptr;
     int C = 0, Cal = 0, H = 0, W = 0;
-    size_t plane() const { return (size_t)(H + 2) * (W + 2); }
+    int hp = 0, h0 = 1;
+    float* base1() const { return p + (h0 - 1); }
+    size_t plane() const { return (size_t)hp * (W + 2); }
     size_t batch_stride() const { return (size_t)Cal * plane(); }
 };
 
