@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 63) * 2] = wall_clock64();
+    if (A.stamps && tid == 0 && blockIdx.x == 0) { A.stamps[8192 + (A.launch_idx & 127) * 4] = wall_clock64(); A.stamps[8192 + (A.launch_idx & 127) * 4 + 3] = (unsigned long long)(CFG * 1000 + nsteps); }
     C6_STAMP(0, 0);
     lds_barrier6();                                                 // barrier 0
     for (int g = 0; g < nsteps; ++g) {
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
         lds_barrier6();                                             // barrier g+1
     }
     C6_STAMP(0, nsteps + 1);
+    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 1] = wall_clock64();
 
     // ---- accumulators -> LDS tile ot[cout][pixel] (the B buffers are free now).  C/D layout: col = lane&31 (pixel),
     // row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -394,12 +395,14 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
         }
     }
     C6_STAMP(0, nsteps + 2);
-    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 63) * 2 + 1] = wall_clock64();
+    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64();
 }
 
 template <int CFG> constexpr size_t conv6_lds() {
     return (size_t)(NABUF * AST + 2 * 3 * 2 * (((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 2)) * 16;
 }
+
+static int g_launch_counter = 0;     // diagnostic: running number of k_conv6 launches (all configurations)
 
 template <int CFG>
 int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
@@ -420,9 +423,8 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.vec4 = (in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
               (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp))) ? 1 : 0;
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
-    static int launch_counter = 0;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
-    A.launch_idx = launch_counter++;
+    A.launch_idx = g_launch_counter++;
     A.detail = (stamp_launch < 0 || A.launch_idx == stamp_launch) ? 1 : 0;
     if (!ctx->conv6_attr[CFG]) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>()));

@@ -36,12 +36,13 @@ m = s[0, 0]
 cyc = m[65:65 + 12]
 print('core cycles per step (WG 0):', ' '.join(str(int(cyc[i + 1] - cyc[i])) for i in range(11)))
 print('wall us per step          :', ' '.join('%.2f' % ((m[i + 2] - m[i + 1]) / 100.0) for i in range(11)))
-seq = buf[8192:8192 + 128].reshape(64, 2).astype(np.int64)
+seq = buf[8192:8192 + 512].reshape(128, 4).astype(np.int64)
 order = np.argsort(seq[:, 0])
 prev = None
-print('last 3x3 launches (WG 0): in-kernel span and gap to the previous launch, us')
+print('k_conv6 launches (WG 0): cfg steps | prologue+loop  epilogue  total | gap to previous launch   (us)')
 for i in order:
-    a, b = seq[i]
+    a, l, e, info = seq[i]
     if a == 0: continue
-    print('  span %.2f   gap %s' % ((b - a) / 100.0, '%.2f' % ((a - prev) / 100.0) if prev else '-'))
-    prev = b
+    print('  cfg %d steps %3d | %6.2f %6.2f %6.2f | %s' % (info // 1000, info % 1000, (l - a) / 100.0, (e - l) / 100.0, (e - a) / 100.0,
+                                                       '%.2f' % ((a - prev) / 100.0) if prev else '-'))
+    prev = e
