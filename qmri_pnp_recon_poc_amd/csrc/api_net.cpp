@@ -41,6 +41,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     for (float* b : p.allocs) if (b) (void)hipFree(b);
     if (p.d_counter) (void)hipFree(p.d_counter);
     if (p.d_stamps) (void)hipFree(p.d_stamps);
+    for (hipGraphExec_t g : p.fwd_graph) if (g) (void)hipGraphExecDestroy(g);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
     p = NetPlan();
 }
@@ -218,6 +219,28 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
     return QMRI_OK;
 }
 
+// The forward pass is a fixed sequence of ~65 dependent launches with fixed arguments.  With QMRI_GRAPH=1 it is captured
+// into a hipGraph per batch size after one ordinary call (which performs every lazy allocation and attribute call) and
+// replayed.  Off by default: measured on MI355X the replay is not faster (413.7 vs 413.8 ADMM it/s) -- the 3-4 us between
+// dependent kernels are spent on the device (command processor, cache maintenance), not on the host.
+static int net_forward(qmri_ctx* ctx, int B) {
+    NetPlan& p = ctx->net;
+    static const bool use_graph = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;
+    if (!use_graph || B > 8 || ctx->prof_level >= 2 || p.d_stamps) return net_forward_padded(ctx, B);
+    if (p.fwd_graph[B]) { QMRI_HIP(ctx, hipGraphLaunch(p.fwd_graph[B], ctx->stream)); return QMRI_OK; }
+    if (p.fwd_calls[B]++ == 0) return net_forward_padded(ctx, B);
+    hipGraph_t graph = nullptr;
+    QMRI_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int st = net_forward_padded(ctx, B);
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (st != QMRI_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+    QMRI_HIP(ctx, e);
+    QMRI_HIP(ctx, hipGraphInstantiate(&p.fwd_graph[B], graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    QMRI_HIP(ctx, hipGraphLaunch(p.fwd_graph[B], ctx->stream));
+    return QMRI_OK;
+}
+
 extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, float* d_out) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
@@ -225,7 +248,7 @@ extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, flo
     if (!p.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
     QMRI_CHECK_ARG(ctx, d_in && d_out && B >= 1 && B <= p.maxB, "qmri_net_forward_dev arguments / batch > max_batch");
     QMRI_TRY(ew_launch_pack(ctx, B, p.desc.in_nc, p.H, p.W, d_in, 0, p.in32));
-    QMRI_TRY(net_forward_padded(ctx, B));
+    QMRI_TRY(net_forward(ctx, B));
     QMRI_TRY(ew_launch_unpack(ctx, B, p.desc.out_nc, p.H, p.W, p.out32, p.in32, 0, d_out, 0));
     return QMRI_OK;
 }
@@ -249,7 +272,7 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
     do {
         if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
         if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32)) != QMRI_OK) break;         // im2single: :72-77
-        if ((st = net_forward_padded(ctx, B)) != QMRI_OK) break;                               // activations(...): :88
+        if ((st = net_forward(ctx, B)) != QMRI_OK) break;                                      // activations(...): :88
         if ((st = ew_launch_unpack(ctx, B, p.desc.out_nc, H, W, p.out32, p.in32, p.desc.residual_noise, d_io, 1)) != QMRI_OK) break;
         if (hipMemcpyAsync(out, d_io, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
@@ -346,7 +369,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
                                             o.ls.nblk_z, net.in32));
         tm.stop(ctx->prof.ms_elementwise);
         tm.start();
-        QMRI_TRY(net_forward_padded(ctx, B));
+        QMRI_TRY(net_forward(ctx, B));
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
         tm.start();

@@ -410,9 +410,19 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         occ[MT - 1] = std::max(1, std::min(nb, occ_cap));
     }
     const int grid = std::min(ntiles, ncu * occ[MT - 1]);
-    // every workgroup issues (tiles it processes + 2) fetches, so a launch advances the counter by ntiles + 2*grid
-    A.base = ctx->net.counter_base;
-    ctx->net.counter_base += (unsigned)(ntiles + 2 * grid);
+    // every workgroup issues (tiles it processes + 2) fetches, so a launch advances the counter by ntiles + 2*grid and the
+    // host can mirror its value.  Inside a stream capture (QMRI_GRAPH=1) the arguments are frozen, so the queue is reset by
+    // a memset node instead.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &cap);
+    if (cap == hipStreamCaptureStatusActive || ctx->net.counter_by_memset) {
+        ctx->net.counter_by_memset = true;                 // once a graph exists the mirror is no longer valid
+        QMRI_HIP(ctx, hipMemsetAsync(ctx->net.d_counter, 0, sizeof(unsigned), ctx->stream));
+        A.base = 0;
+    } else {
+        A.base = ctx->net.counter_base;
+        ctx->net.counter_base += (unsigned)(ntiles + 2 * grid);
+    }
     if (MT == 2) k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2><<<dim3(grid), dim3(NT), 0, ctx->stream>>>(A);
     else k_conv<KIND, 1><<<dim3(grid), dim3(NT), 0, ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());

@@ -156,6 +156,9 @@ struct NetPlan {
     std::vector<float*> allocs;
     unsigned* d_counter = nullptr;   // tile-queue counter of the persistent conv kernels
     unsigned counter_base = 0;       // host mirror of its value after the launches issued so far
+    bool counter_by_memset = false;  // graph mode: the queue is reset before every launch instead
+    hipGraphExec_t fwd_graph[9] = {};  // captured forward pass per batch size 1..8 (index B), null until the second call
+    int fwd_calls[9] = {};
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
