@@ -117,12 +117,12 @@ __device__ __forceinline__ void split_pair(float xa, float xb, unsigned& p0, uns
 }
 
 template <int CFG>
-__global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
+__device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     typedef Cfg6<CFG> C;
     constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT;
     constexpr int IH = TH + 2, IW = TW + 2;                         // input tile with halo
     constexpr int IHP = ((IH + 7) / 16) * 16 + 8;                   // its LDS row pitch, = 8 mod 16 entries: conflict-free ds_read_b128 of 8h x 4w blocks
-    constexpr int NPX = IHP * IW;                                   // LDS entries per (split, k-half) plane
+    constexpr int NPX = IHP * (IW - 1) + IH;                        // LDS entries per (split, k-half) plane (the last row is not padded)
     constexpr int NLP = IH * IW;                                    // pixels actually loaded
     static_assert(IHP >= IH, "row pitch");
     constexpr int NBI = 2 * NLP;                                    // loader items of one chunk of B: (k-half, pixel)
@@ -398,8 +398,10 @@ __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) {
     if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64();
 }
 
+template <int CFG> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG>(A); }
+
 template <int CFG> constexpr size_t conv6_lds() {
-    return (size_t)(NABUF * AST + 2 * 3 * 2 * (((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 2)) * 16;
+    return (size_t)(NABUF * AST + 2 * 3 * 2 * ((((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 1) + Cfg6<CFG>::TH + 2)) * 16;
 }
 
 static int g_launch_counter = 0;     // diagnostic: running number of k_conv6 launches (all configurations)
