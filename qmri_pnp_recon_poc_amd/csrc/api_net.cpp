@@ -67,9 +67,10 @@ static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const floa
     hipError_t e = hipMalloc((void**)&L.wp, packed.size() * sizeof(float));
     if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
     QMRI_HIP(ctx, hipMemcpy(L.wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (kind == CONV_3X3) {                                // the same weights for the bf16 x 6 kernel
+    {                                                      // the same weights for the bf16 x 6 kernels
         std::vector<uint16_t> p6;
-        conv6_plan_pack(L, w, p6);
+        if (kind == CONV_3X3) conv6_plan_pack(L, w, p6);
+        else conv6s_plan_pack(L, w, p6);
         e = hipMalloc(&L.wp6, p6.size() * sizeof(uint16_t));
         if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
         QMRI_HIP(ctx, hipMemcpy(L.wp6, p6.data(), p6.size() * sizeof(uint16_t), hipMemcpyHostToDevice));

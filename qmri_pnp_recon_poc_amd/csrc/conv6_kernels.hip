@@ -245,7 +245,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             ITER(1, ra2, rb2, ra1, rb1)
             ITER(2, ra0, rb0, ra2, rb2)
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (clamped requests past the end are still in flight)
+        gwait<0>(ra0, rb0); gwait<0>(ra1, rb1); gwait<0>(ra2, rb2);   // (clamped requests past the end are still in flight)
 #undef ITER
 #undef LOAD_A
 #undef STORE_A
@@ -400,6 +400,195 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 
 template <int CFG> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG>(A); }
 
+// =====================================================================================================================
+// k_conv6s : the 2x2 / stride-2 layers on the same bf16 x 6 scheme.
+//   DOWN  Conv2d(k=2, s=2)           out[co][oh][ow]       = sum_ci,kh,kw w[co][ci][kh][kw] in[ci][2oh+kh][2ow+kw]
+//   UP    ConvTranspose2d(k=2, s=2)  out[co][2ih+kh][2iw+kw] = sum_ci     w[ci][co][kh][kw] in[ci][ih][iw]
+// Both are GEMMs over an 8h x 8w pixel tile (output pixels for DOWN, input pixels for UP) whose K steps hold two "planes":
+//   DOWN  step g = (16-channel chunk c, kw): plane = kh (the tile's input pixels of row parity kh, column parity kw)
+//   UP    step g = 32 channels: plane = 16-channel slice of the same pixels; the workgroup's 64 rows are kh = 0 / 1 x 32
+//         output channels for one kw, so the LDS output tile interleaves the two kh rows and stores contiguous h.
+// Waves 0-3: 2 row tiles x 2 pixel blocks (8h x 4w), 12 MFMAs per step; waves 4-7: loaders as in k_conv6 (asm requests two
+// steps ahead, counted waits), each thread carries 2 channels x 4 consecutive h (one aligned float4 per channel).
+// 49 KB of LDS: three workgroups share a CU and hide each other's barriers.
+// =====================================================================================================================
+constexpr int ASTS = 2 * 2 * 3 * 64;      // uint4 per step of A: 2 planes x 2 row tiles x 3 splits x 64 lanes
+constexpr int STH = 8, STW = 8;           // pixel tile
+constexpr int SNPX = STH * STW;           // LDS entries per (split, k-half, plane): pitch 8 = 8 mod 16, conflict-free
+
+struct Conv6sArgs {
+    const float* in; const uint4* wp; float* out;
+    int Cout;                     // real output channels
+    int GH, GW;                   // extent of the GEMM pixel grid (DOWN: output image, UP: input image)
+    int in_hp, in_plane; long in_bs;
+    int out_hp, out_plane; long out_bs;
+    int nsteps, n_ct, tiles_h, tiles_w;   // nsteps is a multiple of 3 (the register rotation of the loaders); steps >= nsteps_real
+    int nsteps_real;                      // carry zero weights and repeat the last step's activations
+};
+
+template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[3], f32x4 (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void gload4f(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
+
+template <int KIND>               // 0 = DOWN, 1 = UP
+__global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
+    constexpr int NLS = 3 + 2;                                      // vector-memory loads a loader thread issues per step
+    constexpr int OPX = (KIND == 0) ? SNPX : 2 * SNPX;              // output pixels per row of the LDS output tile
+    constexpr int OROWS = (KIND == 0) ? 64 : 32;                    // output channels of the workgroup
+    constexpr int PPs = OPX + 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* Abuf = (uint4*)smem;                                     // [2][ASTS]
+    unsigned* Bbuf = (unsigned*)(Abuf + 2 * ASTS);                  // [2][3 splits][2 k-halves][2 planes][SNPX] x 4 dwords
+    float* ot = (float*)Bbuf;
+    static_assert(OROWS * PPs * 4 <= 2 * 3 * 2 * 2 * SNPX * 16, "output tile must fit the B buffers");
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int ct = bid % A.n_ct; bid /= A.n_ct;
+    const int th = bid % A.tiles_h; bid /= A.tiles_h;
+    const int tw = bid % A.tiles_w;
+    const int b = bid / A.tiles_w;
+    const int gh0 = th * STH, gw0 = tw * STW;                       // tile origin in the GEMM pixel grid
+    const int nsteps = A.nsteps;
+
+    if (tid >= NT6 - NLD6) {
+        // ------------------------------------------------------------------ loaders
+        const int lt = tid - (NT6 - NLD6);
+        const uint4* wsrc = A.wp + (size_t)ct * nsteps * ASTS;
+        unsigned aoff[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);
+        // this thread's activations: 2 channels (pair cp of an 8-channel half) x 4 consecutive h
+        const int cp = lt & 3, rest = lt >> 2;
+        int h2, pl, hg, wq;                                         // k-half, plane (UP: channel slice), h group, column
+        if (KIND == 0) { h2 = rest & 1; hg = (rest >> 1) & 3; wq = rest >> 3; pl = 0; }
+        else { pl = rest & 1; h2 = (rest >> 1) & 1; hg = (rest >> 2) & 1; wq = rest >> 3; }
+        // byte offset of (channel 0 of the pair, first h) relative to the step's base pointer; second channel = + plane
+        unsigned boff;
+        if (KIND == 0) boff = (unsigned)((((size_t)(h2 * 8 + cp * 2)) * A.in_plane + (size_t)(2 * wq) * A.in_hp + 4 * hg) * 4);
+        else boff = (unsigned)((((size_t)(pl * 16 + h2 * 8 + cp * 2)) * A.in_plane + (size_t)wq * A.in_hp + 4 * hg) * 4);
+        const unsigned boff2 = boff + (unsigned)A.in_plane * 4u;
+        // halo-free tile origin: padded coordinates = logical + 1
+        const float* isrc = A.in + (size_t)b * A.in_bs + ((KIND == 0) ? ((size_t)(2 * gw0 + 1) * A.in_hp + 2 * gh0 + 1)
+                                                                      : ((size_t)(gw0 + 1) * A.in_hp + gh0 + 1));
+        __builtin_amdgcn_s_setprio(2);
+        u32x4 ra0[3], ra1[3], ra2[3];
+        f32x4 rb0[2], rb1[2], rb2[2];
+#define SLOAD(g_, ra_, rb_)                                                                                      \
+        {                                                                                                        \
+            const int ga = ((g_) < nsteps) ? (g_) : nsteps - 1, gg = (ga < A.nsteps_real) ? ga : A.nsteps_real - 1;   \
+            const uint4* ws = uniform_ptr(wsrc + (size_t)ga * ASTS);                                             \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) gload4(ra_[q], aoff[q], ws);                           \
+            const float* bs_ = (KIND == 0) ? uniform_ptr(isrc + (size_t)(gg >> 1) * CK * A.in_plane + (size_t)(gg & 1) * A.in_hp) \
+                                           : uniform_ptr(isrc + (size_t)gg * 32 * A.in_plane);                   \
+            gload4f(rb_[0], boff, bs_); gload4f(rb_[1], boff2, bs_);                                             \
+        }
+#define SSTORE(g_, ra_, rb_)                                                                                     \
+        {                                                                                                        \
+            uint4* ad = Abuf + ((g_) & 1) * ASTS;                                                                \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) ad[lt + NLD6 * q] = __builtin_bit_cast(uint4, ra_[q]); \
+            unsigned* bd = Bbuf + ((g_) & 1) * (3 * 2 * 2 * SNPX * 4);                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+                unsigned p0, p1, p2;                                                                             \
+                split_pair(rb_[0][j], rb_[1][j], p0, p1, p2);                                                    \
+                const int hh = 4 * hg + j;                                                                       \
+                const int plane_ = (KIND == 0) ? (hh & 1) : pl;                                                  \
+                const int px = (KIND == 0) ? (wq * STH + (hh >> 1)) : (wq * STH + hh);                           \
+                const int e = ((h2 * 2 + plane_) * SNPX + px) * 4 + cp;                                          \
+                bd[e] = p0; bd[2 * 2 * SNPX * 4 + e] = p1; bd[2 * 2 * 2 * SNPX * 4 + e] = p2;                    \
+            }                                                                                                    \
+        }
+        SLOAD(0, ra0, rb0) SLOAD(1, ra1, rb1) SLOAD(2, ra2, rb2)
+        gwait_s<2 * NLS>(ra0, rb0);
+        SSTORE(0, ra0, rb0)
+        lds_barrier6();                                             // barrier 0
+        // iteration g stores step g+1 (requested two iterations ago) and requests step g+3
+#define SITER(k_, rs_a, rs_b, rq_a, rq_b)                                                                        \
+        {                                                                                                        \
+            __builtin_amdgcn_s_setprio(2);                                                                       \
+            SLOAD(g + (k_) + 3, rq_a, rq_b)                                                                      \
+            __builtin_amdgcn_s_setprio(0);                                                                       \
+            gwait_s<2 * NLS>(rs_a, rs_b);                                                                        \
+            SSTORE(g + (k_) + 1, rs_a, rs_b)                                                                     \
+            lds_barrier6();                                                                                      \
+        }
+        for (int g = 0; g < nsteps; g += 3) {                      // (nsteps % 3 == 0: straight-line rotation, no copies of in-flight registers)
+            SITER(0, ra1, rb1, ra0, rb0)
+            SITER(1, ra2, rb2, ra1, rb1)
+            SITER(2, ra0, rb0, ra2, rb2)
+        }
+        // drain; naming every register set here keeps the compiler from reusing the destinations of requests whose data is
+        // never consumed (the clamped ones past the end) while they are still in flight
+        gwait_s<0>(ra0, rb0); gwait_s<0>(ra1, rb1); gwait_s<0>(ra2, rb2);
+#undef SITER
+#undef SLOAD
+#undef SSTORE
+    } else {
+        // ------------------------------------------------------------------ MFMA waves: row tile m0, pixel block (8h x 4w)
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h2 = lane >> 5;
+        const int m0 = wave & 1, pbw = 4 * (wave >> 1);
+        const int pxl = (pbw + (li >> 3)) * STH + (li & 7);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        lds_barrier6();                                             // barrier 0
+        for (int g = 0; g < nsteps; ++g) {
+            const uint4* ab = Abuf + (g & 1) * ASTS + lane;
+            const uint4* bb = (const uint4*)(Bbuf + (g & 1) * (3 * 2 * 2 * SNPX * 4)) + (h2 * 2) * SNPX + pxl;
+            bf16x8 bf[2][3], af[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    bf[t][sp] = __builtin_bit_cast(bf16x8, bb[sp * 2 * 2 * SNPX + t * SNPX]);
+                    af[t][sp] = __builtin_bit_cast(bf16x8, ab[((t * 2 + m0) * 3 + sp) * 64]);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][2], bf[t][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], bf[t][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], bf[t][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], bf[t][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], bf[t][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], bf[t][0], acc, 0, 0, 0);
+            }
+            lds_barrier6();                                         // barrier g+1
+        }
+        // accumulators -> LDS output tile.  C/D layout: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h2;
+            if (KIND == 0) ot[(m0 * 32 + row) * PPs + (pbw + (li >> 3)) * STH + (li & 7)] = acc[r];
+            else ot[row * PPs + (pbw + (li >> 3)) * (2 * STH) + 2 * (li & 7) + m0] = acc[r];      // m0 = kh: rows interleave in h
+        }
+    }
+    lds_barrier6();
+    // ---- all eight waves: aligned float4 rows of the output tile
+    {
+        constexpr int NG = OROWS * OPX / 4, GQ = NG / NT6;
+        static_assert(NG % NT6 == 0, "epilogue");
+#pragma unroll
+        for (int k = 0; k < GQ; ++k) {
+            const int e = k * NT6 + tid;
+            const int co = e / (OPX / 4), rem = e - co * (OPX / 4);
+            const f32x4 x = *(const f32x4*)(ot + co * PPs + 4 * rem);
+            if (KIND == 0) {
+                const int w = rem / (STH / 4), h = 4 * (rem - w * (STH / 4));
+                const int cog = ct * 64 + co, oh = gh0 + h, ow = gw0 + w;
+                if (cog < A.Cout && oh < A.GH && ow < A.GW)
+                    *(f32x4*)(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) = x;
+            } else {
+                const int iw = rem / (2 * STH / 4), hh = 4 * (rem - iw * (2 * STH / 4));   // hh = 2*ih + kh
+                const int kw = ct & 1, cog = (ct >> 1) * 32 + co, ih = gh0 + (hh >> 1), iwg = gw0 + iw;
+                if (cog < A.Cout && ih < A.GH && iwg < A.GW)
+                    *(f32x4*)(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(2 * iwg + kw + 1) * A.out_hp + (2 * gh0 + hh + 1)) = x;
+            }
+        }
+    }
+}
+
+constexpr size_t conv6s_lds() { return (size_t)(2 * ASTS) * 16 + (size_t)2 * 3 * 2 * 2 * SNPX * 16; }
+
 template <int CFG> constexpr size_t conv6_lds() {
     return (size_t)(NABUF * AST + 2 * 3 * 2 * ((((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 1) + Cfg6<CFG>::TH + 2)) * 16;
 }
@@ -501,6 +690,70 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
                             packed[((base + 1) * 64 + lane) * 8 + j] = h1;
                             packed[((base + 2) * 64 + lane) * 8 + j] = h2;
                         }
+}
+
+// 2x2 / stride-2 layers: pre-split A fragments for k_conv6s
+//   uint4 index = ((((ct*nsteps + g)*2 + plane)*2 + m)*3 + split)*64 + lane, element j, k = 8*(lane>>5) + j
+//   DOWN (Conv2d OIHW):          row = ct*64 + m*32 + (lane&31) ; g = chunk*2 + kw ; plane = kh ; ci = chunk*16 + k
+//   UP   (ConvTranspose2d IOHW): ct = cob*2 + kw ; m = kh ; co = cob*32 + (lane&31) ; plane = slice ; ci = g*32 + slice*16 + k
+void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed) {
+    const bool up = (L.kind == CONV_UP);
+    L.nsteps6s = up ? (L.Cin + 31) / 32 : 2 * ((L.Cin + CK - 1) / CK);        // real steps
+    L.nchunk6 = ((L.nsteps6s + 2) / 3) * 3;                                   // padded with zero-weight steps to a multiple of 3
+    L.n_ct6 = up ? 2 * ((L.Cout + 31) / 32) : (L.Cout + 63) / 64;
+    packed.assign((size_t)L.n_ct6 * L.nchunk6 * ASTS * 8, 0);
+    for (int ct = 0; ct < L.n_ct6; ++ct)
+        for (int g = 0; g < L.nsteps6s; ++g)
+            for (int plane = 0; plane < 2; ++plane)
+                for (int m = 0; m < 2; ++m)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 8 * (lane >> 5) + j;
+                            float v;
+                            if (up) {
+                                const int kw = ct & 1, kh = m, co = (ct >> 1) * 32 + (lane & 31), ci = g * 32 + plane * 16 + k;
+                                if (co >= L.Cout || ci >= L.Cin) continue;
+                                v = w[(((size_t)ci * L.Cout + co) * 2 + kh) * 2 + kw];
+                            } else {
+                                const int kw = g & 1, kh = plane, row = ct * 64 + m * 32 + (lane & 31), ci = (g >> 1) * CK + k;
+                                if (row >= L.Cout || ci >= L.Cin) continue;
+                                v = w[(((size_t)row * L.Cin + ci) * 2 + kh) * 2 + kw];
+                            }
+                            const uint16_t h0 = host_bf16(v);
+                            const float r1 = v - host_bf16_to_f(h0);
+                            const uint16_t h1 = host_bf16(r1);
+                            const float r2 = r1 - host_bf16_to_f(h1);
+                            const uint16_t h2 = host_bf16(r2);
+                            const size_t base = ((((size_t)ct * L.nchunk6 + g) * 2 + plane) * 2 + m) * 3;
+                            packed[((base + 0) * 64 + lane) * 8 + j] = h0;
+                            packed[((base + 1) * 64 + lane) * 8 + j] = h1;
+                            packed[((base + 2) * 64 + lane) * 8 + j] = h2;
+                        }
+}
+
+// returns false if the layer/tensors do not meet the kernel's alignment assumptions (the f32 kernel then runs)
+bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out) {
+    if (!L.wp6 || (L.kind != CONV_DOWN && L.kind != CONV_UP)) return false;
+    if (in.h0 % 4 || in.hp % 4 || out.h0 % 4 || out.hp % 4) return false;
+    if (L.kind == CONV_DOWN) return in.H % 2 == 0 && in.W % 2 == 0 && (in.H / 2) % 4 == 0 && in.Cal >= (L.nsteps6s / 2) * CK;
+    return in.H % 2 == 0 && in.Cal >= L.nsteps6s * 32;
+}
+
+int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out) {
+    const bool up = (L.kind == CONV_UP);
+    Conv6sArgs A;
+    A.in = in.base1(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.base1();
+    A.Cout = L.Cout;
+    A.GH = up ? in.H : in.H / 2; A.GW = up ? in.W : in.W / 2;
+    A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
+    A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
+    A.nsteps = L.nchunk6; A.nsteps_real = L.nsteps6s; A.n_ct = L.n_ct6;
+    A.tiles_h = (A.GH + STH - 1) / STH; A.tiles_w = (A.GW + STW - 1) / STW;
+    const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;
+    if (up) k_conv6s<1><<<dim3(grid), dim3(NT6), conv6s_lds(), ctx->stream>>>(A);
+    else k_conv6s<0><<<dim3(grid), dim3(NT6), conv6s_lds(), ctx->stream>>>(A);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
 }
 
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,

@@ -129,7 +129,8 @@ struct ConvLayer {
     void* d_tab;             // tile table {cout tile, ow0, oh0, batch} for (tab_B, tab_MT)
     int tab_B, tab_MT;
     void* wp6 = nullptr;     // 3x3 layers: weights split into bf16 triples, MFMA A-fragment order (conv6_kernels.hip)
-    int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks, 64-row output tiles of wp6
+    int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks (2x2 layers: K steps), 64-row output tiles of wp6
+    int nsteps6s = 0;             // 2x2 layers: K steps that carry weights (nchunk6 is padded to a multiple of 3)
 };
 
 // activation tensor in HBM: [B][Cal][W+2][hp] fp32, h fastest, permanent zero halo, channels >= C are zero.
@@ -262,6 +263,9 @@ bool conv6_enabled();
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out);
+void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);   // 2x2 / stride-2 layers
+bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out);
+int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out);
 size_t conv_pack_weights(const ConvLayer& L, const float* w_src, std::vector<float>& packed);
 void conv_plan_layer(ConvLayer& L, ConvKind kind, int Cin, int Cout);
 
