@@ -766,10 +766,15 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     // once per tile (16 x 14 MB); instead keep the 256-pixel tile and split K over workgroups, then add the partial
     // outputs in slice order (deterministic) in a second, elementwise kernel.
     static const bool splitk_on = !(getenv("QMRI_CONV_SPLITK") && atoi(getenv("QMRI_CONV_SPLITK")) == 0);
-    if (splitk_on && in.H <= 32 && L.nchunk6 >= 16) {
+    static const int mid_cfg = getenv("QMRI_CONV_MIDCFG") ? atoi(getenv("QMRI_CONV_MIDCFG")) : 1;   // 56 x 56 level: tile config of the split-K variant (0, 1), 2 = no split
+    if (splitk_on && L.nchunk6 >= 16) {
+        // candidate: the 256-pixel tile (28 x 28 level) or the 128-pixel tile (56 x 56 level), K split so that about one
+        // workgroup per CU results and every workgroup still walks >= 4 chunks
+        const int cfg = (in.H <= 32) ? 0 : mid_cfg;
+        const long nt = (cfg == 0) ? ntiles(16, 16) : ntiles(16, 8);
         int ksplit = 1;
-        while (ksplit * 2 * ntiles(16, 16) <= 256 && L.nchunk6 % (ksplit * 2) == 0 && L.nchunk6 / (ksplit * 2) >= 4) ksplit *= 2;
-        if (ksplit > 1) {
+        while (cfg < 2 && ksplit * 2 * nt <= 256 && L.nchunk6 % (ksplit * 2) == 0 && L.nchunk6 / (ksplit * 2) >= 4) ksplit *= 2;
+        if (ksplit > 1 && in.H <= 64) {
             const long out_ks = (long)B * out.Cal * out.plane();
             const size_t need = (size_t)ksplit * out_ks + 8192;
             NetPlan& net = ctx->net;
@@ -778,7 +783,8 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
                 QMRI_HIP(ctx, hipMalloc((void**)&net.d_c6part, need * sizeof(float)));
                 net.c6part_floats = need;
             }
-            QMRI_TRY(launch6<0>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            if (cfg == 0) QMRI_TRY(launch6<0>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            else QMRI_TRY(launch6<1>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
             const long total = (long)B * L.Cout * in.H * in.W;
             k_conv6_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(
                 net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.base1(), add1 ? add1->base1() : nullptr, add2 ? add2->base1() : nullptr,
