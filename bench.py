@@ -35,6 +35,10 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16, 32 cycles)
 SPLIT_PRODUCTS = 6                    # bf16 x bf16 MFMA products per fp32-equivalent product (conv6_kernels.hip)
+# HBM-side bytes per launch of the dominant kernel at the 224 x 224 x 64 level, from two separate rocprofv3 --pmc passes
+# (FETCH_SIZE, WRITE_SIZE; profiles/r01_d_pmc_conv_traffic.txt): 33 073 KB + 11 956 KB, raw counters.  Algorithmic: input with
+# halo 16.3 MB + residual 12.8 MB (every second layer) + output 12.8 MB + weights 0.2 MB per XCD.
+CONV6_PMC_TRAFFIC_BYTES = (33073 + 11956) * 1024
 CONV3X3_FLOP = 2 * 64 * 64 * 9 * 224 * 224      # 3 699 376 128: identical at all four UNetRes levels
 DENOISER_FLOP = 213_253_619_712                 # SURVEY.md section 8d (10-channel UNetRes at 224 x 224)
 
@@ -178,7 +182,7 @@ def main():
                 ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
                 roof = {"kernel": "k_conv6 (implicit-GEMM conv3x3 on v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate)",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                        "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": CONV6_PMC_TRAFFIC_BYTES * B, "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches_timed": int(pr["n_conv3x3"]), "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B,
                         "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3), "fp32_equivalent_flop_per_launch": CONV3X3_FLOP * B}
         # stage split of one short run (profile level 1 synchronises per stage; not part of the timed region)
