@@ -63,6 +63,20 @@ def test_seq_conv_and_residual(engine_mod, oracle, synth):
     e.close()
 
 
+def test_seq_conv_odd_sizes(engine_mod, oracle, synth):
+    # extents that are no multiple of the 8 x 4 MFMA pixel block, of the tiles, or of 4 (scalar epilogue path)
+    nb, width = 3, 32
+    n = 32 * 10 * 9 + (nb - 2) * 32 * 32 * 9 + 10 * 32 * 9
+    w = ((synth.uniform01(7, n) - 0.5) * 0.2).astype(np.float32)
+    for H, W in ((30, 22), (17, 9), (36, 52)):
+        x = synth.uniform01(8, H * W * 10).reshape(H, W, 10)
+        e = engine_mod.Engine(0)
+        e.set_denoiser(w, H, W, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1, residual_noise=False)
+        net = oracle.Net(w, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1)
+        assert rel_err(e.denoise(x), net.denoise(x)) < 1e-5
+        e.close()
+
+
 def test_denoiser_errors(engine_mod, synth):
     e = engine_mod.Engine(0)
     with pytest.raises(engine_mod.QmriError):
