@@ -79,3 +79,47 @@ def test_direct_xupdate_vs_oracle(eng, case224):
     # and LSQR at tol 1e-4 lands within the stop-rule ambiguity of the exact minimiser
     xl, _, _ = eng.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
     assert rel_err(xl, xd) < 5e-4
+
+
+def test_lsqr_kspace_long_run_matches_closed_form(eng, case224):
+    # many iterations: the scalar recurrences that carry the never-sampled k locations must stay consistent with the
+    # vector iteration on the sampled ones; LSQR run to a tight tolerance must land on the exact minimiser
+    op, y = case224["op"], case224["y"]
+    x0 = 0.5 * op.adjoint(y)
+    z = 0.9 * op.adjoint(y)
+    xd = op.direct(y, z, 0.05)
+    xg, itg, flg = eng.xupdate(y, z, 0.05, 1e-13, 100, x0, solver="lsqr")
+    xo, ito, flo, _ = op.lsqr(y, z, 0.05, 1e-13, 100, x0)
+    assert (itg, flg) == (ito, flo)
+    assert rel_err(xg, xo) < 1e-9
+    assert rel_err(xg, xd) < 1e-7
+
+
+def test_lsqr_exact_start_and_zero_iterations(eng, case224):
+    op, y = case224["op"], case224["y"]
+    z = 0.9 * op.adjoint(y)
+    xd = op.direct(y, z, 0.05)
+    xg, itg, flg = eng.xupdate(y, z, 0.05, 1e-4, 100, xd, solver="lsqr")        # start at the minimiser: stops at once
+    xo, ito, flo, _ = op.lsqr(y, z, 0.05, 1e-4, 100, xd)
+    assert (itg, flg) == (ito, flo)
+    assert rel_err(xg, xd) < 1e-9
+    x0 = op.adjoint(y)
+    xg, itg, flg = eng.xupdate(y, z, 0.05, 1e-4, 0, x0, solver="lsqr")          # maxit = 0 returns x0
+    assert itg == 0 and rel_err(xg, x0) < 1e-12
+
+
+def test_lsqr_epi_mask_vs_oracle(engine_mod, oracle, case224):
+    # EPI: whole k-rows sampled in a few frames each -- a very different slot / work-unit structure from the spiral
+    fp, k = oracle.epi_mask(224, 224, 1 / 65, 200)
+    V = case224["dic"]["V"]
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, V, fp, k)
+    op = oracle.Operator(224, 224, V, fp, k)
+    y = op.forward(case224["X0"])
+    x0 = op.adjoint(y)
+    z = 0.8 * x0
+    xo, ito, flo, _ = op.lsqr(y, z, 0.05, 1e-4, 100, x0)
+    xg, itg, flg = e.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    assert (itg, flg) == (ito, flo)
+    assert rel_err(xg, xo) < 1e-10
+    e.close()
