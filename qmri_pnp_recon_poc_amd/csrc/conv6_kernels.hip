@@ -63,7 +63,8 @@ template <> struct Cfg6<2> {     // 64 px, waves = 2 cout halves x 2 pixel block
     static constexpr int TH = 8, TW = 8, MW = 1, NCT = 1;
     static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 0; pbw = 4 * (wave >> 1); m0 = wave & 1; }
 };
-constexpr int NABUF = 2;         // LDS buffers of A (one step each)
+constexpr int NABUF = 3;         // LDS buffers of A (one step each): step g lives in buffer g % 3 = its kh; a step's weights are complete one
+                                 // barrier before the step starts, so the MFMA waves can request its first fragments across that barrier
 
 #define C6_STAMP(role, k)                                                                        \
     do {                                                                                         \
@@ -209,34 +210,34 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 }                                                                                                \
             }                                                                                                    \
         }
-        // prologue: B(chunk 0) in three parts, A(0); then the requests for the stores of iterations 0 and 1
-        // (all of the first chunk is requested at once -- one memory latency, not three)
+        // prologue: all of B(chunk 0), A(0) and A(1); then the requests for the stores of iterations 0 and 1.
+        // (All of the first chunk is requested at once -- one memory latency, not three.)
         LOAD_A(0, ra0) LOAD_B(0, 0, rb0)
-        LOAD_A(0, ra1) LOAD_B(0, 1, rb1)
-        LOAD_A(0, ra2) LOAD_B(0, 2, rb2)
+        LOAD_A(1, ra1) LOAD_B(0, 1, rb1)
+        LOAD_A(1, ra2) LOAD_B(0, 2, rb2)
         gwait<2 * NLOAD>(ra0, rb0);
         STORE_A(0, ra0) STORE_B(0, 0, rb0)
         gwait<NLOAD>(ra1, rb1);
-        STORE_B(0, 1, rb1)
+        STORE_A(1, ra1) STORE_B(0, 1, rb1)
         gwait<0>(ra2, rb2);
         STORE_B(0, 2, rb2)
-        LOAD_A(1, ra1) LOAD_B(1, 0, rb1)                            // stored by iteration 0
-        LOAD_A(2, ra2) LOAD_B(1, 1, rb2)                            // stored by iteration 1
+        LOAD_A(2, ra1) LOAD_B(1, 0, rb1)                            // stored by iteration 0
+        LOAD_A(3, ra2) LOAD_B(1, 1, rb2)                            // stored by iteration 1
         C6_STAMP(1, 0);
         lds_barrier6();                                             // barrier 0: step 0 may start
-        // iteration g stores A(g+1) and part g%3 of B(g/3+1) from set (g+1)%3 and requests what iteration g+2 stores,
-        // A(g+3) and part (g+2)%3 of B((g+2)/3+1), into set g%3 (whose content iteration g-1 stored).  At the wait the
+        // iteration g stores A(g+2) and part g%3 of B(g/3+1) from set (g+1)%3 and requests what iteration g+2 stores,
+        // A(g+4) and part (g+2)%3 of B((g+2)/3+1), into set g%3 (whose content iteration g-1 stored).  At the wait the
         // requests of this and of the previous iteration may stay in flight: vmcnt(2*NLOAD).
 #define ITER(k_, rs_a, rs_b, rq_a, rq_b)   /* iteration g + k_, g = 3*c0 */                                       \
         {                                                                                                        \
             constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
             __builtin_amdgcn_s_setprio(2);         /* requests first ... */                                       \
-            LOAD_A(g + (k_) + 3, rq_a) LOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                       \
+            LOAD_A(g + (k_) + 4, rq_a) LOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                       \
             __builtin_amdgcn_s_setprio(0);         /* ... the split arithmetic only in the MFMA waves' issue gaps */ \
             C6_STAMP(2, g + (k_) + 1);                                                                           \
             gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
             C6_STAMP(3, g + (k_) + 1);                                                                           \
-            STORE_A(g + (k_) + 1, rs_a) STORE_B(c0 + 1, part_, rs_b)                                             \
+            STORE_A(g + (k_) + 2, rs_a) STORE_B(c0 + 1, part_, rs_b)                                             \
             C6_STAMP(1, g + (k_) + 1);                                                                           \
             lds_barrier6();                                                                                      \
         }
@@ -268,27 +269,30 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     if (A.stamps && tid == 0 && blockIdx.x == 0) { A.stamps[8192 + (A.launch_idx & 127) * 4] = wall_clock64(); A.stamps[8192 + (A.launch_idx & 127) * 4 + 3] = (unsigned long long)(CFG * 1000 + nsteps); }
     C6_STAMP(0, 0);
     lds_barrier6();                                                 // barrier 0
-    for (int g = 0; g < nsteps; ++g) {
-        const int c = g / 3, part = g - 3 * c;                      // part = kh ; the step's three taps are kw = 0, 1, 2
-        const uint4* ab = Abuf + (g % NABUF) * AST + lane;
-        const uint4* bb = Bbuf + (c & 1) * (3 * 2 * NPX) + h2 * NPX + pxl + part;
-        // fragments of tap t+1 are requested before the MFMAs of tap t (register double buffer)
+    for (int c = 0; c < A.nchunk; ++c) {
+        // One chunk = 9 taps = 3 steps (kh = 0, 1, 2; a step's taps are kw = 0, 1, 2), fully unrolled.  Fragments of tap T+1
+        // are requested before the MFMAs of tap T (register double buffer, alternating with T) -- also across the two
+        // barriers inside the chunk: the next step's weights were published one barrier earlier (three A buffers) and the
+        // chunk's activations are complete.  Only the chunk's first tap waits for its fragments after a barrier.
+        const uint4* ab = Abuf + lane;
+        const uint4* bb = Bbuf + (c & 1) * (3 * 2 * NPX) + h2 * NPX + pxl;
         bf16x8 bf[2][NCT][3], af[2][MW][3];
-        auto frags = [&](int t, int set) __attribute__((always_inline)) {
+        auto frags = [&](int T, int set) __attribute__((always_inline)) {
+            const int kh = T / 3, kw = T - 3 * kh;
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) bf[set][n][sp] = __builtin_bit_cast(bf16x8, bb[sp * 2 * NPX + t * IHP + 8 * n]);
+                for (int sp = 0; sp < 3; ++sp) bf[set][n][sp] = __builtin_bit_cast(bf16x8, bb[sp * 2 * NPX + kw * IHP + kh + 8 * n]);
 #pragma unroll
             for (int m = 0; m < MW; ++m)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) af[set][m][sp] = __builtin_bit_cast(bf16x8, ab[((t * 2 + (m0 + m)) * 3 + sp) * 64]);
+                for (int sp = 0; sp < 3; ++sp) af[set][m][sp] = __builtin_bit_cast(bf16x8, ab[kh * AST + ((kw * 2 + (m0 + m)) * 3 + sp) * 64]);
         };
         frags(0, 0);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int cur = t & 1;
-            if (t < 2) frags(t + 1, cur ^ 1);
+        for (int T = 0; T < 9; ++T) {
+            const int cur = T & 1;
+            if (T < 8) frags(T + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);              // keep the requests above the MFMAs they overlap with
 #pragma unroll
             for (int m = 0; m < MW; ++m)
@@ -303,11 +307,14 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                     a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][0], a_, 0, 0, 0);
                     acc[m][n] = a_;
                 }
+            if (T % 3 == 2) {
+                const int g = 3 * c + T / 3;
+                C6_STAMP(0, g + 1);
+                if (A.stamps && A.detail && tid == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && g + 65 < 128)
+                    A.stamps[((blockIdx.x / 13) * 4 + 0) * 128 + g + 65] = __builtin_readcyclecounter();
+                lds_barrier6();                                     // barrier g+1
+            }
         }
-        C6_STAMP(0, g + 1);
-        if (A.stamps && A.detail && tid == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && g + 65 < 128)
-            A.stamps[((blockIdx.x / 13) * 4 + 0) * 128 + g + 65] = __builtin_readcyclecounter();
-        lds_barrier6();                                             // barrier g+1
     }
     C6_STAMP(0, nsteps + 1);
     if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 1] = wall_clock64();
