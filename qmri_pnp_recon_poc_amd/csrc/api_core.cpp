@@ -71,7 +71,7 @@ void qmri_free_operator(qmri_ctx* ctx) {
     OpHost& o = ctx->op;
     void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
                      o.ls.st, o.ls.pz, o.ls.yk,
-                     (void*)o.ks.bslot, (void*)o.ks.sptr, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.gptr, (void*)o.ks.sgrp,
+                     (void*)o.ks.unit, (void*)o.ks.bslot, (void*)o.ks.sptr, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.gptr, (void*)o.ks.sgrp,
                      o.ks.pu[0], o.ks.pu[1], o.ks.pv[0], o.ks.pv[1], o.ks.pinit, o.ks.pR, o.ks.cx, o.ks.cv, o.ks.cd, o.ks.cub,
                      o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.stamps,
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
@@ -320,7 +320,9 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
             qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
             return QMRI_ERR_UNSUPPORTED;
         }
-        int32_t* p32; KSample* pes; KsGroup* pg;
+        std::vector<KsUnit> units(ks.G);
+        for (int g = 0; g < ks.G; ++g) units[g] = KsUnit{bslot[g], bslot[g + 1], sptr[bslot[g]], sptr[bslot[g + 1]], gptr[g], gptr[g + 1], 0, 0};
+        int32_t* p32; KSample* pes; KsGroup* pg; KsUnit* pu_;
 #define KS_UPLOAD(ptr, field, vec, T_)                                                                 \
         QMRI_TRY(dev_alloc(ctx, &ptr, (vec).size()));                                                  \
         QMRI_HIP(ctx, hipMemcpy(ptr, (vec).data(), (vec).size() * sizeof(T_), hipMemcpyHostToDevice)); \
@@ -331,6 +333,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         KS_UPLOAD(p32, sgrp, sgrp, int32_t)
         KS_UPLOAD(pes, es, es, KSample)
         KS_UPLOAD(pg, grp, grp, KsGroup)
+        KS_UPLOAD(pu_, unit, units, KsUnit)
 #undef KS_UPLOAD
         ctx->ks_lds_attr[0] = ctx->ks_lds_attr[1] = false;
     }
@@ -531,7 +534,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         worst = std::max(worst, it);
         ctx->prof.lsqr_iters += it;
     }
-    ctx->lsqr_pred = worst + 2;      // convergence is detected one iteration after the last x update; +1 margin
+    ctx->lsqr_pred = worst + 1;      // convergence is detected one iteration after the last x update; counts fall from one x-update to the next
     return QMRI_OK;
 }
 

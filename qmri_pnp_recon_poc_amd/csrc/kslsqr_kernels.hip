@@ -128,8 +128,9 @@ __global__ __launch_bounds__(KT, 2) void k_ks_a(OpDev op, KsDev ks) {
     LsqrState* st = ks.st + b;
     KS_STAMP(0, 0);
     const int done = st->done;
-    const int s0 = ks.bslot[g], s1 = ks.bslot[g + 1], ne = (s1 - s0) * s;
-    const int e0 = ks.sptr[s0], nsamp = ks.sptr[s1] - e0;
+    const KsUnit un = ks.unit[g];                                   // (one scalar load instead of a chain of dependent ones)
+    const int s0 = un.s0, s1 = un.s1, ne = (s1 - s0) * s;
+    const int e0 = un.e0, nsamp = un.e1 - e0;
     const size_t cb = ((size_t)b * ks.ns + s0) * s, mb = (size_t)b * op.m + e0;
     double2 rcv[NEQ], rub[NEQ];
 #pragma unroll
@@ -212,9 +213,10 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
     LsqrState* st = ks.st + b;
     KS_STAMP(1, 0);
     const int done = INIT ? 0 : st->done;
-    const int s0 = ks.bslot[g], s1 = ks.bslot[g + 1], nsl = s1 - s0, ne = nsl * s;
-    const int e0 = ks.sptr[s0], nsamp = ks.sptr[s1] - e0;
-    const int g0 = ks.gptr[g], ng = ks.gptr[g + 1] - g0;
+    const KsUnit un = ks.unit[g];
+    const int s0 = un.s0, s1 = un.s1, nsl = s1 - s0, ne = nsl * s;
+    const int e0 = un.e0, nsamp = un.e1 - e0;
+    const int g0 = un.g0, ng = un.g1 - g0;
     const size_t cb = ((size_t)b * ks.ns + s0) * s, mb = (size_t)b * op.m + e0;
     double2 rcv[NEQ], rub[NEQ], rd[NEQ], rx[NEQ];
 #pragma unroll

@@ -67,9 +67,11 @@ struct KsGroup { uint16_t ls, b, e, pad; };      // <= DC_GCAP samples of one sl
 constexpr int KS_SCAP = 64;                      // slots per block
 constexpr int KS_ECAP = 1024;                    // samples per block
 constexpr int KS_GCAPB = 96;                     // groups per block  (>= KS_ECAP / DC_GCAP + KS_SCAP)
+struct KsUnit { int32_t s0, s1, e0, e1, g0, g1, pad0, pad1; };   // a work unit: its slots, samples and groups (one 32-byte scalar load)
 struct LsqrState;
 struct KsDev {
     int ns, G;                                   // sampled k locations; blocks of the iteration kernels
+    const KsUnit* unit;                          // [G]    slot / sample / group ranges of each block
     const int32_t* bslot;                        // [G+1]  first slot of each block
     const int32_t* sptr;                         // [ns+1] first sample of each slot (k-sorted sample order)
     const KSample* es;                           // [m]
