@@ -166,6 +166,12 @@ typedef struct {
 int qmri_profile_enable(qmri_ctx* ctx, int level);   /* 0 off, 1 per stage, 2 also per conv3x3 launch */
 int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset);
 
+/* Diagnostics (no counterpart in the reference): in-kernel 100 MHz phase stamps, recorded only when the library was
+ * started with QMRI_LSQR_STAMPS=1 / QMRI_CONV_STAMPS=1 (otherwise QMRI_ERR_STATE).  `out` receives 2*512*16 and 4096*11
+ * 64-bit values; layouts are those read by tools/lsqr_stamps.py and tools/conv6_stamps.py. */
+int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out);
+int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int reserved);
+
 #ifdef __cplusplus
 }
 #endif

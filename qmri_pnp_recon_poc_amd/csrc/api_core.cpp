@@ -71,7 +71,7 @@ void qmri_free_operator(qmri_ctx* ctx) {
     OpHost& o = ctx->op;
     void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
                      o.ls.st, o.ls.pz, o.ls.yk,
-                     (void*)o.ks.unit, (void*)o.ks.bslot, (void*)o.ks.sptr, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.gptr, (void*)o.ks.sgrp,
+                     (void*)o.ks.unit, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.sgrp,
                      o.ks.pu[0], o.ks.pu[1], o.ks.pv[0], o.ks.pv[1], o.ks.pinit, o.ks.pR, o.ks.cx, o.ks.cv, o.ks.cd, o.ks.cub,
                      o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.stamps,
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
@@ -327,9 +327,6 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         QMRI_TRY(dev_alloc(ctx, &ptr, (vec).size()));                                                  \
         QMRI_HIP(ctx, hipMemcpy(ptr, (vec).data(), (vec).size() * sizeof(T_), hipMemcpyHostToDevice)); \
         ks.field = ptr;
-        KS_UPLOAD(p32, bslot, bslot, int32_t)
-        KS_UPLOAD(p32, sptr, sptr, int32_t)
-        KS_UPLOAD(p32, gptr, gptr, int32_t)
         KS_UPLOAD(p32, sgrp, sgrp, int32_t)
         KS_UPLOAD(pes, es, es, KSample)
         KS_UPLOAD(pg, grp, grp, KsGroup)

@@ -33,13 +33,6 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return r;
 }
 
-// fixed-order reduction of a partial-sum array by a whole block (every block gets the same bits)
-__device__ __forceinline__ double reduce_array(const double* __restrict__ p, int n, double* sh) {
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) a += p[i];
-    return block_sum(a, sh);
-}
-
 // Two-step FFT of `nlines` lines held in LDS (natural order, pitch LINE).  On return thread (line2,k1) holds
 // X[k1 + R1*k2] in out[k2].  LINE_FAST selects the step-2 thread layout: line fastest or k1 fastest.
 template <int R1, int R2, bool LINE_FAST>

@@ -72,11 +72,8 @@ struct LsqrState;
 struct KsDev {
     int ns, G;                                   // sampled k locations; blocks of the iteration kernels
     const KsUnit* unit;                          // [G]    slot / sample / group ranges of each block
-    const int32_t* bslot;                        // [G+1]  first slot of each block
-    const int32_t* sptr;                         // [ns+1] first sample of each slot (k-sorted sample order)
     const KSample* es;                           // [m]
     const KsGroup* grp;                          // scatter groups, block after block
-    const int32_t* gptr;                         // [G+1]  first group of each block
     const int32_t* sgrp;                         // [ns+1] first group of each slot
     LsqrState* st;                               // [B]
     double* pu[2];                               // [B][2G] partial |u|^2 (image part, then samples), by iteration parity
