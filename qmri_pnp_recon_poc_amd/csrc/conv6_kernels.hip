@@ -154,7 +154,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         __builtin_amdgcn_s_setprio(2);                             // requests first: the MFMA waves have work queued anyway
         const uint4* wsrc = A.wp + ((size_t)ct * A.nchunk_all + (size_t)ks * A.nchunk) * 3 * AST;   // steps of a cout tile are contiguous
         const float* isrc = A.in + (size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0;   // halo origin = padded (oh0, ow0)
-        unsigned aoff[NAQ], boff[3][8];                            // loop-invariant byte offsets of this thread's requests
+        unsigned aoff[NAQ], boff[3];                               // loop-invariant byte offsets of this thread's requests (B: channel 0 of its 8)
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
 #pragma unroll
@@ -163,8 +163,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             if (item >= NBI) item = 0;
             const int h2 = item / NLP, px = item - h2 * NLP;
             const int dw = px / IH, dh = px - dw * IH;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) boff[part][j] = (unsigned)((((size_t)(h2 * 8 + j)) * A.in_plane + dw * A.in_hp + dh) * 4);
+            boff[part] = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
         }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
         float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
@@ -187,7 +186,8 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         {                                                                                                        \
             const int cc = ((c_) < A.nchunk) ? (c_) : A.nchunk - 1;                                              \
             const float* bs_ = uniform_ptr(isrc + (size_t)cc * CK * A.in_plane);                                 \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) gload1(rb_[0][j], boff[part_][j], bs_);                \
+            /* the 8 channels differ by a plane: the step goes into the scalar base, not into 8 more offset registers */ \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) gload1(rb_[0][j], boff[part_], uniform_ptr(bs_ + (size_t)j * A.in_plane)); \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
         {                                                                                                        \
