@@ -60,51 +60,75 @@ __device__ __forceinline__ void store_v(const OpDev& op, const double* rv, doubl
 // k_ks_init_a : one block per k-row kh.  xhat0 / zhat rows -> compact x, u(m+1:end) on the sampled k; R on the rest;
 // u(1:m) = y - P xhat0 for the row's samples.
 // ---------------------------------------------------------------------------------------------------------------
+template <int N>
 __global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, kh = blockIdx.x, b = blockIdx.y, s = op.s, N = op.N, M = op.M, sM = s * M;
+    constexpr int M = N;                                   // square grids only (checked by qmri_set_operator)
+    const int tid = threadIdx.x, kh = blockIdx.x, b = blockIdx.y, s = op.s, sM = s * M;
     cd* lines = (cd*)smem;                                 // [c][kw] xhat0 of the row
     double* vlds = (double*)(lines + sM);
     __shared__ double red[3 * KT / 64];
     const size_t n = (size_t)s * N * M;
     const double sr = ks.sr;
+    // ---- request everything (clamped, not predicated): one memory latency for the whole row
+    constexpr int NQ = (DC_MAXS * N + KT - 1) / KT, NE = 4;
+    double2 xv[NQ], zv[NQ];
+    int slot[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = (tid + KT * q < sM) ? tid + KT * q : sM - 1;
+        const int c = i / M, kw = i - c * M;
+        const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
+        xv[q] = ks.xhat[g]; zv[q] = ks.zhat[g];
+        slot[q] = op.kslot[kh * M + kw];
+    }
+    const int r0 = op.kptr[kh * M], r1 = op.kptr[(kh + 1) * M];
+    const size_t mb = (size_t)b * op.m;
+    KEntry en[NE];
+    double2 yv[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = (r0 + tid + KT * q < r1) ? r0 + tid + KT * q : ((r1 > r0) ? r1 - 1 : 0);
+        en[q] = op.ent[e]; yv[q] = ks.yk[mb + e];
+    }
     double rv[NVQ];
     load_v(op, rv);
     double accS = 0.0, accR = 0.0;
-    for (int i = tid; i < sM; i += KT) {
-        const int c = i / M, kw = i - c * M;
-        const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
-        const double2 xv = ks.xhat[g], zv = ks.zhat[g];
-        lines[i] = xv;
-        const int slot = op.kslot[kh * M + kw];
-        if (slot >= 0) {
-            const size_t ci = ((size_t)b * ks.ns + slot) * s + c;
-            const double2 ub = make_double2(zv.x * sr - xv.x * sr, zv.y * sr - xv.y * sr);   // sqrt(r) z - sqrt(r) x0
-            ks.cx[ci] = xv;
-            ks.cub[ci] = ub;
-            accS += ub.x * ub.x + ub.y * ub.y;
-        } else {
-            const double dx = zv.x - xv.x, dy = zv.y - xv.y;
-            accR += dx * dx + dy * dy;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + KT * q;
+        if (i < sM) {
+            const int c = i / M;
+            lines[i] = xv[q];
+            if (slot[q] >= 0) {
+                const size_t ci = ((size_t)b * ks.ns + slot[q]) * s + c;
+                const double2 ub = make_double2(zv[q].x * sr - xv[q].x * sr, zv[q].y * sr - xv[q].y * sr);   // sqrt(r) z - sqrt(r) x0
+                ks.cx[ci] = xv[q];
+                ks.cub[ci] = ub;
+                accS += ub.x * ub.x + ub.y * ub.y;
+            } else {
+                const double dx = zv[q].x - xv[q].x, dy = zv[q].y - xv[q].y;
+                accR += dx * dx + dy * dy;
+            }
         }
     }
     store_v(op, rv, vlds);
     lds_barrier();
-    const size_t mb = (size_t)b * op.m;
     double accT = 0.0;
-    for (int e = op.kptr[kh * M] + tid; e < op.kptr[(kh + 1) * M]; e += KT) {
-        const KEntry en = op.ent[e];
+    auto sample = [&](int e, const KEntry k, const double2 y) {
         double re = 0.0, im = 0.0;
         for (int c = 0; c < s; ++c) {
-            const double v = vlds[en.t * s + c];
-            const cd X = lines[c * M + en.kw];
+            const double v = vlds[k.t * s + c];
+            const cd X = lines[c * M + k.kw];
             re += v * X.x; im += v * X.y;
         }
-        const double2 yv = ks.yk[mb + e];
-        const double2 u = make_double2(yv.x - re, yv.y - im);   // u(1:m) = y - A x0
+        const double2 u = make_double2(y.x - re, y.y - im);     // u(1:m) = y - A x0
         ks.ut[mb + e] = u;
         accT += u.x * u.x + u.y * u.y;
-    }
+    };
+#pragma unroll
+    for (int q = 0; q < NE; ++q) { const int e = r0 + tid + KT * q; if (e < r1) sample(e, en[q], yv[q]); }
+    for (int e = r0 + tid + KT * NE; e < r1; e += KT) sample(e, op.ent[e], ks.yk[mb + e]);
     block_sum2(accS, accT, red);
     const double r = block_sum(accR, red);
     if (tid == 0) {
@@ -417,19 +441,34 @@ __global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* 
     const double ue = ks.st[b].ue_final;
     double rv[NVQ];
     load_v(op, rv);
-    for (int i = tid; i < sM; i += KT) {
+    // ---- request everything (clamped, not predicated): the slots first, then the compact x / the two spectra
+    constexpr int NQ = (DC_MAXS * N + KT - 1) / KT;
+    int slot[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = (tid + KT * q < sM) ? tid + KT * q : sM - 1;
+        slot[q] = op.kslot[kh * M + (i - (i / M) * M)];
+    }
+    double2 cxv[NQ], xv[NQ], zv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = (tid + KT * q < sM) ? tid + KT * q : sM - 1;
         const int c = i / M, kw = i - c * M;
         const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
-        const int slot = op.kslot[kh * M + kw];
-        double2 val;
-        if (slot >= 0) {
-            val = ks.cx[((size_t)b * ks.ns + slot) * s + c];
-        } else {
-            const double2 xv = ks.xhat[g], zv = ks.zhat[g];
-            val = make_double2(xv.x + ue * (zv.x - xv.x), xv.y + ue * (zv.y - xv.y));
+        cxv[q] = ks.cx[((size_t)b * ks.ns + ((slot[q] >= 0) ? slot[q] : 0)) * s + c];
+        xv[q] = ks.xhat[g]; zv[q] = ks.zhat[g];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + KT * q;
+        if (i < sM) {
+            const int c = i / M, kw = i - c * M;
+            const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
+            const double2 val = (slot[q] >= 0) ? cxv[q]
+                                               : make_double2(xv[q].x + ue * (zv[q].x - xv[q].x), xv[q].y + ue * (zv[q].y - xv[q].y));
+            ks.xhat[g] = val;
+            lds[c * P::LINE + kw] = val;
         }
-        ks.xhat[g] = val;
-        lds[c * P::LINE + kw] = val;
     }
     store_v(op, rv, vlds);
     lds_barrier();
@@ -483,7 +522,10 @@ int launch_final_t(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, doubl
 
 static int ks_attrs(qmri_ctx* ctx) {
     if (ctx->ks_lds_attr[0]) return QMRI_OK;
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<224>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<128>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<64>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<32>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_a));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<true>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<false>));
@@ -495,7 +537,13 @@ static int ks_attrs(qmri_ctx* ctx) {
 int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
     QMRI_TRY(ks_attrs(ctx));
     const size_t vb = (size_t)ks.vcap * 8;
-    k_ks_init_a<<<dim3(op.N, B), dim3(KT), (size_t)op.s * op.M * 16 + vb, ctx->stream>>>(op, ks);
+    const size_t ib = (size_t)op.s * op.M * 16 + vb;
+    switch (op.N) {
+        case 224: k_ks_init_a<224><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
+        case 128: k_ks_init_a<128><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
+        case 64: k_ks_init_a<64><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
+        default: k_ks_init_a<32><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
+    }
     k_ks_b<true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
