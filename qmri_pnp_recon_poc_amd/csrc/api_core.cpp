@@ -73,7 +73,7 @@ void qmri_free_operator(qmri_ctx* ctx) {
                      o.ls.st, o.ls.pz, o.ls.yk,
                      (void*)o.ks.unit, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.sgrp,
                      o.ks.pu[0], o.ks.pu[1], o.ks.pv[0], o.ks.pv[1], o.ks.pinit, o.ks.pR, o.ks.cx, o.ks.cv, o.ks.cd, o.ks.cub,
-                     o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.stamps,
+                     o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.xhat_out, o.ks.stamps,
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
     for (void* p : ptrs) free_dev(p);
     if (o.h_state) (void)hipHostFree(o.h_state);
@@ -91,6 +91,7 @@ extern "C" int qmri_destroy(qmri_ctx* ctx) {
     qmri_free_net(ctx);
     qmri_free_dict(ctx);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_state) (void)hipEventDestroy(ctx->ev_state);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return QMRI_OK;
@@ -354,6 +355,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &ks.ut, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &ks.xhat, B * n));
     QMRI_TRY(dev_alloc(ctx, &ks.zhat, B * n));
+    QMRI_TRY(dev_alloc(ctx, &ks.xhat_out, B * n));
     ks.stamps = nullptr;
     if (const char* e = getenv("QMRI_LSQR_STAMPS")) {
         if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ks.stamps, (size_t)2 * 512 * 16)); QMRI_HIP(ctx, hipMemset(ks.stamps, 0, 2 * 512 * 16 * 8)); }
@@ -500,29 +502,32 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     if (!o.xhat_valid) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_x, o.d_tmp, ks.xhat, nullptr));
     QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_z, o.d_tmp, ks.zhat, nullptr));
     QMRI_TRY(ks_launch_init(ctx, op, ks, B));
+    // The predicted number of iterations is launched, then -- speculatively -- the kernels that turn the solution back into
+    // an image.  The host waits only for the copy of the LSQR state (an event between the two), so the device keeps working
+    // while the host wakes up and enqueues the next stage.  If a slice was not done yet (rare: counts fall from one x-update
+    // to the next), two more iterations at a time follow and the final kernels run again from the untouched inputs.
+    if (!ctx->ev_state) QMRI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_state, hipEventDisableTiming));
     int launched = 0;
     int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
     bool all_done = false;
-    while (launched < maxit && !all_done) {
+    do {
         const int nthis = std::min(chunk, maxit - launched);
         for (int k = 0; k < nthis; ++k) {
             ks.ii = launched + k + 1;
             QMRI_TRY(ks_launch_iter(ctx, op, ks, B));
         }
-        launched += nthis;
+        launched += std::max(nthis, 0);
         QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ks.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
-        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        QMRI_HIP(ctx, hipEventRecord(ctx->ev_state, ctx->stream));
+        QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));              // reads ks.xhat (x0), writes ks.xhat_out
+        QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
+        QMRI_HIP(ctx, hipEventSynchronize(ctx->ev_state));
         all_done = true;
         for (int b = 0; b < B; ++b) all_done = all_done && o.h_state[b].done;
         chunk = 2;
-    }
-    QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));
-    QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
+    } while (launched < maxit && !all_done);
+    std::swap(o.ks.xhat, o.ks.xhat_out);                                  // the assembled spectrum is the next solve's xhat0
     o.xhat_valid = true;
-    if (maxit <= 0) {
-        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ks.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
-        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
     int worst = 0;
     for (int b = 0; b < B; ++b) {
         const int it = o.h_state[b].done ? o.h_state[b].iter : maxit;

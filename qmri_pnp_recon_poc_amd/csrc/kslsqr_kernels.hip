@@ -425,7 +425,8 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_ks_final_w : one block per k-row kh.  Assemble xhat (kept for the next x-update's warm start), ||y - P xhat||^2 of the
+// k_ks_final_w : one block per k-row kh.  Assemble xhat_out (the next x-update's xhat0; xhat itself stays untouched so the
+// kernel can be re-run), ||y - P xhat||^2 of the
 // row's samples (PnP_ADMM.m:106), then the conj-domain inverse w-pass into tmp (k_adj_h finishes the transform).
 // ---------------------------------------------------------------------------------------------------------------
 template <int R1, int R2>
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* 
             const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
             const double2 val = (slot[q] >= 0) ? cxv[q]
                                                : make_double2(xv[q].x + ue * (zv[q].x - xv[q].x), xv[q].y + ue * (zv[q].y - xv[q].y));
-            ks.xhat[g] = val;
+            ks.xhat_out[g] = val;
             lds[c * P::LINE + kw] = val;
         }
     }

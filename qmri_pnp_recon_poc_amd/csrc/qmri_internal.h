@@ -84,6 +84,7 @@ struct KsDev {
     double2* cx; double2* cv; double2* cd; double2* cub;   // [B][ns*s] x, v (not normalised), d, u(m+1:end) on the sampled k
     double2* ut; const double2* yk;              // [B][m]
     double2* xhat; double2* zhat;                // [B][n] unitary spectra, layout [c][kh][kw]
+    double2* xhat_out;                           // [B][n] assembled solution spectrum (becomes xhat of the next solve)
     double* pdiag;                               // [B][N] partial ||y - A x||^2 or null
     double sr, tol;
     int maxit, ii, vcap;
@@ -214,6 +215,7 @@ struct qmri_ctx {
     int prof_level = 0;
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_state = nullptr;      // LSQR state copied to the host
     bool conv6_attr[3] = {false, false, false};   // dynamic LDS size of k_conv6 allowed
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
