@@ -348,7 +348,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     for (int it = 0; it < prm->iters; ++it) {
         // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
         tm.start();
-        QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, B, o.d_vv, o.d_u, o.d_z));
+        if (it == 0) QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, B, o.d_vv, o.d_u, o.d_z));   // later: fused into the dual update
         if (prm->solver == QMRI_SOLVER_LSQR) {
             QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr,
                                    diag ? o.d_pd : nullptr));          // (the data-fidelity partials come with the solve)
@@ -374,7 +374,8 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
         tm.start();
-        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.d_vv));
+        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.d_vv,
+                                            o.d_z, o.ls.pz, o.ls.nblk_z));
         tm.stop(ctx->prof.ms_elementwise);
         ctx->prof.admm_iters += 1;
     }

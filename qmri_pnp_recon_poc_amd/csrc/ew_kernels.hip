@@ -96,28 +96,50 @@ __global__ __launch_bounds__(NT) void k_normalise(size_t n, int plane, int H, in
     }
 }
 
-// v = double(I)*range + min ;  uold = uold + x - v     (I = CNN output, or input - CNN output)
+// v = double(I)*range + min ;  uold = uold + x - v     (I = CNN output, or input - CNN output)      PnP_ADMM.m:138,144
+// and, for the next iteration's x-update, z = v - uold with the partial sums of ||z||^2 (PnP_ADMM.m:102) -- the same
+// partition and summation order as k_prepare_z, which only the first iteration still needs.
 __global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, int plane, int H, int php, int pplane, size_t out_bs,
                                                           size_t in_bs, const float* __restrict__ out32,
                                                           const float* __restrict__ in32, int residual_noise,
                                                           const double* __restrict__ norm, const double2* __restrict__ x,
-                                                          double2* __restrict__ u, double2* __restrict__ v) {
+                                                          double2* __restrict__ u, double2* __restrict__ v,
+                                                          double2* __restrict__ z, double* __restrict__ pz) {
+    __shared__ double red[NT / 64];
     const int b = blockIdx.y;
     const double lo = norm[2 * b], range = norm[2 * b + 1];
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
-    const int w = rem / H, h = rem - w * H;
-    const size_t pi = (size_t)c * pplane + (size_t)(w + 1) * php + h + 1;
-    float I = out32[(size_t)b * out_bs + pi];
-    if (residual_noise) I = in32[(size_t)b * in_bs + pi] - I;
-    const double vv = (double)I * range + lo;
-    const double2 xv = x[(size_t)b * n + i];
-    double2 uv = u[(size_t)b * n + i];
-    uv.x = uv.x + xv.x - vv;
-    uv.y = uv.y + xv.y - 0.0;
-    u[(size_t)b * n + i] = uv;
-    v[(size_t)b * n + i] = make_double2(vv, 0.0);
+    const size_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const size_t i0 = (size_t)blockIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    double acc = 0.0;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += NT) {
+        const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
+        const int w = rem / H, h = rem - w * H;
+        const size_t pi = (size_t)c * pplane + (size_t)(w + 1) * php + h + 1;
+        float I = out32[(size_t)b * out_bs + pi];
+        if (residual_noise) I = in32[(size_t)b * in_bs + pi] - I;
+        const double vv = (double)I * range + lo;
+        const double2 xv = x[(size_t)b * n + i];
+        double2 uv = u[(size_t)b * n + i];
+        uv.x = uv.x + xv.x - vv;
+        uv.y = uv.y + xv.y - 0.0;
+        u[(size_t)b * n + i] = uv;
+        v[(size_t)b * n + i] = make_double2(vv, 0.0);
+        const double2 zz = make_double2(vv - uv.x, 0.0 - uv.y);
+        z[(size_t)b * n + i] = zz;
+        acc += zz.x * zz.x + zz.y * zz.y;
+    }
+    // block total in the order of dc_kernels.hip's block_sum (shuffle tree, then the waves in order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += red[i];
+        pz[(size_t)b * gridDim.x + blockIdx.x] = r;
+    }
 }
 
 // ||gt - x||^2 partials, then the final diagnostics for this ADMM iteration
@@ -205,10 +227,11 @@ int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H,
 }
 
 int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H, const PTensor& out32, const PTensor& in32,
-                               int residual_noise, const double* norm, const double2* x, double2* u, double2* v) {
-    k_unnormalise_dual<<<dim3((unsigned)((n + NT - 1) / NT), B), dim3(NT), 0, ctx->stream>>>(
+                               int residual_noise, const double* norm, const double2* x, double2* u, double2* v, double2* z,
+                               double* pz, int nblk_z) {
+    k_unnormalise_dual<<<dim3(nblk_z, B), dim3(NT), 0, ctx->stream>>>(
         n, plane, H, out32.hp, (int)out32.plane(), out32.batch_stride(), in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, norm,
-        x, u, v);
+        x, u, v, z, pz);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }

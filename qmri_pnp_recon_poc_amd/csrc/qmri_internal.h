@@ -247,7 +247,8 @@ int dc_launch_prepare_z(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B
 int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H, int s, int multi_level, double noise_std,
                                const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32);
 int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H, const PTensor& out32, const PTensor& in32,
-                               int residual_noise, const double* norm, const double2* x, double2* u, double2* v);
+                               int residual_noise, const double* norm, const double2* x, double2* u, double2* v, double2* z,
+                               double* pz, int nblk_z);   // also z = v - u and the partials of ||z||^2 for the next x-update
 int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* x, const double2* gt,
                    double* pd, double* diag_slot, int iters_total, int it);
 int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst);
