@@ -767,8 +767,10 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
                  const PTensor* add2, int relu_out) {
     // the largest pixel tile that still gives most CUs a workgroup (one workgroup per CU is the design point)
     auto ntiles = [&](int th, int tw) { return (long)L.n_ct6 * ((in.H + th - 1) / th) * ((in.W + tw - 1) / tw) * B; };
-    if (in.H % 16 == 0 && in.W % 16 == 0 && ntiles(16, 16) >= 160) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
-    if (in.H % 16 == 0 && ntiles(16, 8) >= 160) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
+    // (tiles may overhang the image -- the kernel masks its stores -- as long as the padded area stays below 1.35 x the image)
+    auto waste = [&](int th, int tw) { return (double)(((in.H + th - 1) / th) * th) * (((in.W + tw - 1) / tw) * tw) / ((double)in.H * in.W); };
+    if (ntiles(16, 16) >= 160 && waste(16, 16) <= 1.35) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
+    if (ntiles(16, 8) >= 160 && waste(16, 8) <= 1.35) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
     // Small feature maps with many channels (the 28 x 28 x 512 level): a 64-pixel tile would re-read the layer's weights
     // once per tile (16 x 14 MB); instead keep the 256-pixel tile and split K over workgroups, then add the partial
     // outputs in slice order (deterministic) in a second, elementwise kernel.
