@@ -50,6 +50,20 @@ def test_full_unetres_224_vs_golden_and_batch(engine_mod, synth):
     e.close()
 
 
+def test_full_unetres_224_batch_of_five(engine_mod, synth):
+    # five slices per forward change the tile choice of the small levels (large overhanging tiles instead of split-K):
+    # every slice of the batch must reproduce its own single-slice result
+    w = synth.structured_weights(seed=2, eps=0.02)
+    xs = [synth.uniform01(9100 + i, 10 * 224 * 224).astype(np.float32).reshape(10, 224, 224).transpose(1, 2, 0).astype(np.float64)
+          for i in range(5)]
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 224, 224, max_batch=5)
+    yb = e.denoise(np.stack(xs, axis=3))
+    for i in (0, 2, 4):
+        assert rel_err(yb[..., i], e.denoise(xs[i])) < 2e-6          # same arithmetic, different summation split at two levels
+    e.close()
+
+
 def test_seq_conv_and_residual(engine_mod, oracle, synth):
     # DnCNN-style stack with residual_noise = true (denoiseImage_PnP_ADMM.m:99-104); no reference definition
     nb, width = 5, 32
