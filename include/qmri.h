@@ -9,6 +9,7 @@
  *   P = setup_subsampling_spiralgrided(N,M,S,V)   setup_subsampling_spiralgrided.m:1-43 -> qmri_build_spiral
  *   P = setup_subsampling_epi(N,M,pct,V)          setup_subsampling_epi.m:1-36     -> qmri_build_epi
  *   param.net = @(x) denoiseImage_PnP_ADMM(...)   main_recon_tsmis_FFT.m:164, denoiseImage_PnP_ADMM.m:1-117 -> qmri_set_denoiser, qmri_denoise
+ *   Net = importONNXNetwork(denoiser_path, ...)   main_recon_tsmis_FFT.m:138 (weights only)      -> qmri_onnx_read_unetres
  *   x = PnP_ADMM(y, param)                        PnP_ADMM.m:1                      -> qmri_pnp_admm
  *   out = mrf_dtm_cpu(dict, data, par)            mrf_dtm_cpu.m:1                   -> qmri_set_dictionary, qmri_dict_match
  *
@@ -98,6 +99,14 @@ typedef struct {
 size_t qmri_net_nparams(const qmri_net_desc* desc);
 int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const float* weights, size_t nbytes,
                       int H, int W, int max_batch);
+/* Weight ingestion from the ONNX file the reference loads with `Net = importONNXNetwork(denoiser_path, ...)`
+ * (main_recon_tsmis_FFT.m:79-83,138), i.e. what export_to_onnx (PyTorch_Denoiser/utils.py:468-481: opset 9, weights as
+ * graph initializers) writes.  Reads the Conv / ConvTranspose weights in graph order, checks that they form a UNetRes,
+ * fills desc_out (arch, in_nc, out_nc, nc, nb; residual_noise = 0) and *nfloats_out, and -- when weights != NULL --
+ * copies the blob qmri_set_denoiser takes (capacity_floats >= *nfloats_out).  Call once with weights == NULL to size
+ * the buffer.  Host-only (no GPU, no ONNX / protobuf library); errors via qmri_last_error(NULL). */
+int qmri_onnx_read_unetres(const char* path, qmri_net_desc* desc_out, float* weights, size_t capacity_floats,
+                           size_t* nfloats_out);
 /* out = denoiseImage_PnP_ADMM(in, net, true, residual_noise): in H x W x C x B doubles -> out H x W x out_nc x B. */
 int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C, int B, double* out);
 /* raw network forward on device fp32 tensors [B][C][W][H] (no casts); the dominant kernel chain */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
-    "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps",
+    "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_onnx_read_unetres",
 ]
 
 
@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
     L.qmri_net_nparams.argtypes = [C.POINTER(NetDesc)]
     L.qmri_set_denoiser.argtypes = [vp, C.POINTER(NetDesc), fp, C.c_size_t, i, i, i]
     L.qmri_denoise.argtypes = [vp, dp, i, i, i, i, dp]
+    L.qmri_onnx_read_unetres.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qmri_net_forward_dev.argtypes = [vp, vp, i, vp]
     L.qmri_pnp_admm.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_pnp_admm_dev.argtypes = [vp, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]

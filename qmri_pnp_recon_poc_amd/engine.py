@@ -58,6 +58,21 @@ def build_epi(N: int, M: int, percentage: float, T: int):
     return fp, k[: m.value].copy()
 
 
+def read_onnx_unetres(path):
+    """Weights of the ONNX file main_recon_tsmis_FFT.m:138 imports, through the library's own reader
+    (qmri_onnx_read_unetres) -> (flat fp32 weights, dict(in_nc, out_nc, nc, nb))."""
+    L = _lib.lib()
+    d, n = NetDesc(), C.c_size_t(0)
+    st = L.qmri_onnx_read_unetres(str(path).encode(), C.byref(d), None, 0, C.byref(n))
+    if st != 0:
+        raise QmriError(st, L.qmri_last_error(None).decode())
+    w = np.empty(n.value, np.float32)
+    st = L.qmri_onnx_read_unetres(str(path).encode(), C.byref(d), w.ctypes.data_as(C.POINTER(C.c_float)), w.size, C.byref(n))
+    if st != 0:
+        raise QmriError(st, L.qmri_last_error(None).decode())
+    return w, {"in_nc": int(d.in_nc), "out_nc": int(d.out_nc), "nc": tuple(int(v) for v in d.nc), "nb": int(d.nb)}
+
+
 class Engine:
     """One device context: operator + denoiser + dictionary + workspaces."""
 

@@ -23,6 +23,25 @@ def test_tiny_unetres_vs_golden(engine_mod, oracle, in_nc):
     e.close()
 
 
+def test_checkpoint_and_onnx_files_to_engine(engine_mod, tmp_path):
+    """A checkpoint the reference's training loop would save (main_train.py:407-411) and the ONNX export of the same
+    net, read by the two weight readers, run on the GPU, compared with the reference network's own output."""
+    import onnx_writer as ow
+    from qmri_pnp_recon_poc_amd import weights as W
+    g = np.load(os.path.join(GOLDEN, "checkpoint_small.npz"))
+    w, a = W.load_denoiser_weights(os.path.join(GOLDEN, "checkpoint_small.pt"))
+    onnx_path = str(tmp_path / "net.onnx")
+    with open(onnx_path, "wb") as f:
+        f.write(ow.unetres_model(ow.split_blob(w, a["in_nc"], a["out_nc"], a["nc"], a["nb"]), a["in_nc"], a["out_nc"], a["nc"], a["nb"]))
+    w2, a2 = engine_mod.read_onnx_unetres(onnx_path)
+    assert a2 == a and np.array_equal(w2, w)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w2, 32, 32, **a)
+    y = e.denoise(g["x"].transpose(1, 2, 0).astype(np.float64)).transpose(2, 0, 1)
+    assert rel_err(y, g["y"]) < 2e-5
+    e.close()
+
+
 def test_full_unetres_64_vs_golden(engine_mod, synth):
     g = np.load(os.path.join(GOLDEN, "unetres_full_64.npz"))
     w = synth.random_weights(seed=1)

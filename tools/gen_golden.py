@@ -17,6 +17,11 @@ Fixtures
   unetres_full_224.npz                            G3: same arch, synth.structured_weights(seed=2), input
                                                   10 x 224 x 224 in [0,1]; per-channel sums / norms + a 32x32 crop
   unetres_homogeneity.npz                         G4: net(3x) vs 3 net(x) relative deviation of the reference itself
+  checkpoint_small.pt (+ checkpoint_small.npz)    G5: a checkpoint in the layout main_train.py:407-411 saves (epoch,
+                                                  model_state_dict, optimizer_state_dict after one Adam step, loss) of
+                                                  UNetRes(11,10,[4,8,8,16],nb=2), written by torch.save; the .npz holds
+                                                  the expected flat weights, an input and the reference's output
+`python tools/gen_golden.py [tiny full64 full224 checkpoint]` regenerates a subset.
 Tensor layout in the fixtures is PyTorch's [C][H][W]; tests transpose to the MATLAB order.
 """
 import os
@@ -109,8 +114,36 @@ def full224():
     print("full224: ch_sum", y.sum(axis=(1, 2))[:3], "homogeneity dev", dev)
 
 
+def checkpoint():
+    in_nc, nc, nb = 11, [4, 8, 8, 16], 2
+    torch.manual_seed(4321)
+    net = UNetRes(in_nc=in_nc, out_nc=10, nc=nc, nb=nb, act_mode="R", downsample_mode="strideconv",
+                  upsample_mode="convtranspose")
+    check_order(net, in_nc, 10, nc, nb)
+    with torch.enable_grad():                                    # one optimiser step so the Adam state holds tensors
+        opt = torch.optim.Adam(params=net.parameters(), lr=1e-3)          # main_train.py:274
+        xin = torch.from_numpy(synth.uniform01(55, in_nc * 16 * 16).astype(np.float32).reshape(1, in_nc, 16, 16))
+        loss = torch.nn.functional.mse_loss(net(xin), xin[:, :10])
+        loss.backward()
+        opt.step()
+    net.eval()
+    torch.save({"epoch": 1, "model_state_dict": net.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                "loss": loss.item()}, os.path.join(OUT, "checkpoint_small.pt"))      # main_train.py:407-411
+    x = synth.uniform01(56, in_nc * 32 * 32).astype(np.float32).reshape(in_nc, 32, 32)
+    y = net(torch.from_numpy(x)[None])[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "checkpoint_small.npz"), weights=flat_weights(net), x=x, y=y,
+                        in_nc=in_nc, out_nc=10, nc=np.array(nc), nb=nb, loss=loss.item())
+    print(f"checkpoint: params {flat_weights(net).size}, file {os.path.getsize(os.path.join(OUT, 'checkpoint_small.pt'))} B")
+
+
 if __name__ == "__main__":
-    tiny(10)
-    tiny(11)
-    full64()
-    full224()
+    todo = sys.argv[1:] or ["tiny", "full64", "full224", "checkpoint"]
+    if "tiny" in todo:
+        tiny(10)
+        tiny(11)
+    if "full64" in todo:
+        full64()
+    if "full224" in todo:
+        full224()
+    if "checkpoint" in todo:
+        checkpoint()
