@@ -43,6 +43,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     if (p.d_stamps) (void)hipFree(p.d_stamps);
     for (hipGraphExec_t g : p.fwd_graph) if (g) (void)hipGraphExecDestroy(g);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
+    if (p.d_range_flag) (void)hipFree(p.d_range_flag);
     p = NetPlan();
 }
 
@@ -59,6 +60,16 @@ static int alloc_tensor(qmri_ctx* ctx, PTensor& t, int C, int Cal, int H, int W,
     return QMRI_OK;
 }
 
+static int pack_layer6(qmri_ctx* ctx, ConvLayer& L, const float* w) {
+    std::vector<uint16_t> p6;
+    if (L.kind == CONV_3X3 || L.kind == CONV_3X3N) conv6_plan_pack(L, w, p6);     // (conv_plan_layer renames narrow 3x3 layers)
+    else conv6s_plan_pack(L, w, p6);
+    hipError_t e = hipMalloc(&L.wp6, p6.size() * sizeof(uint16_t));
+    if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+    QMRI_HIP(ctx, hipMemcpy(L.wp6, p6.data(), p6.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return QMRI_OK;
+}
+
 static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const float*& w) {
     ConvLayer L;
     conv_plan_layer(L, kind, Cin, Cout);
@@ -67,17 +78,43 @@ static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const floa
     hipError_t e = hipMalloc((void**)&L.wp, packed.size() * sizeof(float));
     if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
     QMRI_HIP(ctx, hipMemcpy(L.wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    {                                                      // the same weights for the bf16 x 6 kernels
-        std::vector<uint16_t> p6;
-        if (kind == CONV_3X3) conv6_plan_pack(L, w, p6);
-        else conv6s_plan_pack(L, w, p6);
-        e = hipMalloc(&L.wp6, p6.size() * sizeof(uint16_t));
-        if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
-        QMRI_HIP(ctx, hipMemcpy(L.wp6, p6.data(), p6.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
+    L.sp6 = ctx->net.sp6;
+    QMRI_TRY(pack_layer6(ctx, L, w));                      // the same weights, split for the bf16 / f16 matrix-core kernels
     const int taps = (kind == CONV_3X3) ? 9 : 4;
     w += (size_t)Cin * Cout * taps;
     ctx->net.layers.push_back(L);
+    return QMRI_OK;
+}
+
+// Re-pack every layer for the other operand-splitting scheme (sp = 2: f16 x 3 products, sp = 3: bf16 x 6 products).
+static int net_set_scheme(qmri_ctx* ctx, int sp) {
+    NetPlan& p = ctx->net;
+    if (p.sp6 == sp) return QMRI_OK;
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const float* w = p.w_host.data();
+    for (ConvLayer& L : p.layers) {
+        if (L.wp6) { (void)hipFree(L.wp6); L.wp6 = nullptr; }
+        L.sp6 = sp;
+        QMRI_TRY(pack_layer6(ctx, L, w));
+        w += (size_t)L.Cin * L.Cout * ((L.kind == CONV_3X3 || L.kind == CONV_3X3N) ? 9 : 4);
+    }
+    p.sp6 = sp;
+    for (hipGraphExec_t& g : p.fwd_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }   // captured launches name the old kernels
+    return QMRI_OK;
+}
+
+// After a synchronisation: did a layer's output leave the range the f16 split carries (|x| <= 6e4, finite)?  If so the
+// network is switched to the bf16 scheme (8 exponent bits, no range limit) and the caller runs its work again.
+static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
+    NetPlan& p = ctx->net;
+    tripped = false;
+    if (p.sp6 != 2 || !p.d_range_flag) return QMRI_OK;
+    unsigned f = 0;
+    QMRI_HIP(ctx, hipMemcpy(&f, p.d_range_flag, sizeof f, hipMemcpyDeviceToHost));
+    if (!f) return QMRI_OK;
+    QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
+    QMRI_TRY(net_set_scheme(ctx, 3));
+    tripped = true;
     return QMRI_OK;
 }
 
@@ -112,6 +149,11 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     qmri_free_net(ctx);
     NetPlan& p = ctx->net;
     p.desc = *desc; p.H = H; p.W = W; p.maxB = max_batch;
+    p.w_host.assign(weights, weights + nbytes / 4);
+    p.sp6 = conv6_default_sp();
+    if (p.sp6 == 2 && !conv6_weights_fit_f16(weights, nbytes / 4)) p.sp6 = 3;     // weights beyond the f16 range: bf16 scheme
+    QMRI_HIP(ctx, hipMalloc((void**)&p.d_range_flag, sizeof(unsigned)));
+    QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof(unsigned)));
     const float* w = weights;
     const int nb = desc->nb;
     const size_t B = (size_t)max_batch;
@@ -270,14 +312,19 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
     double* d_io = nullptr;
     QMRI_HIP(ctx, hipMalloc((void**)&d_io, std::max(nin, nout) * sizeof(double)));
     int st = QMRI_OK;
-    do {
-        if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
-        if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32)) != QMRI_OK) break;         // im2single: :72-77
-        if ((st = net_forward(ctx, B)) != QMRI_OK) break;                                      // activations(...): :88
-        if ((st = ew_launch_unpack(ctx, B, p.desc.out_nc, H, W, p.out32, p.in32, p.desc.residual_noise, d_io, 1)) != QMRI_OK) break;
-        if (hipMemcpyAsync(out, d_io, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
-    } while (0);
+    for (int attempt = 0; attempt < 2; ++attempt) {        // (second pass only after the f16 range guard switched the scheme)
+        bool again = false;
+        do {
+            if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
+            if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32)) != QMRI_OK) break;         // im2single: :72-77
+            if ((st = net_forward(ctx, B)) != QMRI_OK) break;                                      // activations(...): :88
+            if ((st = ew_launch_unpack(ctx, B, p.desc.out_nc, H, W, p.out32, p.in32, p.desc.residual_noise, d_io, 1)) != QMRI_OK) break;
+            if (hipMemcpyAsync(out, d_io, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
+            st = net_range_tripped(ctx, again);
+        } while (0);
+        if (st != QMRI_OK || !again) break;
+    }
     (void)hipFree(d_io);
     if (st == QMRI_ERR_HIP && ctx->err.empty()) qmri_set_error(ctx, "HIP failure in qmri_denoise");
     return st;
@@ -383,6 +430,12 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     if (prm->want_diag && diag_out && prm->iters > 0)
         QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (prm->iters > 0) {
+        // f16 range guard: the network now runs on the bf16 scheme; the inputs are untouched (d_x_out must not alias d_x0), run again
+        bool again = false;
+        QMRI_TRY(net_range_tripped(ctx, again));
+        if (again) return qmri_pnp_admm_dev(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+    }
     return QMRI_OK;
 }
 

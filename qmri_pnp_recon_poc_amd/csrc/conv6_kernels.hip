@@ -26,6 +26,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (register arrays of HIP's uint4 struct are not promoted out of scratch)
@@ -33,7 +34,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (register array
 constexpr int NT6 = 512;         // threads per workgroup: 4 MFMA waves + 4 loader waves
 constexpr int NLD6 = 256;        // loader threads
 constexpr int CK = 16;           // input channels per chunk = K of one MFMA
-constexpr int AST = 3 * 2 * 3 * 64;   // uint4 per step of A: 3 taps x 2 cout tiles x 3 splits x 64 lanes
+// SP = pieces an fp32 operand is split into: 3 (bf16 x 6 products) or 2 (f16 x 3 products), see the header comment
+constexpr int ast6(int SP) { return 3 * 2 * SP * 64; }   // uint4 per step of A: 3 taps x 2 cout tiles x SP splits x 64 lanes
+constexpr float LO_SCALE = 2048.f;    // f16 scheme: the low piece is stored as (x - hi) * 2^11, so it is normal whenever x is
 
 struct Conv6Args {
     const float* in; const uint4* wp; float* out; const float* add1; const float* add2;
@@ -45,6 +48,7 @@ struct Conv6Args {
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
+    unsigned* range_flag;         // f16 scheme: set to 1 when an output leaves the range the next layer's f16 split can carry
     unsigned long long* stamps;   // diagnostic (QMRI_CONV_STAMPS): [16 workgroups][2 roles][128] barrier-arrival times, 100 MHz clock
 };
 
@@ -78,6 +82,13 @@ __device__ __forceinline__ void lds_barrier6() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+__device__ __forceinline__ f32x16 mfma_b(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 
 // Loader waves request their operands with inline-asm loads and wait with hand-counted s_waitcnt: hipcc's own counter
@@ -90,6 +101,14 @@ __device__ __forceinline__ void gload1(float& dst, unsigned off, const void* bas
 template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], float (&b)[1][8]) {
     asm volatile("s_waitcnt vmcnt(%13)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
+                   "+v"(b[0][4]), "+v"(b[0][5]), "+v"(b[0][6]), "+v"(b[0][7])
+                 : "n"(N)
+                 : "memory");
+}
+
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], float (&b)[1][8]) {
+    asm volatile("s_waitcnt vmcnt(%11)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
                    "+v"(b[0][4]), "+v"(b[0][5]), "+v"(b[0][6]), "+v"(b[0][7])
                  : "n"(N)
                  : "memory");
@@ -117,8 +136,19 @@ __device__ __forceinline__ void split_pair(float xa, float xb, unsigned& p0, uns
     p2 = (unsigned)__builtin_bit_cast(unsigned short, a2) | ((unsigned)__builtin_bit_cast(unsigned short, b2) << 16);
 }
 
-template <int CFG>
+// x = hi + lo' / 2^11 with hi = f16(x), lo' = f16((x - hi) * 2^11): 22 significant bits plus the sign of lo'
+// (x - hi is exact in fp32; lo' rounds at 2^-22 |x|); two values packed per dword, low half = first
+__device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, unsigned& p1) {
+    const _Float16 a0 = (_Float16)xa, b0 = (_Float16)xb;
+    const _Float16 a1 = (_Float16)((xa - (float)a0) * LO_SCALE), b1 = (_Float16)((xb - (float)b0) * LO_SCALE);
+    p0 = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, b0) << 16);
+    p1 = (unsigned)__builtin_bit_cast(unsigned short, a1) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+}
+constexpr float F16_RANGE = 60000.f;  // |activation| above this cannot be split (f16 max 65504): reported through range_flag
+
+template <int CFG, int SP>
 __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
+    constexpr int AST = ast6(SP);
     typedef Cfg6<CFG> C;
     constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT;
     constexpr int IH = TH + 2, IW = TW + 2;                         // input tile with halo
@@ -129,15 +159,16 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int NBI = 2 * NLP;                                    // loader items of one chunk of B: (k-half, pixel)
     constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);          // ... per loader thread and step (a chunk is spread over its 3 steps)
     constexpr int NAQ = (AST + NLD6 - 1) / NLD6;                    // uint4 of A per loader thread and step
-    static_assert(NAQ == 5 && NBQ == 1, "gwait() is written for 5 + 8 loads per step");
+    static_assert(((SP == 3 && NAQ == 5) || (SP == 2 && NAQ == 3)) && NBQ == 1, "gwait() is written for 5 + 8 / 3 + 8 loads per step");
     constexpr int NLOAD = NAQ + 8 * NBQ;                            // vector-memory loads a loader thread issues per step
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
     constexpr int PXT = TH * TW, PP = PXT + 4;                      // output tile in LDS: [64 cout][PP], aliases the B buffers
-    uint4* Bbuf = Abuf + NABUF * AST;                                   // [2][3 splits][2 k-halves][NPX]  (8 channels = 16 B per entry)
-
-    float* ot = (float*)Bbuf;
-    static_assert(64 * PP * 4 <= 2 * 3 * 2 * NPX * 16, "output tile must fit the B buffers");
+    uint4* Bbuf = Abuf + NABUF * AST;                                   // [2][SP splits][2 k-halves][NPX]  (8 channels = 16 B per entry)
+    // The output tile aliases the operand buffers (SP == 3: the B buffers; SP == 2: from the start -- the loaders' last
+    // stores into A precede the loop's last barrier, the tile is written after it).
+    float* ot = (SP == 3) ? (float*)Bbuf : (float*)smem;
+    static_assert(SP == 3 ? (64 * PP * 4 <= 2 * 3 * 2 * NPX * 16) : (64 * PP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "output tile must fit the operand buffers");
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
@@ -191,7 +222,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
         {                                                                                                        \
-            uint4* bd = Bbuf + ((c_) & 1) * (3 * 2 * NPX);                                                       \
+            uint4* bd = Bbuf + ((c_) & 1) * (SP * 2 * NPX);                                                      \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                                    \
                 int item = (part_) * (NBQ * NLD6) + lt + NLD6 * q;                                               \
                 if (item >= NBI) item = 0;                                                                       \
@@ -200,13 +231,20 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                     const int dw = px / IH, dh = px - dw * IH;                                                   \
                     const int e = h2 * NPX + dw * IHP + dh;                                                      \
                     uint4 s0, s1, s2;                                                                            \
-                    split_pair(rb_[q][0], rb_[q][1], s0.x, s1.x, s2.x);                                          \
-                    split_pair(rb_[q][2], rb_[q][3], s0.y, s1.y, s2.y);                                          \
-                    split_pair(rb_[q][4], rb_[q][5], s0.z, s1.z, s2.z);                                          \
-                    split_pair(rb_[q][6], rb_[q][7], s0.w, s1.w, s2.w);                                          \
+                    if constexpr (SP == 3) {                                                                     \
+                        split_pair(rb_[q][0], rb_[q][1], s0.x, s1.x, s2.x);                                      \
+                        split_pair(rb_[q][2], rb_[q][3], s0.y, s1.y, s2.y);                                      \
+                        split_pair(rb_[q][4], rb_[q][5], s0.z, s1.z, s2.z);                                      \
+                        split_pair(rb_[q][6], rb_[q][7], s0.w, s1.w, s2.w);                                      \
+                    } else {                                                                                     \
+                        split_pair_h(rb_[q][0], rb_[q][1], s0.x, s1.x);                                          \
+                        split_pair_h(rb_[q][2], rb_[q][3], s0.y, s1.y);                                          \
+                        split_pair_h(rb_[q][4], rb_[q][5], s0.z, s1.z);                                          \
+                        split_pair_h(rb_[q][6], rb_[q][7], s0.w, s1.w);                                          \
+                    }                                                                                            \
                     bd[e] = s0;                  /* split planes are 2*NPX entries apart */                       \
                     bd[2 * NPX + e] = s1;                                                                        \
-                    bd[4 * NPX + e] = s2;                                                                        \
+                    if constexpr (SP == 3) bd[4 * NPX + e] = s2;                                                 \
                 }                                                                                                \
             }                                                                                                    \
         }
@@ -259,12 +297,13 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     C::wave_map(wave, pbh, pbw, m0);
     const int pxl = (pbw + (li >> 3)) * IHP + pbh + (li & 7);       // LDS entry of this lane's pixel at tap (0,0), pixel block 0
     f32x16 acc[MW][NCT];
+    f32x16 accl[SP == 2 ? MW : 1][SP == 2 ? NCT : 1];              // f16 scheme: the cross terms hi*lo' + lo'*hi, 2^11 too large
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
         for (int n = 0; n < NCT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.f; if constexpr (SP == 2) accl[m][n][r] = 0.f; }
 
     if (A.stamps && tid == 0 && blockIdx.x == 0) { A.stamps[8192 + (A.launch_idx & 127) * 4] = wall_clock64(); A.stamps[8192 + (A.launch_idx & 127) * 4 + 3] = (unsigned long long)(CFG * 1000 + nsteps); }
     C6_STAMP(0, 0);
@@ -275,18 +314,18 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         // barriers inside the chunk: the next step's weights were published one barrier earlier (three A buffers) and the
         // chunk's activations are complete.  Only the chunk's first tap waits for its fragments after a barrier.
         const uint4* ab = Abuf + lane;
-        const uint4* bb = Bbuf + (c & 1) * (3 * 2 * NPX) + h2 * NPX + pxl;
-        bf16x8 bf[2][NCT][3], af[2][MW][3];
+        const uint4* bb = Bbuf + (c & 1) * (SP * 2 * NPX) + h2 * NPX + pxl;
+        u32x4 bf[2][NCT][SP], af[2][MW][SP];
         auto frags = [&](int T, int set) __attribute__((always_inline)) {
             const int kh = T / 3, kw = T - 3 * kh;
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) bf[set][n][sp] = __builtin_bit_cast(bf16x8, bb[sp * 2 * NPX + kw * IHP + kh + 8 * n]);
+                for (int sp = 0; sp < SP; ++sp) bf[set][n][sp] = __builtin_bit_cast(u32x4, bb[sp * 2 * NPX + kw * IHP + kh + 8 * n]);
 #pragma unroll
             for (int m = 0; m < MW; ++m)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) af[set][m][sp] = __builtin_bit_cast(bf16x8, ab[kh * AST + ((kw * 2 + (m0 + m)) * 3 + sp) * 64]);
+                for (int sp = 0; sp < SP; ++sp) af[set][m][sp] = __builtin_bit_cast(u32x4, ab[kh * AST + ((kw * 2 + (m0 + m)) * SP + sp) * 64]);
         };
         frags(0, 0);
 #pragma unroll
@@ -298,14 +337,22 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int n = 0; n < NCT; ++n) {
-                    f32x16 a_ = acc[m][n];                          // smallest terms first
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][2], bf[cur][n][0], a_, 0, 0, 0);
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][2], a_, 0, 0, 0);
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bf[cur][n][1], a_, 0, 0, 0);
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bf[cur][n][0], a_, 0, 0, 0);
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][1], a_, 0, 0, 0);
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bf[cur][n][0], a_, 0, 0, 0);
-                    acc[m][n] = a_;
+                    if constexpr (SP == 3) {
+                        f32x16 a_ = acc[m][n];                      // smallest terms first
+                        a_ = mfma_b(af[cur][m][2], bf[cur][n][0], a_);
+                        a_ = mfma_b(af[cur][m][0], bf[cur][n][2], a_);
+                        a_ = mfma_b(af[cur][m][1], bf[cur][n][1], a_);
+                        a_ = mfma_b(af[cur][m][1], bf[cur][n][0], a_);
+                        a_ = mfma_b(af[cur][m][0], bf[cur][n][1], a_);
+                        a_ = mfma_b(af[cur][m][0], bf[cur][n][0], a_);
+                        acc[m][n] = a_;
+                    } else {
+                        f32x16 l_ = accl[m][n];
+                        l_ = mfma_h(af[cur][m][1], bf[cur][n][0], l_);
+                        l_ = mfma_h(af[cur][m][0], bf[cur][n][1], l_);
+                        accl[m][n] = l_;
+                        acc[m][n] = mfma_h(af[cur][m][0], bf[cur][n][0], acc[m][n]);
+                    }
                 }
             if (T % 3 == 2) {
                 const int g = 3 * c + T / 3;
@@ -328,7 +375,9 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = acc[m][n][r];
+                float v = acc[m][n][r];
+                if constexpr (SP == 2) v += accl[m][n][r] * (1.f / LO_SCALE);
+                ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = v;
             }
     }   // MFMA waves
 
@@ -337,6 +386,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     // before the barrier that publishes the LDS tile: one memory latency, overlapped.
     {
         const bool has1 = A.add1 != nullptr, has2 = A.add2 != nullptr;
+        bool bad = false;
         if (A.vec4) {
             constexpr int NG = 64 * PXT / 4, GQ = NG / NT6;         // float4 groups of the tile; per thread
             static_assert(NG % NT6 == 0 && TH % 4 == 0, "epilogue");
@@ -367,6 +417,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
                 if (off[k] != ~0u) *(f32x4*)(A.out + (size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]) = x;
+                if constexpr (SP == 2) bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);   // (also NaN)
             }
         } else {
             constexpr int NE = 64 * PXT, EQ = NE / NT6;             // tile elements; elements per thread
@@ -398,14 +449,16 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 float x = (ot[co * PP + rem] + r1[k]) + r2[k];
                 if (A.relu_out) x = fmaxf(x, 0.f);
                 if (off[k] != ~0u) A.out[(size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]] = x;
+                if constexpr (SP == 2) bad |= !(fabsf(x) <= F16_RANGE);
             }
         }
+        if constexpr (SP == 2) { if (bad && A.range_flag) *A.range_flag = 1u; }   // (every writer stores the same value)
     }
     C6_STAMP(0, nsteps + 2);
     if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64();
 }
 
-template <int CFG> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG>(A); }
+template <int CFG, int SP> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP>(A); }
 
 // =====================================================================================================================
 // k_conv6s : the 2x2 / stride-2 layers on the same bf16 x 6 scheme.
@@ -419,7 +472,7 @@ template <int CFG> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Arg
 // steps ahead, counted waits), each thread carries 2 channels x 4 consecutive h (one aligned float4 per channel).
 // 49 KB of LDS: three workgroups share a CU and hide each other's barriers.
 // =====================================================================================================================
-constexpr int ASTS = 2 * 2 * 3 * 64;      // uint4 per step of A: 2 planes x 2 row tiles x 3 splits x 64 lanes
+constexpr int asts6(int SP) { return 2 * 2 * SP * 64; }   // uint4 per step of A: 2 planes x 2 row tiles x SP splits x 64 lanes
 constexpr int STH = 8, STW = 8;           // pixel tile
 constexpr int SNPX = STH * STW;           // LDS entries per (split, k-half, plane): pitch 8 = 8 mod 16, conflict-free
 
@@ -431,24 +484,32 @@ struct Conv6sArgs {
     int out_hp, out_plane; long out_bs;
     int nsteps, n_ct, tiles_h, tiles_w;   // nsteps is a multiple of 3 (the register rotation of the loaders); steps >= nsteps_real
     int nsteps_real;                      // carry zero weights and repeat the last step's activations
+    unsigned* range_flag;                 // as in Conv6Args
 };
 
 template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[3], f32x4 (&b)[2]) {
     asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
 }
+template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[2], f32x4 (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+}
 __device__ __forceinline__ void gload4f(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 
-template <int KIND>               // 0 = DOWN, 1 = UP
+template <int KIND, int SP>       // 0 = DOWN, 1 = UP; SP as in k_conv6
 __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
-    constexpr int NLS = 3 + 2;                                      // vector-memory loads a loader thread issues per step
+    constexpr int ASTS = asts6(SP);
+    constexpr int NAS = ASTS / NLD6;                                // uint4 of A per loader thread and step
+    static_assert(NAS * NLD6 == ASTS && NAS == SP, "loader split of A");
+    constexpr int NLS = NAS + 2;                                    // vector-memory loads a loader thread issues per step
     constexpr int OPX = (KIND == 0) ? SNPX : 2 * SNPX;              // output pixels per row of the LDS output tile
     constexpr int OROWS = (KIND == 0) ? 64 : 32;                    // output channels of the workgroup
     constexpr int PPs = OPX + 4;
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [2][ASTS]
-    unsigned* Bbuf = (unsigned*)(Abuf + 2 * ASTS);                  // [2][3 splits][2 k-halves][2 planes][SNPX] x 4 dwords
-    float* ot = (float*)Bbuf;
-    static_assert(OROWS * PPs * 4 <= 2 * 3 * 2 * 2 * SNPX * 16, "output tile must fit the B buffers");
+    unsigned* Bbuf = (unsigned*)(Abuf + 2 * ASTS);                  // [2][SP splits][2 k-halves][2 planes][SNPX] x 4 dwords
+    constexpr int BSTEP = SP * 2 * 2 * SNPX * 4;                    // dwords of B per step; split planes are 2*2*SNPX*4 dwords apart
+    float* ot = (SP == 3) ? (float*)Bbuf : (float*)smem;            // (SP == 2: aliases A too; the last stores into A precede the loop's last barrier)
+    static_assert(SP == 3 ? (OROWS * PPs * 4 <= 2 * BSTEP * 4) : (OROWS * PPs * 4 <= 2 * ASTS * 16 + 2 * BSTEP * 4), "output tile must fit the operand buffers");
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
@@ -462,9 +523,9 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         // ------------------------------------------------------------------ loaders
         const int lt = tid - (NT6 - NLD6);
         const uint4* wsrc = A.wp + (size_t)ct * nsteps * ASTS;
-        unsigned aoff[3];
+        unsigned aoff[NAS];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);
+        for (int q = 0; q < NAS; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);
         // this thread's activations: 2 channels (pair cp of an 8-channel half) x 4 consecutive h
         const int cp = lt & 3, rest = lt >> 2;
         int h2, pl, hg, wq;                                         // k-half, plane (UP: channel slice), h group, column
@@ -479,13 +540,13 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         const float* isrc = A.in + (size_t)b * A.in_bs + ((KIND == 0) ? ((size_t)(2 * gw0 + 1) * A.in_hp + 2 * gh0 + 1)
                                                                       : ((size_t)(gw0 + 1) * A.in_hp + gh0 + 1));
         __builtin_amdgcn_s_setprio(2);
-        u32x4 ra0[3], ra1[3], ra2[3];
+        u32x4 ra0[NAS], ra1[NAS], ra2[NAS];
         f32x4 rb0[2], rb1[2], rb2[2];
 #define SLOAD(g_, ra_, rb_)                                                                                      \
         {                                                                                                        \
             const int ga = ((g_) < nsteps) ? (g_) : nsteps - 1, gg = (ga < A.nsteps_real) ? ga : A.nsteps_real - 1;   \
             const uint4* ws = uniform_ptr(wsrc + (size_t)ga * ASTS);                                             \
-            _Pragma("unroll") for (int q = 0; q < 3; ++q) gload4(ra_[q], aoff[q], ws);                           \
+            _Pragma("unroll") for (int q = 0; q < NAS; ++q) gload4(ra_[q], aoff[q], ws);                         \
             const float* bs_ = (KIND == 0) ? uniform_ptr(isrc + (size_t)(gg >> 1) * CK * A.in_plane + (size_t)(gg & 1) * A.in_hp) \
                                            : uniform_ptr(isrc + (size_t)gg * 32 * A.in_plane);                   \
             gload4f(rb_[0], boff, bs_); gload4f(rb_[1], boff2, bs_);                                             \
@@ -493,16 +554,18 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
 #define SSTORE(g_, ra_, rb_)                                                                                     \
         {                                                                                                        \
             uint4* ad = Abuf + ((g_) & 1) * ASTS;                                                                \
-            _Pragma("unroll") for (int q = 0; q < 3; ++q) ad[lt + NLD6 * q] = __builtin_bit_cast(uint4, ra_[q]); \
-            unsigned* bd = Bbuf + ((g_) & 1) * (3 * 2 * 2 * SNPX * 4);                                           \
+            _Pragma("unroll") for (int q = 0; q < NAS; ++q) ad[lt + NLD6 * q] = __builtin_bit_cast(uint4, ra_[q]); \
+            unsigned* bd = Bbuf + ((g_) & 1) * BSTEP;                                                            \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-                unsigned p0, p1, p2;                                                                             \
-                split_pair(rb_[0][j], rb_[1][j], p0, p1, p2);                                                    \
+                unsigned p0, p1, p2 = 0;                                                                         \
+                if constexpr (SP == 3) split_pair(rb_[0][j], rb_[1][j], p0, p1, p2);                             \
+                else split_pair_h(rb_[0][j], rb_[1][j], p0, p1);                                                 \
                 const int hh = 4 * hg + j;                                                                       \
                 const int plane_ = (KIND == 0) ? (hh & 1) : pl;                                                  \
                 const int px = (KIND == 0) ? (wq * STH + (hh >> 1)) : (wq * STH + hh);                           \
                 const int e = ((h2 * 2 + plane_) * SNPX + px) * 4 + cp;                                          \
-                bd[e] = p0; bd[2 * 2 * SNPX * 4 + e] = p1; bd[2 * 2 * 2 * SNPX * 4 + e] = p2;                    \
+                bd[e] = p0; bd[2 * 2 * SNPX * 4 + e] = p1;                                                       \
+                if constexpr (SP == 3) bd[2 * 2 * 2 * SNPX * 4 + e] = p2;                                        \
             }                                                                                                    \
         }
         SLOAD(0, ra0, rb0) SLOAD(1, ra1, rb1) SLOAD(2, ra2, rb2)
@@ -535,31 +598,41 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h2 = lane >> 5;
         const int m0 = wave & 1, pbw = 4 * (wave >> 1);
         const int pxl = (pbw + (li >> 3)) * STH + (li & 7);
-        f32x16 acc;
+        f32x16 acc, accl;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; }
         lds_barrier6();                                             // barrier 0
         for (int g = 0; g < nsteps; ++g) {
             const uint4* ab = Abuf + (g & 1) * ASTS + lane;
-            const uint4* bb = (const uint4*)(Bbuf + (g & 1) * (3 * 2 * 2 * SNPX * 4)) + (h2 * 2) * SNPX + pxl;
-            bf16x8 bf[2][3], af[2][3];
+            const uint4* bb = (const uint4*)(Bbuf + (g & 1) * BSTEP) + (h2 * 2) * SNPX + pxl;
+            u32x4 bf[2][SP], af[2][SP];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) {
-                    bf[t][sp] = __builtin_bit_cast(bf16x8, bb[sp * 2 * 2 * SNPX + t * SNPX]);
-                    af[t][sp] = __builtin_bit_cast(bf16x8, ab[((t * 2 + m0) * 3 + sp) * 64]);
+                for (int sp = 0; sp < SP; ++sp) {
+                    bf[t][sp] = __builtin_bit_cast(u32x4, bb[sp * 2 * 2 * SNPX + t * SNPX]);
+                    af[t][sp] = __builtin_bit_cast(u32x4, ab[((t * 2 + m0) * SP + sp) * 64]);
                 }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][2], bf[t][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], bf[t][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], bf[t][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], bf[t][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], bf[t][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], bf[t][0], acc, 0, 0, 0);
+                if constexpr (SP == 3) {
+                    acc = mfma_b(af[t][2], bf[t][0], acc);
+                    acc = mfma_b(af[t][0], bf[t][2], acc);
+                    acc = mfma_b(af[t][1], bf[t][1], acc);
+                    acc = mfma_b(af[t][1], bf[t][0], acc);
+                    acc = mfma_b(af[t][0], bf[t][1], acc);
+                    acc = mfma_b(af[t][0], bf[t][0], acc);
+                } else {
+                    accl = mfma_h(af[t][1], bf[t][0], accl);
+                    accl = mfma_h(af[t][0], bf[t][1], accl);
+                    acc = mfma_h(af[t][0], bf[t][0], acc);
+                }
             }
             lds_barrier6();                                         // barrier g+1
+        }
+        if constexpr (SP == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += accl[r] * (1.f / LO_SCALE);
         }
         // accumulators -> LDS output tile.  C/D layout: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -574,11 +647,13 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
     {
         constexpr int NG = OROWS * OPX / 4, GQ = NG / NT6;
         static_assert(NG % NT6 == 0, "epilogue");
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < GQ; ++k) {
             const int e = k * NT6 + tid;
             const int co = e / (OPX / 4), rem = e - co * (OPX / 4);
             const f32x4 x = *(const f32x4*)(ot + co * PPs + 4 * rem);
+            if constexpr (SP == 2) bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);
             if (KIND == 0) {
                 const int w = rem / (STH / 4), h = 4 * (rem - w * (STH / 4));
                 const int cog = ct * 64 + co, oh = gh0 + h, ow = gw0 + w;
@@ -591,18 +666,19 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
                     *(f32x4*)(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(2 * iwg + kw + 1) * A.out_hp + (2 * gh0 + hh + 1)) = x;
             }
         }
+        if constexpr (SP == 2) { if (bad && A.range_flag) *A.range_flag = 1u; }
     }
 }
 
-constexpr size_t conv6s_lds() { return (size_t)(2 * ASTS) * 16 + (size_t)2 * 3 * 2 * 2 * SNPX * 16; }
+constexpr size_t conv6s_lds(int SP) { return (size_t)(2 * asts6(SP)) * 16 + (size_t)2 * SP * 2 * 2 * SNPX * 16; }
 
-template <int CFG> constexpr size_t conv6_lds() {
-    return (size_t)(NABUF * AST + 2 * 3 * 2 * ((((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 1) + Cfg6<CFG>::TH + 2)) * 16;
+template <int CFG> constexpr size_t conv6_lds(int SP) {
+    return (size_t)(NABUF * ast6(SP) + 2 * SP * 2 * ((((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 1) + Cfg6<CFG>::TH + 2)) * 16;
 }
 
 static int g_launch_counter = 0;     // diagnostic: running number of k_conv6 launches (all configurations)
 
-template <int CFG>
+template <int CFG, int SP>
 int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
             const PTensor* add2, int relu_out, int ksplit = 1, float* partial = nullptr, long out_ks = 0) {
     typedef Cfg6<CFG> C;
@@ -620,25 +696,33 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.relu_out = relu_out;
     A.vec4 = (in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
               (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp))) ? 1 : 0;
+    A.range_flag = ctx->net.d_range_flag;
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
     A.launch_idx = g_launch_counter++;
     A.detail = (stamp_launch < 0 || A.launch_idx == stamp_launch) ? 1 : 0;
-    if (!ctx->conv6_attr[CFG]) {
-        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>()));
-        ctx->conv6_attr[CFG] = true;
+    if (!ctx->conv6_attr[CFG][SP - 2]) {
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>(SP)));
+        ctx->conv6_attr[CFG][SP - 2] = true;
     }
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
-    k_conv6<CFG><<<dim3(grid), dim3(NT6), conv6_lds<CFG>(), ctx->stream>>>(A);
+    k_conv6<CFG, SP><<<dim3(grid), dim3(NT6), conv6_lds<CFG>(SP), ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
+}
+
+template <int CFG>
+int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
+            const PTensor* add2, int relu_out, int ksplit = 1, float* partial = nullptr, long out_ks = 0) {
+    return (L.sp6 == 2) ? launch6<CFG, 2>(ctx, L, B, in, out, add1, add2, relu_out, ksplit, partial, out_ks)
+                        : launch6<CFG, 3>(ctx, L, B, in, out, add1, add2, relu_out, ksplit, partial, out_ks);
 }
 
 // split-K layers: out = relu(sum_k partial_k + add1 + add2), partial sums added in slice order
 __global__ __launch_bounds__(256) void k_conv6_reduce(const float* __restrict__ part, int ksplit, long out_ks, float* __restrict__ out,
                                                         const float* __restrict__ add1, const float* __restrict__ add2, long add1_bs,
                                                         long add2_bs, long out_bs, int Cout, int H, int W, int hp, int plane, int relu,
-                                                        long total) {
+                                                        long total, unsigned* range_flag) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int h = (int)(i % H);
@@ -653,6 +737,7 @@ __global__ __launch_bounds__(256) void k_conv6_reduce(const float* __restrict__ 
     if (add2) v += add2[b * add2_bs + o];
     if (relu) v = fmaxf(v, 0.f);
     out[b * out_bs + o] = v;
+    if (range_flag && !(fabsf(v) <= F16_RANGE)) *range_flag = 1u;
 }
 
 inline uint16_t host_bf16(float x) {                               // round to nearest even, as v_cvt_pk_bf16_f32
@@ -670,13 +755,43 @@ bool conv6_enabled() {
     return on;
 }
 
+// operand splitting of the matrix-core path: 2 = f16 x 3 products (default), 3 = bf16 x 6 products (QMRI_CONV_SCHEME=bf16x6)
+int conv6_default_sp() {
+    static const int sp = (getenv("QMRI_CONV_SCHEME") && !strcmp(getenv("QMRI_CONV_SCHEME"), "bf16x6")) ? 3 : 2;
+    return sp;
+}
+
+// The f16 scheme carries |w| up to the f16 maximum; larger weights (or non-finite ones) need the bf16 scheme.
+bool conv6_weights_fit_f16(const float* w, size_t n) {
+    for (size_t i = 0; i < n; ++i) if (!(std::fabs(w[i]) <= F16_RANGE)) return false;
+    return true;
+}
+
+namespace {
+// pieces of one weight in the layer's scheme (L.sp6): bf16 triple, or f16 (hi, (w - hi) * 2^11)
+inline void host_split(int sp, float v, uint16_t (&h)[3]) {
+    if (sp == 3) {
+        h[0] = host_bf16(v);
+        const float r1 = v - host_bf16_to_f(h[0]);
+        h[1] = host_bf16(r1);
+        const float r2 = r1 - host_bf16_to_f(h[1]);
+        h[2] = host_bf16(r2);
+    } else {
+        const _Float16 hi = (_Float16)v;                           // round to nearest even, as v_cvt_f16_f32
+        const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+        std::memcpy(&h[0], &hi, 2); std::memcpy(&h[1], &lo, 2); h[2] = 0;
+    }
+}
+}  // namespace
+
 // Weights (Conv2d OIHW) -> pre-split A fragments:
-//   uint4 index = ((((ct64*nchunk + chunk)*9 + tap)*2 + m)*3 + split)*64 + lane ; the uint4 holds 8 bf16, element j:
+//   uint4 index = ((((ct64*nchunk + chunk)*9 + tap)*2 + m)*SP + split)*64 + lane ; the uint4 holds 8 pieces, element j:
 //   row = ct64*64 + m*32 + (lane&31),  ci = chunk*16 + 8*(lane>>5) + j,  tap = kh*3 + kw
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed) {
     L.nchunk6 = (L.Cin + CK - 1) / CK;
     L.n_ct6 = (L.Cout + 63) / 64;
-    packed.assign((size_t)L.n_ct6 * L.nchunk6 * 9 * 2 * 3 * 64 * 8, 0);
+    const int SP = L.sp6;
+    packed.assign((size_t)L.n_ct6 * L.nchunk6 * 9 * 2 * SP * 64 * 8, 0);
     for (int ct = 0; ct < L.n_ct6; ++ct)
         for (int chunk = 0; chunk < L.nchunk6; ++chunk)
             for (int tap = 0; tap < 9; ++tap)
@@ -687,20 +802,15 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
                             const int ci = chunk * CK + 8 * (lane >> 5) + j;
                             if (row >= L.Cout || ci >= L.Cin) continue;
                             const float v = w[((size_t)row * L.Cin + ci) * 9 + tap];
-                            const uint16_t h0 = host_bf16(v);
-                            const float r1 = v - host_bf16_to_f(h0);
-                            const uint16_t h1 = host_bf16(r1);
-                            const float r2 = r1 - host_bf16_to_f(h1);
-                            const uint16_t h2 = host_bf16(r2);
-                            const size_t base = ((((size_t)ct * L.nchunk6 + chunk) * 9 + tap) * 2 + m) * 3;
-                            packed[((base + 0) * 64 + lane) * 8 + j] = h0;
-                            packed[((base + 1) * 64 + lane) * 8 + j] = h1;
-                            packed[((base + 2) * 64 + lane) * 8 + j] = h2;
+                            uint16_t h[3];
+                            host_split(SP, v, h);
+                            const size_t base = ((((size_t)ct * L.nchunk6 + chunk) * 9 + tap) * 2 + m) * SP;
+                            for (int sp = 0; sp < SP; ++sp) packed[((base + sp) * 64 + lane) * 8 + j] = h[sp];
                         }
 }
 
 // 2x2 / stride-2 layers: pre-split A fragments for k_conv6s
-//   uint4 index = ((((ct*nsteps + g)*2 + plane)*2 + m)*3 + split)*64 + lane, element j, k = 8*(lane>>5) + j
+//   uint4 index = ((((ct*nsteps + g)*2 + plane)*2 + m)*SP + split)*64 + lane, element j, k = 8*(lane>>5) + j
 //   DOWN (Conv2d OIHW):          row = ct*64 + m*32 + (lane&31) ; g = chunk*2 + kw ; plane = kh ; ci = chunk*16 + k
 //   UP   (ConvTranspose2d IOHW): ct = cob*2 + kw ; m = kh ; co = cob*32 + (lane&31) ; plane = slice ; ci = g*32 + slice*16 + k
 void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed) {
@@ -708,7 +818,8 @@ void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packe
     L.nsteps6s = up ? (L.Cin + 31) / 32 : 2 * ((L.Cin + CK - 1) / CK);        // real steps
     L.nchunk6 = ((L.nsteps6s + 2) / 3) * 3;                                   // padded with zero-weight steps to a multiple of 3
     L.n_ct6 = up ? 2 * ((L.Cout + 31) / 32) : (L.Cout + 63) / 64;
-    packed.assign((size_t)L.n_ct6 * L.nchunk6 * ASTS * 8, 0);
+    const int SP = L.sp6;
+    packed.assign((size_t)L.n_ct6 * L.nchunk6 * asts6(SP) * 8, 0);
     for (int ct = 0; ct < L.n_ct6; ++ct)
         for (int g = 0; g < L.nsteps6s; ++g)
             for (int plane = 0; plane < 2; ++plane)
@@ -726,15 +837,10 @@ void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packe
                                 if (row >= L.Cout || ci >= L.Cin) continue;
                                 v = w[(((size_t)row * L.Cin + ci) * 2 + kh) * 2 + kw];
                             }
-                            const uint16_t h0 = host_bf16(v);
-                            const float r1 = v - host_bf16_to_f(h0);
-                            const uint16_t h1 = host_bf16(r1);
-                            const float r2 = r1 - host_bf16_to_f(h1);
-                            const uint16_t h2 = host_bf16(r2);
-                            const size_t base = ((((size_t)ct * L.nchunk6 + g) * 2 + plane) * 2 + m) * 3;
-                            packed[((base + 0) * 64 + lane) * 8 + j] = h0;
-                            packed[((base + 1) * 64 + lane) * 8 + j] = h1;
-                            packed[((base + 2) * 64 + lane) * 8 + j] = h2;
+                            uint16_t h[3];
+                            host_split(SP, v, h);
+                            const size_t base = ((((size_t)ct * L.nchunk6 + g) * 2 + plane) * 2 + m) * SP;
+                            for (int sp = 0; sp < SP; ++sp) packed[((base + sp) * 64 + lane) * 8 + j] = h[sp];
                         }
 }
 
@@ -755,10 +861,16 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.nsteps = L.nchunk6; A.nsteps_real = L.nsteps6s; A.n_ct = L.n_ct6;
+    A.range_flag = ctx->net.d_range_flag;
     A.tiles_h = (A.GH + STH - 1) / STH; A.tiles_w = (A.GW + STW - 1) / STW;
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;
-    if (up) k_conv6s<1><<<dim3(grid), dim3(NT6), conv6s_lds(), ctx->stream>>>(A);
-    else k_conv6s<0><<<dim3(grid), dim3(NT6), conv6s_lds(), ctx->stream>>>(A);
+    if (L.sp6 == 2) {
+        if (up) k_conv6s<1, 2><<<dim3(grid), dim3(NT6), conv6s_lds(2), ctx->stream>>>(A);
+        else k_conv6s<0, 2><<<dim3(grid), dim3(NT6), conv6s_lds(2), ctx->stream>>>(A);
+    } else {
+        if (up) k_conv6s<1, 3><<<dim3(grid), dim3(NT6), conv6s_lds(3), ctx->stream>>>(A);
+        else k_conv6s<0, 3><<<dim3(grid), dim3(NT6), conv6s_lds(3), ctx->stream>>>(A);
+    }
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -798,7 +910,7 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             k_conv6_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(
                 net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.base1(), add1 ? add1->base1() : nullptr, add2 ? add2->base1() : nullptr,
                 add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(),
-                L.Cout, in.H, in.W, out.hp, (int)out.plane(), relu_out, total);
+                L.Cout, in.H, in.W, out.hp, (int)out.plane(), relu_out, total, (L.sp6 == 2) ? ctx->net.d_range_flag : nullptr);
             QMRI_HIP(ctx, hipGetLastError());
             return QMRI_OK;
         }

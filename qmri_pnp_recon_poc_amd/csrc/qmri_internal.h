@@ -128,7 +128,8 @@ struct ConvLayer {
     size_t wp_floats;
     void* d_tab;             // tile table {cout tile, ow0, oh0, batch} for (tab_B, tab_MT)
     int tab_B, tab_MT;
-    void* wp6 = nullptr;     // 3x3 layers: weights split into bf16 triples, MFMA A-fragment order (conv6_kernels.hip)
+    void* wp6 = nullptr;     // weights split into f16 pairs (sp6 == 2) or bf16 triples (sp6 == 3), MFMA A-fragment order (conv6_kernels.hip)
+    int sp6 = 2;             // pieces per fp32 operand of the matrix-core path
     int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks (2x2 layers: K steps), 64-row output tiles of wp6
     int nsteps6s = 0;             // 2x2 layers: K steps that carry weights (nchunk6 is padded to a multiple of 3)
 };
@@ -160,6 +161,9 @@ struct NetPlan {
     bool counter_by_memset = false;  // graph mode: the queue is reset before every launch instead
     hipGraphExec_t fwd_graph[9] = {};  // captured forward pass per batch size 1..8 (index B), null until the second call
     int fwd_calls[9] = {};
+    unsigned* d_range_flag = nullptr;   // f16 scheme: raised by a conv kernel whose output leaves the f16-splittable range
+    int sp6 = 2;                     // scheme the layers are packed for
+    std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
@@ -216,7 +220,7 @@ struct qmri_ctx {
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_state = nullptr;      // LSQR state copied to the host
-    bool conv6_attr[3] = {false, false, false};   // dynamic LDS size of k_conv6 allowed
+    bool conv6_attr[3][2] = {{false, false}, {false, false}, {false, false}};   // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
 };
@@ -262,6 +266,8 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
 int conv_cin_pad(ConvKind kind, int Cin);
 // bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
 bool conv6_enabled();
+int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (QMRI_CONV_SCHEME=bf16x6)
+bool conv6_weights_fit_f16(const float* w, size_t n);
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out);
