@@ -12,11 +12,11 @@ one GPU and reconstructs its own slice (slices are independent: weak scaling, no
 timed region starts.  Data and weights are synthetic (seeded; the reference ships neither).
 
 The JSON line also carries
-  roofline     -- the dominant kernel (k_conv6: conv3x3 as implicit GEMM on v_mfma_f32_32x32x16_bf16, every fp32 operand
-                  split exactly into three bf16 pieces, six MFMA products per fp32-equivalent product): MFMA FLOP executed
-                  per launch (6 x the algorithmic 2*Cout*Cin*9*H*W) / mean launch duration measured live with HIP events on
-                  the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak; `fp32_equivalent_tflops` is the
-                  algorithmic rate
+  roofline     -- the dominant kernel (k_conv6: conv3x3 as implicit GEMM on v_mfma_f32_32x32x16_f16, every fp32 operand
+                  split into two f16 pieces (hi, scaled residual), three MFMA products per fp32-equivalent product; with
+                  QMRI_CONV_SCHEME=bf16x6: three bf16 pieces, six products): MFMA FLOP executed per launch (3 x, resp. 6 x
+                  the algorithmic 2*Cout*Cin*9*H*W) / mean launch duration measured live with HIP events on the launch
+                  stream, against the 2.5 PFLOP/s dense f16/bf16 MFMA peak; `fp32_equivalent_tflops` is the algorithmic rate
   cpu_baseline -- the CPU oracle (a C/OpenMP restatement of the shipped algorithm, `kind: port`) timed on this
                   box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 `--workload slices` instead times whole slices (100 ADMM iterations + dictionary match) over a per-GPU batch.
@@ -33,8 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
-BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16, 32 cycles)
-SPLIT_PRODUCTS = 6                    # bf16 x bf16 MFMA products per fp32-equivalent product (conv6_kernels.hip)
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 / f16 matrix peak (v_mfma_f32_32x32x16_{bf16,f16}, 32 cycles)
+BF16X6 = os.environ.get("QMRI_CONV_SCHEME", "") == "bf16x6"
+SPLIT_PRODUCTS = 6 if BF16X6 else 3   # MFMA products per fp32-equivalent product (conv6_kernels.hip: bf16 x 6 / f16 x 3)
+SCHEME_TEXT = ("v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate" if BF16X6 else
+               "v_mfma_f32_32x32x16_f16, operands split into f16 (hi, scaled residual), 3 products, f32 accumulate")
 # HBM-side bytes per launch of the dominant kernel at the 224 x 224 x 64 level, from two separate rocprofv3 --pmc passes
 # (FETCH_SIZE, WRITE_SIZE; profiles/r01_d_pmc_conv_traffic.txt): 33 073 KB + 11 956 KB, raw counters.  Algorithmic: input with
 # halo 16.3 MB + residual 12.8 MB (every second layer) + output 12.8 MB + weights 0.2 MB per XCD.
@@ -180,7 +183,7 @@ def main():
                         "flop_per_launch": CONV3X3_FLOP * B}
             else:
                 ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
-                roof = {"kernel": "k_conv6 (implicit-GEMM conv3x3 on v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate)",
+                roof = {"kernel": f"k_conv6 (implicit-GEMM conv3x3 on {SCHEME_TEXT})",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": CONV6_PMC_TRAFFIC_BYTES * B, "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches_timed": int(pr["n_conv3x3"]), "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B,
@@ -221,7 +224,7 @@ def main():
             metric, unit = "ADMM iters/sec (224x224x10 TSMI, spiral mask)", "ADMM iters/s"
             cfg = {"workload": "cut3 224x224x10 single slice per GPU, spiral mask S=771 T=200, PnP-ADMM + 10-channel UNetRes (DRUNet) denoiser",
                    "solver": args.solver, "admm_iters": args.steps, "dc_dtype": "f64",
-                   "denoiser_arith": "f32 results: 3x3 convs as 3-way bf16 split x 6 MFMA products with f32 accumulation, 2x2 convs on the f32 MFMA",
+                   "denoiser_arith": "f32 results: all convs on " + SCHEME_TEXT,
                    "parallelism": f"slice-parallel x{world} (no collective)"}
             ms_per_step = dt / max(args.steps, 1) * 1e3
         else:

@@ -250,10 +250,12 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         }
         // prologue: all of B(chunk 0), A(0) and A(1); then the requests for the stores of iterations 0 and 1.
         // (All of the first chunk is requested at once -- one memory latency, not three.)
+        C6_STAMP(2, 0);
         LOAD_A(0, ra0) LOAD_B(0, 0, rb0)
         LOAD_A(1, ra1) LOAD_B(0, 1, rb1)
         LOAD_A(1, ra2) LOAD_B(0, 2, rb2)
         gwait<2 * NLOAD>(ra0, rb0);
+        C6_STAMP(3, 0);
         STORE_A(0, ra0) STORE_B(0, 0, rb0)
         gwait<NLOAD>(ra1, rb1);
         STORE_A(1, ra1) STORE_B(0, 1, rb1)
@@ -316,8 +318,26 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         const uint4* ab = Abuf + lane;
         const uint4* bb = Bbuf + (c & 1) * (SP * 2 * NPX) + h2 * NPX + pxl;
         u32x4 bf[2][NCT][SP], af[2][MW][SP];
+        auto frag_a = [&](int T, int set, int m, int sp) __attribute__((always_inline)) {
+            const int kh = T / 3, kw = T - 3 * kh;
+            af[set][m][sp] = __builtin_bit_cast(u32x4, ab[kh * AST + ((kw * 2 + (m0 + m)) * SP + sp) * 64]);
+        };
+        auto frag_b = [&](int T, int set, int n, int sp) __attribute__((always_inline)) {
+            const int kh = T / 3, kw = T - 3 * kh;
+            bf[set][n][sp] = __builtin_bit_cast(u32x4, bb[sp * 2 * NPX + kw * IHP + kh + 8 * n]);
+        };
         auto frags = [&](int T, int set) __attribute__((always_inline)) {
             const int kh = T / 3, kw = T - 3 * kh;
+            if constexpr (SP == 2) {
+                // LDS returns data in request order: request in the order the MFMAs consume, so that the first products
+                // of the next tap wait for two fragments, not for all of them
+                frag_a(T, set, 0, 0); frag_b(T, set, 0, 0); frag_a(T, set, 0, 1); frag_b(T, set, 0, 1);
+#pragma unroll
+                for (int n = 1; n < NCT; ++n) { frag_b(T, set, n, 0); frag_b(T, set, n, 1); }
+#pragma unroll
+                for (int m = 1; m < MW; ++m) { frag_a(T, set, m, 0); frag_a(T, set, m, 1); }
+                return;
+            }
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
@@ -347,11 +367,11 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                         a_ = mfma_b(af[cur][m][0], bf[cur][n][0], a_);
                         acc[m][n] = a_;
                     } else {
+                        acc[m][n] = mfma_h(af[cur][m][0], bf[cur][n][0], acc[m][n]);
                         f32x16 l_ = accl[m][n];
                         l_ = mfma_h(af[cur][m][1], bf[cur][n][0], l_);
                         l_ = mfma_h(af[cur][m][0], bf[cur][n][1], l_);
                         accl[m][n] = l_;
-                        acc[m][n] = mfma_h(af[cur][m][0], bf[cur][n][0], acc[m][n]);
                     }
                 }
             if (T % 3 == 2) {

@@ -42,6 +42,43 @@ def test_checkpoint_and_onnx_files_to_engine(engine_mod, tmp_path):
     e.close()
 
 
+def test_f16_range_guard_falls_back_to_bf16_scheme(engine_mod):
+    """Activations beyond the f16-splittable range (|x| > 6e4) trip the guard of the default f16 x 3 scheme; the call is
+    then repeated on the bf16 x 6 scheme (no range limit) and still returns the network's fp32 result.  UNetRes is
+    bias-free with ReLU, so net(c x) = c net(x): the golden output scaled by c is the expected value."""
+    g = np.load(os.path.join(GOLDEN, "unetres_tiny_10ch.npz"))
+    nc, nb = tuple(int(v) for v in g["nc"]), int(g["nb"])
+    e = engine_mod.Engine(0)
+    e.set_denoiser(g["weights"], 32, 32, in_nc=10, out_nc=10, nc=nc, nb=nb)
+    x = g["x"].transpose(1, 2, 0).astype(np.float64)
+    for c in (3.0e3, 1.0e7):                                        # inside the range / input and activations far outside
+        y = e.denoise(c * x).transpose(2, 0, 1)
+        assert np.all(np.isfinite(y))
+        assert rel_err(y, c * g["y"].astype(np.float64)) < 2e-5
+    y = e.denoise(x).transpose(2, 0, 1)                             # (stays on the bf16 scheme; still right)
+    assert rel_err(y, g["y"]) < 2e-5
+    e.close()
+
+
+def test_bf16x6_scheme_selectable():
+    """QMRI_CONV_SCHEME=bf16x6 (read once per process) runs the six-product kernels: same golden vector, own process."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from qmri_pnp_recon_poc_amd import engine as E\n"
+        "g = np.load(%r)\n"
+        "e = E.Engine(0)\n"
+        "e.set_denoiser(g['weights'], 32, 32, in_nc=11, out_nc=10, nc=tuple(int(v) for v in g['nc']), nb=int(g['nb']))\n"
+        "y = e.denoise(g['x'].transpose(1, 2, 0).astype(np.float64)).transpose(2, 0, 1)\n"
+        "print(float(np.linalg.norm(y - g['y']) / np.linalg.norm(g['y'])))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(GOLDEN, "unetres_tiny_11ch.npz"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, QMRI_CONV_SCHEME="bf16x6"), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert float(r.stdout.strip().splitlines()[-1]) < 2e-5
+
+
 def test_full_unetres_64_vs_golden(engine_mod, synth):
     g = np.load(os.path.join(GOLDEN, "unetres_full_64.npz"))
     w = synth.random_weights(seed=1)
