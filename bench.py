@@ -39,9 +39,9 @@ SPLIT_PRODUCTS = 6 if BF16X6 else 3   # MFMA products per fp32-equivalent produc
 SCHEME_TEXT = ("v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate" if BF16X6 else
                "v_mfma_f32_32x32x16_f16, operands split into f16 (hi, scaled residual), 3 products, f32 accumulate")
 # HBM-side bytes per launch of the dominant kernel at the 224 x 224 x 64 level, from two separate rocprofv3 --pmc passes
-# (FETCH_SIZE, WRITE_SIZE; profiles/r01_d_pmc_conv_traffic.txt): 33 073 KB + 11 956 KB, raw counters.  Algorithmic: input with
+# (FETCH_SIZE, WRITE_SIZE; profiles/r01_g_pmc_conv_traffic.txt): 32 803 KB + 11 956 KB, raw counters.  Algorithmic: input with
 # halo 16.3 MB + residual 12.8 MB (every second layer) + output 12.8 MB + weights 0.2 MB per XCD.
-CONV6_PMC_TRAFFIC_BYTES = (33073 + 11956) * 1024
+CONV6_PMC_TRAFFIC_BYTES = (32803 + 11956) * 1024
 CONV3X3_FLOP = 2 * 64 * 64 * 9 * 224 * 224      # 3 699 376 128: identical at all four UNetRes levels
 DENOISER_FLOP = 213_253_619_712                 # SURVEY.md section 8d (10-channel UNetRes at 224 x 224)
 

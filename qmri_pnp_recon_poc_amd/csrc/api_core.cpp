@@ -92,6 +92,7 @@ extern "C" int qmri_destroy(qmri_ctx* ctx) {
     qmri_free_dict(ctx);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_state) (void)hipEventDestroy(ctx->ev_state);
+    for (hipEvent_t e : ctx->chain) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return QMRI_OK;
@@ -578,6 +579,35 @@ extern "C" int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out) {
     if (!ctx || !ctx->op.ks.stamps) return QMRI_ERR_STATE;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     QMRI_HIP(ctx, hipMemcpy(out, ctx->op.ks.stamps, (size_t)2 * 512 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return QMRI_OK;
+}
+
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (ctx->prof_level < 2) return QMRI_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return QMRI_OK;
+    while (ctx->chain.size() < ctx->chain_n + 2) {
+        hipEvent_t e = nullptr;
+        QMRI_HIP(ctx, hipEventCreate(&e));
+        ctx->chain.push_back(e);
+    }
+    *start = ctx->chain[ctx->chain_n];
+    *stop = ctx->chain[ctx->chain_n + 1];
+    ctx->chain_n += 2;
+    return QMRI_OK;
+}
+
+int qmri_prof_chain_finish(qmri_ctx* ctx) {
+    if (ctx->prof_level < 2 || ctx->chain_n == 0) return QMRI_OK;
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < ctx->chain_n; i += 2) {
+        float ms = 0.f;
+        QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->chain[i], ctx->chain[i + 1]));
+        ctx->prof.ms_conv3x3 += ms;
+        ctx->prof.n_conv3x3 += 1;
+    }
+    ctx->chain_n = 0;
     return QMRI_OK;
 }
 

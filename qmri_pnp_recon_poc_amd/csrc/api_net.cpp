@@ -203,18 +203,7 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
 // one conv launch with optional per-launch timing of the dominant kernel (profile level 2)
 static int run_conv(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                     const PTensor* add2, int relu) {
-    const bool timed = ctx->prof_level >= 2 && (L.kind == CONV_3X3 || L.kind == CONV_3X3N) && L.Cin >= 64 && L.Cout >= 64;
-    if (timed) QMRI_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    QMRI_TRY(conv_launch(ctx, L, B, in, out, add1, add2, relu));
-    if (timed) {
-        QMRI_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-        QMRI_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
-        float ms = 0.f;
-        QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-        ctx->prof.ms_conv3x3 += ms;
-        ctx->prof.n_conv3x3 += 1;
-    }
-    return QMRI_OK;
+    return conv_launch(ctx, L, B, in, out, add1, add2, relu);     // (profile level 2: the launchers mark their kernels, qmri_prof_mark)
 }
 
 // nb ResBlocks: cur <- cur + conv(relu(conv(cur)))  (basicblock.py:211-223).  `src` is the block input of the first
@@ -245,7 +234,7 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
             QMRI_TRY(run_conv(ctx, p.layers[l], B, *in, *out, nullptr, nullptr, l != nl - 1));
             in = out;
         }
-        return QMRI_OK;
+        return qmri_prof_chain_finish(ctx);
     }
     // UNetRes.forward, network_unet.py:106-117
     QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.in32, p.x[0], nullptr, nullptr, 0));                       // x1 = m_head(x0)
@@ -259,7 +248,7 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
         QMRI_TRY(run_resblocks(ctx, li, nb, B, p.a[l - 1], p.a[l - 1], p.t[l - 1], &p.x[l - 1]));
     }
     QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[0], p.out32, nullptr, nullptr, 0));                      // m_tail(x + x1)
-    return QMRI_OK;
+    return qmri_prof_chain_finish(ctx);
 }
 
 // The forward pass is a fixed sequence of ~65 dependent launches with fixed arguments.  With QMRI_GRAPH=1 it is captured

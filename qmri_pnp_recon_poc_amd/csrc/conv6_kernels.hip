@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "qmri_internal.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -726,7 +727,10 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
         ctx->conv6_attr[CFG][SP - 2] = true;
     }
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
-    k_conv6<CFG, SP><<<dim3(grid), dim3(NT6), conv6_lds<CFG>(SP), ctx->stream>>>(A);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));                  // (profile level 2 only)
+    if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP>), dim3(grid), dim3(NT6), (std::uint32_t)conv6_lds<CFG>(SP), ctx->stream, e0, e1, 0, A);
+    else k_conv6<CFG, SP><<<dim3(grid), dim3(NT6), conv6_lds<CFG>(SP), ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }

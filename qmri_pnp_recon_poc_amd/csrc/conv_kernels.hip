@@ -27,6 +27,7 @@
 //     ReLU, store) while the MFMA waves are already computing.
 // Results are deterministic: every sum has a fixed order; the queue only decides which workgroup does a tile.
 #include "qmri_internal.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace {
@@ -423,7 +424,11 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         A.base = ctx->net.counter_base;
         ctx->net.counter_base += (unsigned)(ntiles + 2 * grid);
     }
-    if (MT == 2) k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2><<<dim3(grid), dim3(NT), 0, ctx->stream>>>(A);
+    hipEvent_t e0 = nullptr, e1 = nullptr;                  // profile level 2: the kernel's own dispatch timestamps
+    if ((KIND == CONV_3X3 || KIND == CONV_3X3N) && L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
+    if (e0 && MT == 2) hipExtLaunchKernelGGL((k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2>), dim3(grid), dim3(NT), 0, ctx->stream, e0, e1, 0, A);
+    else if (e0) hipExtLaunchKernelGGL((k_conv<KIND, 1>), dim3(grid), dim3(NT), 0, ctx->stream, e0, e1, 0, A);
+    else if (MT == 2) k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2><<<dim3(grid), dim3(NT), 0, ctx->stream>>>(A);
     else k_conv<KIND, 1><<<dim3(grid), dim3(NT), 0, ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;

@@ -220,6 +220,11 @@ struct qmri_ctx {
     qmri_profile prof{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_state = nullptr;      // LSQR state copied to the host
+    // profile level 2: the 3x3 conv kernels are launched with hipExtLaunchKernelGGL and a (start, stop) event pair each,
+    // which takes the timestamps of the kernel's own dispatch packet -- the duration rocprofv3 --kernel-trace reports --
+    // without putting extra packets between dependent kernels (event records in the stream add 3-5 us per kernel)
+    std::vector<hipEvent_t> chain;      // pairs: [2i] start, [2i+1] stop
+    size_t chain_n = 0;                 // events handed out in the current forward
     bool conv6_attr[3][2] = {{false, false}, {false, false}, {false, false}};   // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
@@ -265,6 +270,8 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
                 const PTensor* add2, int relu_out);
 int conv_cin_pad(ConvKind kind, int Cin);
 // bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop);   // profile level 2: next event pair of the forward (else nullptrs)
+int qmri_prof_chain_finish(qmri_ctx* ctx);                 // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3
 bool conv6_enabled();
 int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (QMRI_CONV_SCHEME=bf16x6)
 bool conv6_weights_fit_f16(const float* w, size_t n);
