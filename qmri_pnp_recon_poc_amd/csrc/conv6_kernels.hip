@@ -1,20 +1,23 @@
-// conv6_kernels.hip -- 3x3 convolutions of the UNetRes / DRUNet denoiser on the bf16 matrix cores with fp32-level accuracy.
+// conv6_kernels.hip -- the convolutions of the UNetRes / DRUNet denoiser on the 16-bit matrix cores with fp32-level accuracy.
 //
 // Reference semantics: denoiseImage_PnP_ADMM.m:1-117 runs the network in single precision; layers as in
-// oracle/orc_net.c (Conv2d 3x3, stride 1, pad 1, no bias; optional ReLU; residual adds).
+// oracle/orc_net.c (Conv2d 3x3, stride 1, pad 1, no bias; optional ReLU; residual adds; 2x2 / stride-2 (transposed) convs).
 //
-// Method ("bf16 x 6"): every fp32 operand is split exactly into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 mantissa
-// bits; the residuals x - x0 and x - x0 - x1 are exact in fp32).  A product w*a then expands into nine bf16 x bf16
-// products, each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the six of order >= 2^-16
-//     w0 a0 + (w0 a1 + w1 a0) + (w1 a1 + w0 a2 + w2 a0)
-// are accumulated, the three dropped ones are of order 2^-24 and below, i.e. at the rounding level of an fp32 multiply.
-// The result differs from an fp32 FMA chain by accumulation rounding only (tools/bf16x6_check.py: 1e-7 relative, the
-// same as between two fp32 summation orders).  The bf16 MFMA is 16x the rate of v_mfma_f32_32x32x2_f32 (32 cycles for
-// 32x32x16 vs 64 for 32x32x2), so six of them per fp32-equivalent step are still 2.7x faster than the fp32 matrix path.
+// Every fp32 operand is split into SP 16-bit pieces and the piece products that matter are issued as 32x32x16 MFMAs with
+// fp32 accumulation (32 cycles each, 16x the rate of v_mfma_f32_32x32x2_f32).  Two schemes, one kernel template:
+//   SP = 2, "f16 x 3" (default): x = hi + lo'/2^11, hi = f16(x), lo' = f16((x - hi) * 2^11) (the scaling keeps lo' normal
+//       whenever x is).  hi*hi goes into one accumulator, hi*lo' + lo'*hi into a second one that is folded in with 2^-11 in
+//       the epilogue; lo*lo (2^-22) is dropped.  Per-operand error <= 2^-22 |x|: the result differs from an fp32 FMA chain
+//       at the fp32 rounding level (tools/bf16x6_check.py: 2.2e-7 relative on K = 576, fp32 matmul 2.2e-7).  f16 carries
+//       |x| <= 65504: weights are checked on the host, every epilogue raises Conv6Args::range_flag when an output is not
+//       finite or above 6e4, and the callers then re-pack for SP = 3 and repeat (api_net.cpp: net_range_tripped).
+//   SP = 3, "bf16 x 6" (QMRI_CONV_SCHEME=bf16x6, and the fallback): x = x0 + x1 + x2 exactly (8 + 8 + 8 mantissa bits, no range
+//       limit); of the nine piece products the six of order >= 2^-16,  w0 a0 + (w0 a1 + w1 a0) + (w1 a1 + w0 a2 + w2 a0),
+//       are accumulated (8.6e-8 on the same tile).  Twice the matrix-core cycles of SP = 2.
 //
 // Implicit GEMM per workgroup: 64 output channels x (TH x TW) pixels, K = Cin*9 walked in chunks of 16 channels x 3 taps.
-//   waves 0-3  MFMA: per tap and cout tile 3 A fragments (weights, pre-split and pre-ordered on the host) and 3 B
-//              fragments (activations) from LDS feed 6 MFMAs; one accumulation chain per 32x32 tile
+//   waves 0-3  MFMA: per tap SP A fragments per cout tile (weights, pre-split and pre-ordered on the host) and SP B
+//              fragments per pixel block (activations) from LDS feed 3 (6) MFMAs per 32x32 tile
 //   waves 4-7  loaders: weights global -> LDS (plain copy), activations global fp32 planes -> split -> LDS [pixel][8 ch],
 //              requested two steps ahead and kept in registers for one
 // Tensors stay fp32 padded planes in HBM (qmri_internal.h PTensor), so this kernel is interchangeable with k_conv.
@@ -482,7 +485,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 template <int CFG, int SP> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP>(A); }
 
 // =====================================================================================================================
-// k_conv6s : the 2x2 / stride-2 layers on the same bf16 x 6 scheme.
+// k_conv6s : the 2x2 / stride-2 layers on the same operand-splitting schemes.
 //   DOWN  Conv2d(k=2, s=2)           out[co][oh][ow]       = sum_ci,kh,kw w[co][ci][kh][kw] in[ci][2oh+kh][2ow+kw]
 //   UP    ConvTranspose2d(k=2, s=2)  out[co][2ih+kh][2iw+kw] = sum_ci     w[ci][co][kh][kw] in[ci][ih][iw]
 // Both are GEMMs over an 8h x 8w pixel tile (output pixels for DOWN, input pixels for UP) whose K steps hold two "planes":
@@ -491,7 +494,7 @@ template <int CFG, int SP> __global__ __launch_bounds__(NT6) void k_conv6(const 
 //         output channels for one kw, so the LDS output tile interleaves the two kh rows and stores contiguous h.
 // Waves 0-3: 2 row tiles x 2 pixel blocks (8h x 4w), 12 MFMAs per step; waves 4-7: loaders as in k_conv6 (asm requests two
 // steps ahead, counted waits), each thread carries 2 channels x 4 consecutive h (one aligned float4 per channel).
-// 49 KB of LDS: three workgroups share a CU and hide each other's barriers.
+// 32 KB (SP = 2) / 49 KB (SP = 3) of LDS: several workgroups share a CU and hide each other's barriers.
 // =====================================================================================================================
 constexpr int asts6(int SP) { return 2 * 2 * SP * 64; }   // uint4 per step of A: 2 planes x 2 row tiles x SP splits x 64 lanes
 constexpr int STH = 8, STW = 8;           // pixel tile
