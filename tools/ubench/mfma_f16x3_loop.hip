@@ -13,12 +13,26 @@ __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int SYNC, int READS>
+// DATA: 0 = nearly constant operands, 1 = pseudo-random f16 values in [-2, 2) (every bit of the mantissa toggles)
+__device__ __forceinline__ unsigned rnd16(unsigned& st) {
+    st = st * 1664525u + 1013904223u;
+    const unsigned m = (st >> 9) & 0x3FFu, e = 13u + ((st >> 20) & 3u), sg = (st >> 31) << 15;      // exponents 13..16 -> 0.25 .. 4
+    return sg | (e << 10) | m;
+}
+template <int SYNC, int READS, int DATA>
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, int nchunk) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;
     uint4* Bbuf = Abuf + 3 * AST;
-    for (int i = threadIdx.x; i < 3 * AST + 2 * SP * 2 * NPX; i += 256) Abuf[i] = make_uint4(0x3c003c00u + (i & 7), 0x3c013c00u, 0x3c003c02u, 0x3c033c00u);
+    for (int i = threadIdx.x; i < 3 * AST + 2 * SP * 2 * NPX; i += 256) {
+        if (DATA == 0) Abuf[i] = make_uint4(0x3c003c00u + (i & 7), 0x3c013c00u, 0x3c003c02u, 0x3c033c00u);
+        else {
+            unsigned st = i * 2654435761u + blockIdx.x;
+            uint4 v;
+            v.x = rnd16(st) | (rnd16(st) << 16); v.y = rnd16(st) | (rnd16(st) << 16); v.z = rnd16(st) | (rnd16(st) << 16); v.w = rnd16(st) | (rnd16(st) << 16);
+            Abuf[i] = v;
+        }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h2 = lane >> 5;
     const int pbw = 4 * wave, pbh = 0, m0 = 0;
@@ -73,17 +87,17 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int SYNC, int READS> void run(const char* name) {
+template <int SYNC, int READS, int DATA> void run(const char* name) {
     const int nchunk = 400, nwg = 256;
     const size_t lds = (size_t)(3 * AST + 2 * SP * 2 * NPX) * 16;
     float* out; unsigned long long* cyc;
     hipMalloc(&out, nwg * 256 * 4); hipMalloc(&cyc, nwg * 8);
-    hipFuncSetAttribute((const void*)k<SYNC, READS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k<SYNC, READS, DATA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<SYNC, READS><<<nwg, 256, lds>>>(out, cyc, 4);
+    k<SYNC, READS, DATA><<<nwg, 256, lds>>>(out, cyc, 4);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<SYNC, READS><<<nwg, 256, lds>>>(out, cyc, nchunk);
+    k<SYNC, READS, DATA><<<nwg, 256, lds>>>(out, cyc, nchunk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[256]; hipMemcpy(h, cyc, nwg * 8, hipMemcpyDeviceToHost);
@@ -93,9 +107,12 @@ template <int SYNC, int READS> void run(const char* name) {
     printf("%-44s cycles/MFMA %.1f  (per 36-MFMA step %.0f)  ns/MFMA %.2f  clock %.2f GHz\n", name, c / nm, 36 * c / nm, ms * 1e6 / nm, c / (ms * 1e6));
 }
 int main() {
-    run<0, 2>("A+B fragments from LDS, no sync");
-    run<1, 2>("A+B fragments from LDS, barrier per step");
-    run<0, 1>("B fragments from LDS only, no sync");
-    run<0, 0>("no LDS reads, no sync");
+    run<0, 2, 0>("A+B fragments from LDS, no sync");
+    run<1, 2, 0>("A+B fragments from LDS, barrier per step");
+    run<0, 1, 0>("B fragments from LDS only, no sync");
+    run<0, 0, 0>("no LDS reads, no sync");
+    run<0, 2, 1>("random operands: A+B from LDS, no sync");
+    run<1, 2, 1>("random operands: A+B from LDS, barrier/step");
+    run<0, 0, 1>("random operands: no LDS reads, no sync");
     return 0;
 }
