@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["admm", "slices"], default="admm")
     ap.add_argument("--slices-per-gpu", type=int, default=15)
-    ap.add_argument("--batch", type=int, default=5, help="slices advanced together on one GPU (workload=slices); 5 x 196 conv tiles fill 256 CUs to 96 %")
+    ap.add_argument("--batch", type=int, default=15, help="slices advanced together on one GPU (workload=slices): the whole per-GPU share in one launch sequence "
+                    "(measured 8.8 / 9.7 / 10.1 slices/s at 5 / 8 / 15)")
     ap.add_argument("--solver", choices=["lsqr", "direct"], default="lsqr")
     ap.add_argument("--dict-k", type=int, nargs=2, default=[384, 256], help="dictionary grid n_t1 n_t2 (K = product)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
