@@ -12,6 +12,7 @@
  *   Net = importONNXNetwork(denoiser_path, ...)   main_recon_tsmis_FFT.m:138 (weights only)      -> qmri_onnx_read_unetres
  *   x = PnP_ADMM(y, param)                        PnP_ADMM.m:1                      -> qmri_pnp_admm
  *   out = mrf_dtm_cpu(dict, data, par)            mrf_dtm_cpu.m:1                   -> qmri_set_dictionary, qmri_dict_match
+ *   x = FISTA_deep(data, param) (LRTV option)     FISTA_deep.m:1, main_recon_tsmis_FFT.m:273-282 -> qmri_lrtv, qmri_prox_tv, qmri_norm_tv
  *
  * Conventions (frozen):
  *   - every function returns 0 on success or a negative qmri_status; the message is qmri_last_error(ctx).
@@ -133,6 +134,35 @@ int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_params* p, const
 /* nslices independent slices, device-resident y / x0 / gt / x_out (slice-major); diag/lsqr outputs are host. */
 int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* p, const void* d_x0,
                       const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out);
+
+/* ---- LRTV option: x = FISTA_deep(data, param), main_recon_tsmis_FFT.m:273-282 -------------------------- */
+/* FISTA with backtracking on 0.5 |y - F.forward(x)|^2 + K |x|_TV (FISTA_deep.m:31-104); the TV prox is unlocbox's
+ * prox_tv (prox_tv.m:99-203) on the stacked image [real(x); imag(x)] of 2N rows x M*s columns (FISTA_deep.m:66,75). */
+typedef struct {
+    double  K;           /* param.K = 4e-5 (:275); 0 skips the prox (FISTA_deep.m:74) */
+    int32_t iters;       /* param.iter = 200 (:276) */
+    double  step;        /* param.step; <= 0: numel(X0)/numel(Y) (:277) */
+    double  tol;         /* param.tol = 1e-4: stop when |obj - obj_prev| / obj < tol (FISTA_deep.m:103) */
+    int32_t backtrack;   /* param.backtrack = 1 (:279) */
+    double  prox_tol;    /* prox_tv param.tol; <= 0: 10e-4 (prox_tv.m:99) */
+    int32_t prox_maxit;  /* prox_tv param.maxit; <= 0: 200 (prox_tv.m:101) */
+} qmri_lrtv_params;
+typedef struct {
+    int32_t iters;             /* FISTA iterations performed */
+    int32_t halvings;          /* 'reducing stepsize...' events */
+    double  step;              /* final step size */
+    double  obj;               /* last objective 0.5 |y - Fx|^2 + K |x|_TV */
+    int32_t prox_calls;
+    int32_t prox_iters_total;  /* inner iterations over all prox_tv calls */
+} qmri_lrtv_info;
+/* y: m complex doubles (ABI order); x_out: N x M x s complex doubles; info may be NULL.  Needs qmri_set_operator. */
+int qmri_lrtv(qmri_ctx* ctx, const void* y, const qmri_lrtv_params* p, void* x_out, qmri_lrtv_info* info);
+/* [sol, info] = prox_tv(b, gamma, param) on a real column-major R x C image (prox_tv.m:1); host buffers.
+ * iters_out / obj_out (info.iter, the last objective) may be NULL. */
+int qmri_prox_tv(qmri_ctx* ctx, const double* b, int R, int C, double gamma, double tol, int maxit, double* sol,
+                 int32_t* iters_out, double* obj_out);
+/* y = norm_tv(I) (unlocbox/utils/norm_tv.m:45-55), same layout. */
+int qmri_norm_tv(qmri_ctx* ctx, const double* I, int R, int C, double* out);
 
 /* ---- dictionary match: out = mrf_dtm_cpu(dict, data, par), mrf_dtm_cpu.m:1 --------------------------- */
 /* D: K x s column-major unit-norm atoms, normD: K, lut: K x Q column-major (dict.D / .normD / .lut, :8-12). */

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 _SRCS = ["orc_masks.c", "orc_fft.c", "orc_operator.c", "orc_lsqr.c", "orc_net.c", "orc_admm.c",
-         "orc_dictmatch.c", "orc_util.c", "qmri_oracle.h", "orc_internal.h", "Makefile"]
+         "orc_dictmatch.c", "orc_util.c", "orc_lrtv.c", "qmri_oracle.h", "orc_internal.h", "Makefile"]
 
 
 def build(force: bool = False) -> str:
@@ -81,6 +81,9 @@ def lib():
         L.orc_pnp_admm.argtypes = [vp, vp, dp, C.POINTER(AdmmParams), dp, dp, dp, dp, ip]
         L.orc_dict_match.argtypes = [dp, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_double,
                                      fp, fp, fp, ip, fp]
+        L.orc_norm_tv.restype = C.c_double
+        L.orc_norm_tv.argtypes = [dp, C.c_int, C.c_int]
+        L.orc_prox_tv.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(usable_cpus())
@@ -240,6 +243,76 @@ def pnp_admm(op: Operator, net: Net, y, gamma=0.05, iters=100, cg_tol=1e-4, cg_m
     lib().orc_pnp_admm(op.h, net.h, _dp(yin), C.byref(p), _dp(x0in), _dp(gtin), _dp(x), _dp(diag), _ip(li))
     xo = x.view(np.complex128).reshape((op.N, op.M, op.s), order="F")
     return xo, (diag.reshape(iters, 2) if diag is not None else None), li
+
+
+def norm_tv(I):
+    """norm_tv(I) of a real 2-D image (unlocbox/utils/norm_tv.m:45-55)."""
+    I = np.asfortranarray(I, dtype=np.float64)
+    return float(lib().orc_norm_tv(_dp(I), I.shape[0], I.shape[1]))
+
+
+def prox_tv(b, gamma, tol=10e-4, maxit=200):
+    """[sol, info] = prox_tv(b, gamma) with the defaults FISTA_deep.m uses (prox_tv.m:99-104).  Returns (sol, iters, obj)."""
+    b = np.asfortranarray(b, dtype=np.float64)
+    sol = np.empty_like(b, order="F")
+    obj = C.c_double(0.0)
+    it = lib().orc_prox_tv(_dp(b), b.shape[0], b.shape[1], float(gamma), float(tol), int(maxit), _dp(sol), C.byref(obj))
+    return sol, int(it), obj.value
+
+
+def stack_ri(x):
+    """[reshape(real(x),N,[]); reshape(imag(x),N,[])]  (FISTA_deep.m:66,75): N x M x L complex -> 2N x (M L) real."""
+    N = x.shape[0]
+    return np.concatenate([np.real(x).reshape(N, -1, order="F"), np.imag(x).reshape(N, -1, order="F")], axis=0)
+
+
+def unstack_ri(b, shape):
+    N = shape[0]
+    return (b[:N, :] + 1j * b[N:, :]).reshape(shape, order="F")
+
+
+def fista_lrtv(op: Operator, y, K=4e-5, iters=200, step=None, tol=1e-4, backtrack=True):
+    """x = FISTA_deep(data, param)  (FISTA_deep.m:31-104) with the parameters of main_recon_tsmis_FFT.m:274-281.
+    Returns (x, info) with info = dict(iters, obj[], prox_iters[], step, halvings)."""
+    y = np.asarray(y, dtype=np.complex128).ravel()
+    shape = (op.N, op.M, op.s)
+    if step is None:
+        step = (op.N * op.M * op.s) / y.size                               # param.step = numel(X0)/numel(Y), :277
+    x = np.zeros(shape, np.complex128)
+    x2_prev = x.copy()
+    t, obj_prev = 1, 0.0
+    objs, pits, halv = [], [], 0
+    it = 0
+    for it in range(1, iters + 1):
+        err = op.forward(x).ravel() - y
+        grad1 = op.adjoint(err)
+        cvxobj = 0.5 * float(np.vdot(err, err).real)
+        val = norm_tv(stack_ri(x))
+        while True:
+            x2 = x - grad1 * step
+            if K > 0:
+                b, n, _ = prox_tv(stack_ri(x2), step * K)
+                pits.append(n)
+                x2 = unstack_ri(b, shape)
+            if not backtrack:
+                break
+            r2 = op.forward(x2).ravel() - y
+            tmp = 0.5 * float(np.vdot(r2, r2).real)
+            d = (x2 - x).ravel(order="F")
+            if tmp > cvxobj + float(np.real(np.vdot(grad1.ravel(order="F"), d))) + 1.0 / (2 * step) * float(np.vdot(d, d).real):
+                step = step / 2
+                halv += 1
+            else:
+                break
+        x = x2 + (t - 1) / (t + 2) * (x2 - x2_prev)
+        x2_prev = x2
+        t += 1
+        obj = cvxobj + K * val
+        objs.append(obj)
+        if abs(obj - obj_prev) / obj < tol:
+            break
+        obj_prev = obj
+    return x, {"iters": it, "obj": np.array(objs), "prox_iters": np.array(pits, np.int32), "step": step, "halvings": halv}
 
 
 def dict_match(X, D, normD, lut, block_size=1e9, want_mt=True, want_dm=True, want_xfit=False):

@@ -103,6 +103,11 @@ void orc_dict_match(const double* X, int Npix, int s, const float* D, const floa
                     const float* lut, int K, int Q, double block_size, float* qmap, float* pd,
                     float* mt, int32_t* dm, float* Xfit);
 
+/* ---- LRTV option: the unlocbox TV pieces FISTA_deep.m calls (orc_lrtv.c) ------------------------- */
+/* norm_tv.m:45-55 / prox_tv.m:99-203 on a real column-major R x C image; prox returns the iteration count. */
+double orc_norm_tv(const double* I, int R, int C);
+int orc_prox_tv(const double* b, int R, int C, double gamma, double tol, int maxit, double* sol, double* obj_out);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

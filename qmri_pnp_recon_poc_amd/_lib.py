@@ -22,6 +22,7 @@ SYMBOLS = [
     "qmri_net_forward_dev", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_onnx_read_unetres",
+    "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv",
 ]
 
 
@@ -41,6 +42,16 @@ class Problem(C.Structure):
                 ("net", C.POINTER(NetDesc)), ("weights", C.POINTER(C.c_float)), ("weights_nbytes", C.c_size_t),
                 ("K", C.c_int32), ("Q", C.c_int32), ("D", C.POINTER(C.c_float)), ("normD", C.POINTER(C.c_float)),
                 ("lut", C.POINTER(C.c_float)), ("admm", AdmmParams), ("slices_per_launch", C.c_int32)]
+
+
+class LrtvParams(C.Structure):
+    _fields_ = [("K", C.c_double), ("iters", C.c_int32), ("step", C.c_double), ("tol", C.c_double), ("backtrack", C.c_int32),
+                ("prox_tol", C.c_double), ("prox_maxit", C.c_int32)]
+
+
+class LrtvInfo(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("halvings", C.c_int32), ("step", C.c_double), ("obj", C.c_double),
+                ("prox_calls", C.c_int32), ("prox_iters_total", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -100,6 +111,9 @@ def lib() -> C.CDLL:
     L.qmri_net_forward_dev.argtypes = [vp, vp, i, vp]
     L.qmri_pnp_admm.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_pnp_admm_dev.argtypes = [vp, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
+    L.qmri_lrtv.argtypes = [vp, vp, C.POINTER(LrtvParams), vp, C.POINTER(LrtvInfo)]
+    L.qmri_prox_tv.argtypes = [vp, dp, i, i, C.c_double, C.c_double, i, dp, ip, dp]
+    L.qmri_norm_tv.argtypes = [vp, dp, i, i, dp]
     L.qmri_set_dictionary.argtypes = [vp, i, i, i, fp, fp, fp]
     L.qmri_dict_match.argtypes = [vp, vp, i, fp, fp, fp, ip]
     L.qmri_dict_match_dev.argtypes = [vp, vp, i, vp, vp, vp, vp]

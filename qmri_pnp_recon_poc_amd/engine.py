@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AdmmParams, NetDesc, Profile
+from ._lib import AdmmParams, LrtvInfo, LrtvParams, NetDesc, Profile
 
 ARCH_UNETRES, ARCH_SEQ_CONV = 0, 1
 SOLVER_LSQR, SOLVER_DIRECT = 0, 1
@@ -212,6 +212,44 @@ class Engine:
         f = C.POINTER(C.c_float)
         self._check(self.L.qmri_set_dictionary(self.h, K, s, Q, Df.ctypes.data_as(f), nd.ctypes.data_as(f), lf.ctypes.data_as(f)))
         self.dict_shape = (K, s, Q)
+
+    # -- LRTV option ---------------------------------------------------------------------------------
+    def lrtv(self, y, K=4e-5, iters=200, step=None, tol=1e-4, backtrack=True, prox_tol=None, prox_maxit=None):
+        """x = FISTA_deep(data, param)  (FISTA_deep.m:1, parameters of main_recon_tsmis_FFT.m:274-281).
+        Returns (x [N,M,s] complex, info dict)."""
+        if not hasattr(self, "N"):
+            raise ValueError("operator not set")
+        N, M, s = self.N, self.M, self.s
+        p = LrtvParams(float(K), int(iters), float(step) if step else 0.0, float(tol), int(bool(backtrack)),
+                       float(prox_tol) if prox_tol else 0.0, int(prox_maxit) if prox_maxit else 0)
+        yb = _cbuf(y)
+        if yb.size != self.m:
+            raise ValueError(f"y must have {self.m} elements")
+        x = np.empty(N * M * s, np.complex128)
+        info = LrtvInfo()
+        self._check(self.L.qmri_lrtv(self.h, _vp(yb), C.byref(p), _vp(x), C.byref(info)))
+        return x.reshape((N, M, s), order="F"), {k: getattr(info, k) for k, _ in LrtvInfo._fields_}
+
+    def prox_tv(self, b, gamma, tol=10e-4, maxit=200):
+        """[sol, info] = prox_tv(b, gamma)  (unlocbox/prox/prox_tv.m:1) on a real 2-D image.  Returns (sol, iters, obj)."""
+        b = np.asfortranarray(b, dtype=np.float64)
+        if b.ndim != 2:
+            raise ValueError("b must be a 2-D image")
+        sol = np.empty_like(b, order="F")
+        it, obj = C.c_int32(0), C.c_double(0.0)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.qmri_prox_tv(self.h, b.ctypes.data_as(dp), b.shape[0], b.shape[1], float(gamma), float(tol), int(maxit),
+                                        sol.ctypes.data_as(dp), C.byref(it), C.byref(obj)))
+        return sol, int(it.value), float(obj.value)
+
+    def norm_tv(self, I):
+        """y = norm_tv(I)  (unlocbox/utils/norm_tv.m:1)."""
+        I = np.asfortranarray(I, dtype=np.float64)
+        if I.ndim != 2:
+            raise ValueError("I must be a 2-D image")
+        out = C.c_double(0.0)
+        self._check(self.L.qmri_norm_tv(self.h, I.ctypes.data_as(C.POINTER(C.c_double)), I.shape[0], I.shape[1], C.byref(out)))
+        return float(out.value)
 
     def dict_match(self, X, want_mt=True, want_dm=True):
         """out = mrf_dtm_cpu(dict, data, par)  (mrf_dtm_cpu.m:1).  X [..., s] complex -> dict of arrays."""

@@ -11,7 +11,7 @@ Host logic in numpy/scipy; the reconstruction and the match run on the GPU throu
   awgn_measured(y, snr_db, seed)       `awgn(Y, snr, 'measured')` with an explicit seed       :243
   psnr(A, ref) / ssim(A, ref)          MATLAB `psnr` / `ssim` defaults for double images [MathWorks]   :352-372
   metrics(qmap, qmap0, mask, X, X0)    the block :327-374 as a dict
-  recon_tsmis(...)                     the script's main flow for recon_method 'SVD_MRF' | 'PnP_ADMM'  :263-319
+  recon_tsmis(...)                     the script's main flow for recon_method 'SVD_MRF' | 'LRTV' | 'PnP_ADMM'  :263-319
 
 [MathWorks] functions are restated from their documented defaults (no MATLAB here: parity unpinned for them, see
 DESIGN.md section 10): psnr peak value 1 for class double; ssim with an isotropic Gaussian of sigma 1.5 truncated at
@@ -177,7 +177,7 @@ def metrics(qmap, qmap0, foreground_mask, X=None, X0=None):
 def recon_tsmis(dictionary, X0, qmap0, weights=None, recon_method="PnP_ADMM", subsampling_pattern="Spiral",
                 spiral_sampling_curve=771, epi_sampling_rate=0.05, measurements_type="noisy", measurements_noise=30,
                 denoiser_type="single_level", noise_map_std=0.01, residual_noise=False, iters=100, seed=0, Y=None, device=0,
-                net_arch=None):
+                net_arch=None, lrtv_iters=None):
     """main_recon_tsmis_FFT.m:216-374 on already loaded (and cropped) arrays.
 
     dictionary  dict(V, D, normD, lut) (load_dictionary);  X0  N x M x s ground-truth TSMI;  qmap0  N x M x 3
@@ -221,8 +221,10 @@ def recon_tsmis(dictionary, X0, qmap0, weights=None, recon_method="PnP_ADMM", su
                  "X0": F.adjoint(Y), "net": net, "denoiser_type": denoiser_type,
                  "noise_map": R.build_noise_map(noise_map_std, N, M)}                # :166-171
         X = R.PnP_ADMM(np.asarray(Y, dtype=np.complex128), param)
-    elif recon_method == "LRTV":
-        raise NotImplementedError("LRTV (FISTA_deep.m + unlocbox prox_tv) is not part of this build (SURVEY.md section 8f rank 3)")
+    elif recon_method == "LRTV":                                                     # :273-282
+        param = {"K": 4e-5, "iter": 200 if lrtv_iters is None else int(lrtv_iters), "step": X0.size / np.asarray(Y).size, "tol": 1e-4,
+                 "backtrack": 1, "usegpu": 0}
+        X = R.FISTA_deep({"N": M, "M": M, "L": s, "y": np.asarray(Y, dtype=np.complex128), "F": F, "D": []}, param)
     else:
         raise ValueError(f"unknown reconstruction method {recon_method}")
     par = {"f": {"qout": 1, "pdout": 1, "mtout": 0, "Xout": 0, "dmout": 0, "Yout": 0, "verbose": 0}, "fp": {"blockSize": 1e9}}   # :302-309

@@ -8,6 +8,7 @@ pipeline, so this Python mirror is the executable counterpart of the `.m` wrappe
     net = make_net(weights, denoiser_type, residual_noise)  # param.net, main_recon_tsmis_FFT.m:164
     x   = PnP_ADMM(y, param)                                # PnP_ADMM.m:1, param = dict with the reference's field names
     out = mrf_dtm_cpu(dict, data, par)                      # mrf_dtm_cpu.m:1 (name kept; it runs on the GPU)
+    x   = FISTA_deep(data, param)                           # LRTV option, FISTA_deep.m:1 (+ TV_operator, prox_tv, norm_tv)
 """
 from __future__ import annotations
 
@@ -106,6 +107,43 @@ def PnP_ADMM(y, param):
                                      x0=param.get("X0"), gt=param.get("gt_tsmi"), want_diag=param.get("gt_tsmi") is not None)
     PnP_ADMM.last_diagnostics, PnP_ADMM.last_lsqr_iters = diag, li
     return x
+
+
+def FISTA_deep(data, param):
+    """[x] = FISTA_deep(data, param)  (FISTA_deep.m:1): data = dict(N, M, L, y, F, D), param = dict(K, iter, step, tol,
+    backtrack, usegpu) as main_recon_tsmis_FFT.m:274-281 builds them.  F must come from make_F; the whole loop runs on the
+    GPU (param.usegpu is ignored)."""
+    F = data["F"]
+    if not hasattr(F, "_engine"):
+        raise TypeError("data.F must come from make_F of this package")
+    eng = F._engine
+    if (data["N"], data["M"], data["L"]) != (eng.N, eng.M, eng.s) and (data["M"], data["M"], data["L"]) != (eng.N, eng.M, eng.s):
+        raise ValueError("data.N / M / L do not match the operator")       # (the script passes data.N = M, :281)
+    x, info = eng.lrtv(data["y"], K=param["K"], iters=int(param["iter"]), step=param.get("step"), tol=param["tol"],
+                       backtrack=param.get("backtrack", 1))
+    FISTA_deep.last_info = info
+    return x
+
+
+def TV_operator(mode="2D", usegpu=0, device=0):
+    """J = TV_operator('2D', usegpu)  (TV_operator.m:1): J.norm / J.prox applied slice by slice along the third dimension."""
+    if mode != "2D":
+        raise NotImplementedError("only the 2-D operator is on the path (main_recon_tsmis_FFT.m:280)")
+    eng = _engine(device)
+
+    def norm(x2):
+        x2 = np.asarray(x2, dtype=np.float64)
+        x2 = x2[:, :, None] if x2.ndim == 2 else x2
+        return float(sum(eng.norm_tv(x2[:, :, i]) for i in range(x2.shape[2])))
+
+    def prox(x2, gamma):
+        x2 = np.asarray(x2, dtype=np.float64)
+        squeeze = x2.ndim == 2
+        x2 = x2[:, :, None] if squeeze else x2
+        out = np.stack([eng.prox_tv(x2[:, :, i], gamma)[0] for i in range(x2.shape[2])], axis=2)
+        return out[:, :, 0] if squeeze else out
+
+    return SimpleNamespace(norm=norm, prox=prox)
 
 
 def mrf_dtm_cpu(dict_, data, par, device=0):

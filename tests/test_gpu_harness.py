@@ -39,8 +39,10 @@ def test_recon_tsmis_svd_mrf_and_pnp_admm(engine_mod, oracle, synth):
             assert np.isfinite(m[key]), key
         assert m["tsmi_mean_ssim"] > r0["metrics"]["tsmi_mean_ssim"] - 0.2       # (a sanity bound, not a quality claim: synthetic weights)
         assert r1["foreground_mask"].shape == (N, N)
-        with pytest.raises(NotImplementedError):
-            H.recon_tsmis(dic, X0, qmap0, recon_method="LRTV")
+        r2 = H.recon_tsmis(dic, X0, qmap0, recon_method="LRTV", spiral_sampling_curve=120, seed=7, lrtv_iters=12)
+        xl, info = oracle.fista_lrtv(op, Y, K=4e-5, iters=12)
+        assert R.FISTA_deep.last_info["iters"] == info["iters"]
+        assert rel_err(r2["X"], xl) < 1e-6
         with pytest.raises(ValueError):
             H.recon_tsmis(dic, X0, qmap0, recon_method="PnP_ADMM")                # no weights
     finally:

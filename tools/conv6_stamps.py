@@ -11,9 +11,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
 
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1                # slices per launch
 eng = E.Engine(0)
-eng.set_denoiser(synth.structured_weights(seed=2, eps=0.02), 224, 224, max_batch=1)
+eng.set_denoiser(synth.structured_weights(seed=2, eps=0.02), 224, 224, max_batch=B)
 x = synth.uniform01(9001, 224 * 224 * 10).reshape(224, 224, 10)
+if B > 1:
+    x = np.stack([x] * B, axis=3)
 for _ in range(2):
     y = eng.denoise(x)
 buf = np.zeros((4096 * 11,), np.uint64)
