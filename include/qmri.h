@@ -201,6 +201,8 @@ typedef struct {
     int64_t n_conv3x3;          /* number of those launches */
     int64_t lsqr_iters;         /* LSQR iterations executed */
     int64_t admm_iters;
+    double ms_tv_iter;          /* LRTV: summed duration of the prox_tv iteration kernel's launches (level 2) */
+    int64_t n_tv_iter;
 } qmri_profile;
 int qmri_profile_enable(qmri_ctx* ctx, int level);   /* 0 off, 1 per stage, 2 also per conv3x3 launch */
 int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset);

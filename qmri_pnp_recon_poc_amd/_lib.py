@@ -57,7 +57,8 @@ class LrtvInfo(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("ms_xupdate", C.c_double), ("ms_denoiser", C.c_double), ("ms_elementwise", C.c_double),
                 ("ms_diag", C.c_double), ("ms_match", C.c_double), ("ms_conv3x3", C.c_double),
-                ("n_conv3x3", C.c_int64), ("lsqr_iters", C.c_int64), ("admm_iters", C.c_int64)]
+                ("n_conv3x3", C.c_int64), ("lsqr_iters", C.c_int64), ("admm_iters", C.c_int64),
+                ("ms_tv_iter", C.c_double), ("n_tv_iter", C.c_int64)]
 
 
 def build(force: bool = False) -> str:

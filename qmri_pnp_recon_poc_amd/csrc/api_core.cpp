@@ -598,14 +598,14 @@ int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop) {
     return QMRI_OK;
 }
 
-int qmri_prof_chain_finish(qmri_ctx* ctx) {
+int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv) {
     if (ctx->prof_level < 2 || ctx->chain_n == 0) return QMRI_OK;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i + 1 < ctx->chain_n; i += 2) {
         float ms = 0.f;
         QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->chain[i], ctx->chain[i + 1]));
-        ctx->prof.ms_conv3x3 += ms;
-        ctx->prof.n_conv3x3 += 1;
+        if (tv) { ctx->prof.ms_tv_iter += ms; ctx->prof.n_tv_iter += 1; }
+        else { ctx->prof.ms_conv3x3 += ms; ctx->prof.n_conv3x3 += 1; }
     }
     ctx->chain_n = 0;
     return QMRI_OK;

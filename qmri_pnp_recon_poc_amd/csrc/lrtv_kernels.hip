@@ -16,6 +16,7 @@
 #include <cmath>
 #include <vector>
 #include "qmri_internal.h"
+#include <hip/hip_ext.h>
 
 #pragma clang fp contract(off)      // the oracle is compiled without FMA contraction: keep a*b+c unfused here too
 
@@ -232,12 +233,17 @@ int tv_prox_dev(qmri_ctx* ctx, TvWork& w, const double* d_b, int R, int C, doubl
             const double mom = (told - 1.0) / t;
             told = t;
             const int in = launched & 1;
-            k_tv_iter<<<grid, dim3(TVT), 0, ctx->stream>>>(d_b, w.r[in], w.s[in], w.r[in ^ 1], w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st,
-                                                           R, C, gamma, mom, tol, maxit);
+            hipEvent_t e0 = nullptr, e1 = nullptr;                        // profile level 2: the kernel's own dispatch timestamps
+            QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
+            if (e0) hipExtLaunchKernelGGL(k_tv_iter, grid, dim3(TVT), 0, ctx->stream, e0, e1, 0, d_b, (const double*)w.r[in], (const double*)w.s[in], w.r[in ^ 1],
+                                          w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st, R, C, gamma, mom, tol, maxit);
+            else k_tv_iter<<<grid, dim3(TVT), 0, ctx->stream>>>(d_b, w.r[in], w.s[in], w.r[in ^ 1], w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st,
+                                                                R, C, gamma, mom, tol, maxit);
         }
         QMRI_HIP(ctx, hipGetLastError());
         QMRI_HIP(ctx, hipMemcpyAsync(&h, w.st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        QMRI_TRY(qmri_prof_chain_finish(ctx, true));                      // (launches that found `done` set count with their ~2 us)
         if (h.done) break;
     }
     *iters = h.iter; *obj = h.obj;

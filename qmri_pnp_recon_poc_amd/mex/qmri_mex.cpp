@@ -136,6 +136,26 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                             p.want_diag ? mxGetDoubles(diag) : nullptr, (int32_t*)mxGetData(li)));
         if (nlhs > 1) plhs[1] = diag; else mxDestroyArray(diag);
         if (nlhs > 2) plhs[2] = li; else mxDestroyArray(li);
+    } else if (c == "lrtv") {                        // [x, info] = qmri_mex('lrtv', y, param_struct, [N M s])   (FISTA_deep, main_recon_tsmis_FFT.m:273-282)
+        const mxArray* P = prhs[2];
+        qmri_lrtv_params p;
+        p.K = scalar_field(P, "K", 4e-5);
+        p.iters = (int)scalar_field(P, "iter", 200);
+        p.step = scalar_field(P, "step", 0.0);
+        p.tol = scalar_field(P, "tol", 1e-4);
+        p.backtrack = (int)scalar_field(P, "backtrack", 1);
+        p.prox_tol = 0.0; p.prox_maxit = 0;                        // prox_tv defaults (prox_tv.m:99-101)
+        const double* d = mxGetDoubles(prhs[3]);
+        const mwSize dims[3] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2]};
+        plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
+        qmri_lrtv_info info;
+        check(qmri_lrtv(ctx(), mxGetComplexDoubles(prhs[1]), &p, mxGetComplexDoubles(plhs[0]), &info));
+        if (nlhs > 1) {
+            const char* names[] = {"iters", "halvings", "step", "obj", "prox_calls", "prox_iters_total"};
+            plhs[1] = mxCreateStructMatrix(1, 1, 6, names);
+            const double v[6] = {(double)info.iters, (double)info.halvings, info.step, info.obj, (double)info.prox_calls, (double)info.prox_iters_total};
+            for (int i = 0; i < 6; ++i) mxSetFieldByNumber(plhs[1], 0, i, mxCreateDoubleScalar(v[i]));
+        }
     } else if (c == "set_dictionary") {              // qmri_mex('set_dictionary', D(single KxS), normD(single), lut(single KxQ))
         check(qmri_set_dictionary(ctx(), (int)mxGetM(prhs[1]), (int)mxGetN(prhs[1]), (int)mxGetN(prhs[3]),
                                   (const float*)mxGetData(prhs[1]), (const float*)mxGetData(prhs[2]), (const float*)mxGetData(prhs[3])));
