@@ -66,37 +66,59 @@ __global__ __launch_bounds__(TVT) void k_tv_iter(const double* __restrict__ b, c
     __shared__ int is_last;
     const int tr = blockIdx.x, tc = blockIdx.y;
     const int i0 = tr * TVR, j0 = tc * TVC;
-    // phase 1: sol on the tile plus one halo row and column
-    for (int e = threadIdx.x; e < (TVC + 1) * (TVR + 1); e += TVT) {
-        const int dj = e / (TVR + 1), di = e - dj * (TVR + 1);
-        const int i = i0 + di, j = j0 + dj;
-        double v = 0.0;
+    // phase 1: sol on the tile.  Thread t owns row di = t & 63 of columns (t >> 6) + 4k: a wave reads 64 consecutive rows of one
+    // column (512 contiguous bytes).  b, r, s stay in registers for phase 2.
+    constexpr int NPT = TVC / (TVT / TVR);             // points per thread (4)
+    static_assert(TVT % TVR == 0 && TVC % (TVT / TVR) == 0, "tile / thread mapping");
+    const int di = threadIdx.x & (TVR - 1), c0 = threadIdx.x / TVR;
+    const int i = i0 + di;
+    double bv[NPT], rv[NPT], sv[NPT], vv[NPT], po[NPT], qo[NPT];     // (pold / qold requested here too: one memory latency, not two)
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int dj = c0 + (TVT / TVR) * k, j = j0 + dj;
+        bv[k] = rv[k] = sv[k] = vv[k] = po[k] = qo[k] = 0.0;
         if (i < R && j < C) {
-            v = tv_sol_at(b, r_in, s_in, R, C, gamma, i, j);
-            if (di < TVR && dj < TVC) sol[(size_t)j * R + i] = v;
+            const size_t p = (size_t)j * R + i;
+            bv[k] = b[p]; rv[k] = r_in[p]; sv[k] = s_in[p]; po[k] = pold[p]; qo[k] = qold[p];
+            double dv;                                 // div_op.m:47-54
+            if (i == 0) dv = rv[k];
+            else if (i == R - 1) dv = -r_in[p - 1];
+            else dv = rv[k] - r_in[p - 1];
+            if (j == 0) dv += sv[k];
+            else if (j == C - 1) dv += -s_in[p - R];
+            else dv += sv[k] - s_in[p - R];
+            vv[k] = bv[k] - gamma * dv;
+            sol[p] = vv[k];
         }
-        tile[e] = v;
+        tile[dj * (TVR + 1) + di] = vv[k];
+    }
+    // ... plus one halo row (below the tile) and one halo column (right of it): 16 + 64 points, one per thread
+    if (threadIdx.x < TVC + TVR) {
+        const bool row = threadIdx.x < TVC;
+        const int hdi = row ? TVR : (int)threadIdx.x - TVC, hdj = row ? (int)threadIdx.x : TVC;
+        const int hi = i0 + hdi, hj = j0 + hdj;
+        tile[hdj * (TVR + 1) + hdi] = (hi < R && hj < C) ? tv_sol_at(b, r_in, s_in, R, C, gamma, hi, hj) : 0.0;
     }
     __syncthreads();
     // phase 2: objective shares and the dual update (prox_tv.m:160-186)
     const double c = 1.0 / (8.0 * gamma);
     double fid = 0.0, tv = 0.0;
-    for (int e = threadIdx.x; e < TVC * TVR; e += TVT) {
-        const int dj = e / TVR, di = e - dj * TVR;
-        const int i = i0 + di, j = j0 + dj;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int dj = c0 + (TVT / TVR) * k, j = j0 + dj;
         if (i >= R || j >= C) continue;
         const size_t p = (size_t)j * R + i;
-        const double v = tile[dj * (TVR + 1) + di];
+        const double v = vv[k];
         const double dx = (i < R - 1) ? tile[dj * (TVR + 1) + di + 1] - v : 0.0;
         const double dy = (j < C - 1) ? tile[(dj + 1) * (TVR + 1) + di] - v : 0.0;
-        const double d = b[p] - v;
+        const double d = bv[k] - v;
         fid += d * d;
         tv += sqrt(dx * dx + dy * dy);
-        const double rr = r_in[p] - c * dx, ss = s_in[p] - c * dy;
+        const double rr = rv[k] - c * dx, ss = sv[k] - c * dy;
         const double w = fmax(1.0, sqrt(rr * rr + ss * ss));
         const double pp = rr / w, qq = ss / w;
-        r_out[p] = pp + mom * (pp - pold[p]); pold[p] = pp;
-        s_out[p] = qq + mom * (qq - qold[p]); qold[p] = qq;
+        r_out[p] = pp + mom * (pp - po[k]); pold[p] = pp;
+        s_out[p] = qq + mom * (qq - qo[k]); qold[p] = qq;
     }
     tv_block_sum2(fid, tv, red);
     // phase 3: the last block adds the partial sums in block order and evaluates the stopping rule (prox_tv.m:164-175)
