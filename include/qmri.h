@@ -173,6 +173,12 @@ int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* 
 int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt,
                         int32_t* d_dm);
 
+/* ---- TSMI synthesis from quantitative maps: main_synthesize_tsmis.m:54,82-100 (mode 'real') ------------ */
+/* I = knnsearch(KDTreeSearcher(dict.lut), qm(:,1:2)); X = real(dict.D(I,:)) .* dict.normD(I) .* abs(qm(:,3)); X .* sign(X(:,:,1)).
+ * qmap: Npix x 3 doubles column-major (T1, T2, PD, in the units of dict.lut); X_out: Npix x s singles column-major;
+ * idx_out (nullable): the 1-based nearest entry.  Uses the dictionary of qmri_set_dictionary (Q >= 2). */
+int qmri_synthesize_tsmi(qmri_ctx* ctx, const double* qmap, int Npix, float* X_out, int32_t* idx_out);
+
 /* ---- slice batches over several GPUs of one node (slices are independent; no collective) ------------ */
 typedef struct {
     int32_t N, M, s, T;

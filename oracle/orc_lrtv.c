@@ -90,3 +90,25 @@ int orc_prox_tv(const double* b, int R, int C, double gamma, double tol, int max
     if (obj_out) *obj_out = obj;
     return iter;
 }
+
+/* ---- TSMI synthesis (main_synthesize_tsmis.m:54,82-100, mode 'real'): nearest look-up-table entry in (T1, T2) by exhaustive
+ * search (knnsearch, Euclidean, first index among equal distances), X = D(I,:) * normD(I) * |PD| * sign(first channel). */
+void orc_synthesize_tsmi(const double* qmap, int Npix, const float* D, const float* normD, const float* lut, int K, int s,
+                         float* X, int32_t* idx) {
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < Npix; ++p) {
+        const double q1 = qmap[p], q2 = qmap[(size_t)Npix + p];
+        double best = INFINITY;
+        int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const double d1 = q1 - (double)lut[k], d2 = q2 - (double)lut[(size_t)K + k];
+            const double d = d1 * d1 + d2 * d2;
+            if (d < best) { best = d; bi = k; }
+        }
+        if (idx) idx[p] = bi + 1;
+        const float nd = normD[bi], pd = (float)fabs(qmap[(size_t)2 * Npix + p]);
+        const float x0 = D[bi] * nd * pd;
+        const float sg = (x0 > 0.f) ? 1.f : ((x0 < 0.f) ? -1.f : 0.f);
+        for (int c = 0; c < s; ++c) X[(size_t)c * Npix + p] = D[(size_t)K * c + bi] * nd * pd * sg;
+    }
+}

@@ -108,6 +108,11 @@ void orc_dict_match(const double* X, int Npix, int s, const float* D, const floa
 double orc_norm_tv(const double* I, int R, int C);
 int orc_prox_tv(const double* b, int R, int C, double gamma, double tol, int maxit, double* sol, double* obj_out);
 
+/* main_synthesize_tsmis.m:54,82-100 (mode 'real').  qmap: Npix x 3 col-major (T1, T2, PD); D: K x s, lut: K x Q col-major
+ * (columns 1-2 used); X: Npix x s col-major single; idx (nullable): 1-based nearest entry. */
+void orc_synthesize_tsmi(const double* qmap, int Npix, const float* D, const float* normD, const float* lut, int K, int s,
+                         float* X, int32_t* idx);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "qmri_net_forward_dev", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_onnx_read_unetres",
-    "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv",
+    "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi",
 ]
 
 
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
     L.qmri_lrtv.argtypes = [vp, vp, C.POINTER(LrtvParams), vp, C.POINTER(LrtvInfo)]
     L.qmri_prox_tv.argtypes = [vp, dp, i, i, C.c_double, C.c_double, i, dp, ip, dp]
     L.qmri_norm_tv.argtypes = [vp, dp, i, i, dp]
+    L.qmri_synthesize_tsmi.argtypes = [vp, dp, i, fp, ip]
     L.qmri_set_dictionary.argtypes = [vp, i, i, i, fp, fp, fp]
     L.qmri_dict_match.argtypes = [vp, vp, i, fp, fp, fp, ip]
     L.qmri_dict_match_dev.argtypes = [vp, vp, i, vp, vp, vp, vp]

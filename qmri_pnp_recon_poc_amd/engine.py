@@ -213,6 +213,23 @@ class Engine:
         self._check(self.L.qmri_set_dictionary(self.h, K, s, Q, Df.ctypes.data_as(f), nd.ctypes.data_as(f), lf.ctypes.data_as(f)))
         self.dict_shape = (K, s, Q)
 
+    def synthesize_tsmi(self, qmap):
+        """TSMI of a quantitative map (main_synthesize_tsmis.m:82-100, mode 'real'): qmap [..., 3] (T1, T2, PD) ->
+        (X [..., s] float32, idx [...] 1-based nearest dictionary entry).  Needs set_dictionary."""
+        qmap = np.asarray(qmap, dtype=np.float64)
+        if qmap.shape[-1] != 3:
+            raise ValueError("qmap must have T1, T2, PD along its last dimension")
+        if getattr(self, "dict_shape", None) is None:
+            raise ValueError("dictionary not set")
+        shp = qmap.shape[:-1]
+        q = np.ascontiguousarray(qmap.reshape(-1, 3, order="F").ravel(order="F"))
+        npix, s = q.size // 3, self.dict_shape[1]
+        X = np.empty(npix * s, np.float32)
+        idx = np.empty(npix, np.int32)
+        self._check(self.L.qmri_synthesize_tsmi(self.h, q.ctypes.data_as(C.POINTER(C.c_double)), npix, X.ctypes.data_as(C.POINTER(C.c_float)),
+                                                idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return X.reshape(shp + (s,), order="F"), idx.reshape(shp, order="F")
+
     # -- LRTV option ---------------------------------------------------------------------------------
     def lrtv(self, y, K=4e-5, iters=200, step=None, tol=1e-4, backtrack=True, prox_tol=None, prox_maxit=None):
         """x = FISTA_deep(data, param)  (FISTA_deep.m:1, parameters of main_recon_tsmis_FFT.m:274-281).

@@ -11,6 +11,8 @@ Host logic in numpy/scipy; the reconstruction and the match run on the GPU throu
   awgn_measured(y, snr_db, seed)       `awgn(Y, snr, 'measured')` with an explicit seed       :243
   psnr(A, ref) / ssim(A, ref)          MATLAB `psnr` / `ssim` defaults for double images [MathWorks]   :352-372
   metrics(qmap, qmap0, mask, X, X0)    the block :327-374 as a dict
+  synthesize_tsmis(qmap, dictionary)   main_synthesize_tsmis.m:76-100: quantitative maps -> TSMIs (GPU)
+  training_volume / save_training_pickle   the `.mat` -> training-pickle layout of main_save_python_tsmis.py:132-190
   recon_tsmis(...)                     the script's main flow for recon_method 'SVD_MRF' | 'LRTV' | 'PnP_ADMM'  :263-319
 
 [MathWorks] functions are restated from their documented defaults (no MATLAB here: parity unpinned for them, see
@@ -24,7 +26,7 @@ from __future__ import annotations
 import numpy as np
 
 __all__ = ["load_mat", "load_dictionary", "load_tsmi", "crop_tsmi", "load_qmaps", "getmask_fromPD", "awgn_measured",
-           "psnr", "ssim", "metrics", "recon_tsmis"]
+           "psnr", "ssim", "metrics", "recon_tsmis", "synthesize_tsmis", "training_volume", "save_training_pickle"]
 
 CROP = slice(3, 227)          # MATLAB (4:227): 230 -> 224                                       main_recon_tsmis_FFT.m:189,212
 
@@ -169,6 +171,33 @@ def metrics(qmap, qmap0, foreground_mask, X=None, X0=None):
         out["tsmi_mean_psnr"] = float(np.mean([psnr(np.abs(X[:, :, c]), np.abs(X0[:, :, c])) for c in range(X0.shape[2])]))
         out["tsmi_mean_ssim"] = float(np.mean([ssim(np.abs(X[:, :, c]), np.abs(X0[:, :, c])) for c in range(X0.shape[2])]))
     return out
+
+
+def synthesize_tsmis(qmap, dictionary, device=0):
+    """main_synthesize_tsmis.m:76-100 (mode 'real') for one volume: qmap slices x 3 x N x M (the file layout, :180) ->
+    X slices x N x M x s single, first SVD channel non-negative.  Runs on the GPU (exhaustive nearest-entry search)."""
+    from . import reference_api as R
+    q = np.asarray(qmap, dtype=np.float64)
+    if q.ndim != 4 or q.shape[1] != 3:
+        raise ValueError("qmap must be slices x 3 x N x M")
+    eng = R._engine(device)
+    eng.set_dictionary(dictionary["D"], dictionary["normD"], dictionary["lut"])
+    return np.stack([eng.synthesize_tsmi(np.transpose(q[i], (1, 2, 0)))[0] for i in range(q.shape[0])])
+
+
+def training_volume(X_slices, channels_to_save=None):
+    """PyTorch_Denoiser/main_save_python_tsmis.py:132-166: the TSMIs of one volume (slices x N x M x C, as synthesize_tsmis
+    returns them or as loaded from the per-slice `.mat` files) -> the float64 array slices x C x N x M the training kit
+    pickles (`data_slice` transposed (2,1,0) then (0,2,1), i.e. channel first); optionally only the first channels."""
+    v = np.moveaxis(np.asarray(X_slices, dtype=np.float64), 3, 1)
+    return np.ascontiguousarray(v if channels_to_save is None else v[:, :channels_to_save])
+
+
+def save_training_pickle(path, X_slices, channels_to_save=None):
+    """pickle.dump(vol_data, f) of main_save_python_tsmis.py:184-190 (file naming is the caller's)."""
+    import pickle
+    with open(path, "wb") as f:
+        pickle.dump(training_volume(X_slices, channels_to_save), f)
 
 
 # ------------------------------------------------------------------------------------------------------------

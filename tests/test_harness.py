@@ -117,3 +117,18 @@ def test_awgn_measured_and_metrics_block():
     assert abs(m["t1_psnr"] - 10 * np.log10(1.0 / (0.01 * mask.mean()))) < 1e-9     # the +0.1 offset only inside the mask
     assert m["t2_psnr"] == float("inf") and abs(m["t2_ssim"] - 1) < 1e-12
     assert m["tsmi_mean_psnr"] > 140 and abs(m["tsmi_mean_ssim"] - 1) < 1e-9        # |X| ignores the global phase
+
+
+def test_training_volume_layout(tmp_path):
+    """main_save_python_tsmis.py:132-190: per-slice (N, M, C) arrays -> (slices, C, N, M) float64, pickled."""
+    import pickle
+    rng = np.random.default_rng(4)
+    X = rng.random((3, 8, 9, 5)).astype(np.float32)
+    v = H.training_volume(X)
+    assert v.shape == (3, 5, 8, 9) and v.dtype == np.float64
+    ref = np.stack([np.transpose(np.transpose(X[i], (2, 1, 0)), (0, 2, 1)) for i in range(3)])     # the script's two transposes
+    assert np.array_equal(v, ref.astype(np.float64))
+    assert H.training_volume(X, channels_to_save=1).shape == (3, 1, 8, 9)
+    H.save_training_pickle(tmp_path / "vol1.pkl", X)
+    with open(tmp_path / "vol1.pkl", "rb") as f:
+        assert np.array_equal(pickle.load(f), v)
