@@ -115,8 +115,11 @@ __global__ __launch_bounds__(TVT) void k_tv_iter(const double* __restrict__ b, c
         fid += d * d;
         tv += sqrt(dx * dx + dy * dy);
         const double rr = rv[k] - c * dx, ss = sv[k] - c * dy;
-        const double w = fmax(1.0, sqrt(rr * rr + ss * ss));
-        const double pp = rr / w, qq = ss / w;
+        // projection onto the unit ball: weights = max(1, |(r, s)|) (prox_tv.m:178-181).  Inside the ball the division is by 1,
+        // i.e. exact: skip the fp64 sqrt and divisions there (the result is bit-identical)
+        const double n2 = rr * rr + ss * ss;
+        double pp = rr, qq = ss;
+        if (n2 > 1.0) { const double w = sqrt(n2); pp = rr / w; qq = ss / w; }
         r_out[p] = pp + mom * (pp - po[k]); pold[p] = pp;
         s_out[p] = qq + mom * (qq - qo[k]); qold[p] = qq;
     }
