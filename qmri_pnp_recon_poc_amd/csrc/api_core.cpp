@@ -598,10 +598,11 @@ int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop) {
     return QMRI_OK;
 }
 
-int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv) {
+int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv, long count) {
     if (ctx->prof_level < 2 || ctx->chain_n == 0) return QMRI_OK;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i + 1 < ctx->chain_n; i += 2) {
+        if (count >= 0 && (long)(i / 2) >= count) break;
         float ms = 0.f;
         QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->chain[i], ctx->chain[i + 1]));
         if (tv) { ctx->prof.ms_tv_iter += ms; ctx->prof.n_tv_iter += 1; }

@@ -8,9 +8,10 @@
 // column-major -- finite differences also run across the real/imaginary seam and across channel seams, as in the reference.
 // One inner iteration of prox_tv is ONE kernel: a block computes sol = b - gamma div(r, s) on its 64 x 16 tile plus one halo row
 // and column (LDS), the tile's share of the objective, and the dual update with projection and FISTA momentum (r, s are
-// ping-pong buffers: neighbouring tiles still read the old ones).  The last block to finish adds the partial sums in block
-// order, evaluates the stopping rule and sets `done`; kernels launched after that return at once, so `sol` keeps the value of
-// the iteration that met the tolerance -- the host only looks at the flag every few launches.  HBM/L2 streaming work
+// ping-pong buffers: neighbouring tiles still read the old ones).  The stopping rule of an iteration is evaluated at the start
+// of the NEXT launch, by every block, from the per-block partial sums (no fences, no atomics: the kernel boundary orders it);
+// once it is met the launches return at once, so `sol` keeps the iterate that met the tolerance -- the host only looks at the
+// flag every few launches.  HBM/L2 streaming work
 // (10 arrays of R*C doubles per iteration), no matrix cores.
 #include <algorithm>
 #include <cmath>
@@ -25,7 +26,7 @@ namespace {
 constexpr int TVR = 64, TVC = 16, TVT = 256;       // tile rows x columns, threads
 constexpr int RED_BLOCKS = 256;                    // fixed grid of the streaming reductions (partials are added in block order)
 
-struct TvState { double prev_obj, obj; int iter, done; unsigned counter; int pad; };
+struct TvState { double obj[2]; int iter, done; };     // obj[k & 1] = objective of iteration k (obj of "iteration 0" = 0), written by block 0
 
 __device__ __forceinline__ double tv_sol_at(const double* __restrict__ b, const double* __restrict__ r, const double* __restrict__ s,
                                             int R, int C, double gamma, int i, int j) {
@@ -59,11 +60,26 @@ __device__ __forceinline__ void tv_block_sum2(double& a, double& b, double* sh /
 __global__ __launch_bounds__(TVT) void k_tv_iter(const double* __restrict__ b, const double* __restrict__ r_in, const double* __restrict__ s_in,
                                                   double* __restrict__ r_out, double* __restrict__ s_out, double* __restrict__ pold,
                                                   double* __restrict__ qold, double* __restrict__ sol, double* __restrict__ partials,
-                                                  TvState* __restrict__ st, int R, int C, double gamma, double mom, double tol, int maxit) {
+                                                  TvState* __restrict__ st, int R, int C, double gamma, double mom, double tol, int maxit, int launch) {
+    // Launch number `launch` (0-based) performs iteration launch + 1.  It first evaluates the stopping rule of iteration `launch`
+    // (prox_tv.m:164-175) from the partial sums the previous launch left -- every block adds the same numbers in the same order,
+    // so all blocks decide alike; the kernel boundary is the only synchronisation (a device-scope fence per block, as a "last
+    // block reduces" scheme needs, costs an L2 write-back each on this part).
     if (st->done) return;                              // the stopping rule was met by an earlier launch
     __shared__ double tile[(TVC + 1) * (TVR + 1)];
     __shared__ double red[2 * (TVT / 64)];
-    __shared__ int is_last;
+    const unsigned nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (launch > 0) {
+        const double* pp = partials + (size_t)((launch - 1) & 1) * 2 * nblk;
+        double a = 0.0, t = 0.0;
+        for (unsigned k = threadIdx.x; k < nblk; k += TVT) { a += pp[2 * k]; t += pp[2 * k + 1]; }
+        tv_block_sum2(a, t, red);
+        const double obj = 0.5 * a + gamma * t;
+        const double rel = fabs(obj - st->obj[(launch - 1) & 1]) / obj;
+        const bool stop = rel < tol || launch >= maxit;
+        if (bid == 0 && threadIdx.x == 0) { st->obj[launch & 1] = obj; st->iter = launch; if (stop) st->done = 1; }
+        if (stop) return;                              // `sol` keeps the iterate of iteration `launch`
+    }
     const int tr = blockIdx.x, tc = blockIdx.y;
     const int i0 = tr * TVR, j0 = tc * TVC;
     // phase 1: sol on the tile.  Thread t owns row di = t & 63 of columns (t >> 6) + 4k: a wave reads 64 consecutive rows of one
@@ -124,27 +140,8 @@ __global__ __launch_bounds__(TVT) void k_tv_iter(const double* __restrict__ b, c
         s_out[p] = qq + mom * (qq - qo[k]); qold[p] = qq;
     }
     tv_block_sum2(fid, tv, red);
-    // phase 3: the last block adds the partial sums in block order and evaluates the stopping rule (prox_tv.m:164-175)
-    const unsigned nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0) {
-        partials[2 * bid] = fid; partials[2 * bid + 1] = tv;
-        __threadfence();
-        is_last = (atomicAdd(&st->counter, 1u) == nblk - 1);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    double a = 0.0, t = 0.0;
-    for (unsigned k = threadIdx.x; k < nblk; k += TVT) { a += partials[2 * k]; t += partials[2 * k + 1]; }
-    tv_block_sum2(a, t, red);
-    if (threadIdx.x == 0) {
-        const double obj = 0.5 * a + gamma * t;
-        const double rel = fabs(obj - st->prev_obj) / obj;
-        st->prev_obj = obj; st->obj = obj;
-        st->iter += 1;
-        if (rel < tol || st->iter >= maxit) st->done = 1;
-        st->counter = 0;
-    }
+    // phase 3: this block's shares, for the next launch
+    if (threadIdx.x == 0) { double* po_ = partials + (size_t)(launch & 1) * 2 * nblk; po_[2 * bid] = fid; po_[2 * bid + 1] = tv; }
 }
 
 // ---- streaming pieces of the outer FISTA loop ------------------------------------------------------------------
@@ -221,13 +218,14 @@ struct TvWork {                                      // device buffers of one pr
     double *r[2] = {nullptr, nullptr}, *s[2] = {nullptr, nullptr}, *pold = nullptr, *qold = nullptr, *partials = nullptr;
     TvState* st = nullptr;
     size_t n = 0; unsigned nblk = 0;
+    int pred = 0;                                    // iterations the previous call needed: the first batch of launches of the next one
 };
 
 int tv_alloc(qmri_ctx* ctx, TvWork& w, int R, int C) {
     w.n = (size_t)R * C;
     w.nblk = (unsigned)(((R + TVR - 1) / TVR) * ((C + TVC - 1) / TVC));
     for (double** p : {&w.r[0], &w.r[1], &w.s[0], &w.s[1], &w.pold, &w.qold}) QMRI_HIP(ctx, hipMalloc((void**)p, w.n * sizeof(double)));
-    QMRI_HIP(ctx, hipMalloc((void**)&w.partials, (size_t)2 * std::max(w.nblk, (unsigned)RED_BLOCKS) * sizeof(double)));
+    QMRI_HIP(ctx, hipMalloc((void**)&w.partials, (size_t)4 * std::max(w.nblk, (unsigned)RED_BLOCKS) * sizeof(double)));   // two sets of (fid, tv) per block
     QMRI_HIP(ctx, hipMalloc((void**)&w.st, sizeof(TvState)));
     return QMRI_OK;
 }
@@ -250,9 +248,12 @@ int tv_prox_dev(qmri_ctx* ctx, TvWork& w, const double* d_b, int R, int C, doubl
     double told = 1.0;
     TvState h{};
     int launched = 0;
-    constexpr int CHUNK = 6;                                              // launches between two looks at the flag
-    while (launched < maxit) {
-        const int n = std::min(CHUNK, maxit - launched);
+    constexpr int CHUNK = 4;                                              // launches between two looks at the flag ...
+    while (launched < maxit + 1) {                                        // (launch `maxit` only evaluates iteration maxit)
+        // ... the first batch is what the previous call needed plus the launch that evaluates the rule (consecutive FISTA steps
+        // need nearly the same number of inner iterations)
+        const int want = (launched == 0 && w.pred > 0) ? w.pred + 1 : CHUNK;
+        const int n = std::min(want, maxit + 1 - launched), chunk_start = launched;
         for (int k = 0; k < n; ++k, ++launched) {
             const double t = (1.0 + std::sqrt(4.0 * told * told)) / 2.0;  // prox_tv.m:183 (as written)
             const double mom = (told - 1.0) / t;
@@ -261,17 +262,19 @@ int tv_prox_dev(qmri_ctx* ctx, TvWork& w, const double* d_b, int R, int C, doubl
             hipEvent_t e0 = nullptr, e1 = nullptr;                        // profile level 2: the kernel's own dispatch timestamps
             QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
             if (e0) hipExtLaunchKernelGGL(k_tv_iter, grid, dim3(TVT), 0, ctx->stream, e0, e1, 0, d_b, (const double*)w.r[in], (const double*)w.s[in], w.r[in ^ 1],
-                                          w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st, R, C, gamma, mom, tol, maxit);
+                                          w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st, R, C, gamma, mom, tol, maxit, launched);
             else k_tv_iter<<<grid, dim3(TVT), 0, ctx->stream>>>(d_b, w.r[in], w.s[in], w.r[in ^ 1], w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st,
-                                                                R, C, gamma, mom, tol, maxit);
+                                                                R, C, gamma, mom, tol, maxit, launched);
         }
         QMRI_HIP(ctx, hipGetLastError());
         QMRI_HIP(ctx, hipMemcpyAsync(&h, w.st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        QMRI_TRY(qmri_prof_chain_finish(ctx, true));                      // (launches that found `done` set count with their ~2 us)
+        // profile: launches 0 .. iter-1 performed an iteration; the later ones only evaluated the rule or returned at once
+        QMRI_TRY(qmri_prof_chain_finish(ctx, true, std::max(0, std::min(n, (h.done ? h.iter : launched) - chunk_start))));
         if (h.done) break;
     }
-    *iters = h.iter; *obj = h.obj;
+    *iters = h.iter; *obj = h.obj[h.iter & 1];
+    w.pred = h.iter;
     return QMRI_OK;
 }
 

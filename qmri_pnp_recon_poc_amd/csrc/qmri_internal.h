@@ -271,7 +271,7 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
 int conv_cin_pad(ConvKind kind, int Cin);
 // bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
 int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop);   // profile level 2: next event pair of the forward (else nullptrs)
-int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv = false);   // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3 (tv: ms_tv_iter / n_tv_iter)
+int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv = false, long count = -1);   // count >= 0: only the first `count` pairs are accumulated   // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3 (tv: ms_tv_iter / n_tv_iter)
 bool conv6_enabled();
 int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (QMRI_CONV_SCHEME=bf16x6)
 bool conv6_weights_fit_f16(const float* w, size_t n);
