@@ -121,3 +121,27 @@ def test_recon_batch_single_device(engine_mod, oracle, synth):
         o = oracle.dict_match(res["X"][sl], dic["D"], dic["normD"], dic["lut"])
         same = bool(np.array_equal(res["qmap"][sl], o["qmap"]))       # same X in -> bit-exact maps out
         assert same
+
+
+def test_config2_epi_multi_level_batch_224(engine_mod, oracle, synth, case224):
+    """BASELINE.json configs[2] at full size: cut3 slices, EPI mask (setup_subsampling_epi, 1/65 of the k-space lines per frame),
+    the 11-channel multi-level DRUNet with its constant noise-map channel, several slices advanced together."""
+    from qmri_pnp_recon_poc_amd import batch
+    dic = case224["dic"]
+    fp, k = oracle.epi_mask(224, 224, 1 / 65, 200)
+    op = oracle.Operator(224, 224, dic["V"], fp, k)
+    w = synth.structured_weights(in_nc=11, out_nc=10, seed=5, eps=0.02)
+    ys = []
+    for sl in range(3):
+        X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(224, seed=10 + sl), dic)
+        ys.append(synth.awgn_measured(op.forward(X0), 30.0, seed=10 + sl))
+    ys = np.stack(ys)
+    iters = 4
+    res = batch.recon_batch([0], ys, N=224, M=224, V=dic["V"], frame_ptr=fp, kidx=k, weights=w, in_nc=11, out_nc=10,
+                            dictionary=dic, iters=iters, multi_level=True, noise_std=0.01, slices_per_launch=3)
+    net = oracle.Net(w, in_nc=11, out_nc=10)
+    for sl in range(3):
+        xo, _, lo = oracle.pnp_admm(op, net, ys[sl], iters=iters, multi_level=True, noise_std=0.01)
+        err = rel_err(res["X"][sl], xo)
+        print(f"config2 slice {sl}: rel_err {err:.2e}, oracle lsqr iters {lo.tolist()}")
+        assert err < 1e-4
