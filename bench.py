@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo + --one-device: rehearsal of the "
+                    "multi-rank path on a single-GPU box; the ranks then share device 0, so the value is not a scaling result)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,10 +71,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libqmri has no CPU path")
     dev = torch.device("cuda", local_rank)
@@ -158,7 +163,7 @@ def main():
 
     # max over ranks
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
