@@ -60,7 +60,15 @@ extern "C" int qmri_create(int device, qmri_ctx** out) {
         return QMRI_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    for (auto& ev : ctx->ev) hipEventCreate(&ev);
+    for (auto& ev : ctx->ev) {
+        if ((e = hipEventCreate(&ev)) != hipSuccess) {
+            qmri_set_error(nullptr, "hipEventCreate failed: %s", hipGetErrorString(e));
+            for (auto& x : ctx->ev) if (x) (void)hipEventDestroy(x);
+            (void)hipStreamDestroy(ctx->own_stream);
+            delete ctx;
+            return QMRI_ERR_HIP;
+        }
+    }
     *out = ctx;
     return QMRI_OK;
 }
