@@ -22,6 +22,7 @@
 //              requested two steps ahead and kept in registers for one
 // Tensors stay fp32 padded planes in HBM (qmri_internal.h PTensor), so this kernel is interchangeable with k_conv.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "qmri_internal.h"
@@ -53,6 +54,7 @@ struct Conv6Args {
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
     unsigned* range_flag;         // f16 scheme: set to 1 when an output leaves the range the next layer's f16 split can carry
+    float descale_hi, descale_lo; // f16 scheme: the layer's weights are packed times 2^k (largest |w| in [1, 2)): 2^-k and 2^-k / 2^11
     unsigned long long* stamps;   // diagnostic (QMRI_CONV_STAMPS): [16 workgroups][2 roles][128] barrier-arrival times, 100 MHz clock
 };
 
@@ -400,7 +402,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             for (int r = 0; r < 16; ++r) {
                 const int co = (m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
                 float v = acc[m][n][r];
-                if constexpr (SP == 2) v += accl[m][n][r] * (1.f / LO_SCALE);
+                if constexpr (SP == 2) v = v * A.descale_hi + accl[m][n][r] * A.descale_lo;      // (powers of two: exact)
                 ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = v;
             }
     }   // MFMA waves
@@ -509,6 +511,7 @@ struct Conv6sArgs {
     int nsteps, n_ct, tiles_h, tiles_w;   // nsteps is a multiple of 3 (the register rotation of the loaders); steps >= nsteps_real
     int nsteps_real;                      // carry zero weights and repeat the last step's activations
     unsigned* range_flag;                 // as in Conv6Args
+    float descale_hi, descale_lo;
 };
 
 template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[3], f32x4 (&b)[2]) {
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         }
         if constexpr (SP == 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += accl[r] * (1.f / LO_SCALE);
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] * A.descale_hi + accl[r] * A.descale_lo;
         }
         // accumulators -> LDS output tile.  C/D layout: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -721,6 +724,7 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.vec4 = (in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
               (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp))) ? 1 : 0;
     A.range_flag = ctx->net.d_range_flag;
+    A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
     A.launch_idx = g_launch_counter++;
@@ -796,7 +800,8 @@ bool conv6_weights_fit_f16(const float* w, size_t n) {
 
 namespace {
 // pieces of one weight in the layer's scheme (L.sp6): bf16 triple, or f16 (hi, (w - hi) * 2^11)
-inline void host_split(int sp, float v, uint16_t (&h)[3]) {
+inline void host_split(int sp, float v, uint16_t (&h)[3], float scale = 1.f) {
+    v *= scale;                                                    // (f16 scheme: a power of two, exact)
     if (sp == 3) {
         h[0] = host_bf16(v);
         const float r1 = v - host_bf16_to_f(h[0]);
@@ -811,6 +816,22 @@ inline void host_split(int sp, float v, uint16_t (&h)[3]) {
 }
 }  // namespace
 
+// f16 scheme: the layer's weights are packed times 2^k with the largest |w| in [1, 2), and the epilogue multiplies by 2^-k -- both
+// exact.  An f16 piece below 6.1e-5 is subnormal and carries an absolute, not a relative error; scaling keeps a layer of
+// uniformly small weights (say 1e-5) as accurate as any other.  Returns the factor and records its inverse in the layer.
+static float conv6_weight_scale(ConvLayer& L, const float* w, size_t n) {
+    L.w6_descale = 1.f;
+    if (L.sp6 != 2) return 1.f;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+    int e = 0;
+    (void)std::frexp(mx, &e);                                      // mx = f * 2^e, f in [0.5, 1)
+    const int k = std::min(60, std::max(-60, 1 - e));              // mx * 2^k in [1, 2)
+    L.w6_descale = std::ldexp(1.f, -k);
+    return std::ldexp(1.f, k);
+}
+
 // Weights (Conv2d OIHW) -> pre-split A fragments:
 //   uint4 index = ((((ct64*nchunk + chunk)*9 + tap)*2 + m)*SP + split)*64 + lane ; the uint4 holds 8 pieces, element j:
 //   row = ct64*64 + m*32 + (lane&31),  ci = chunk*16 + 8*(lane>>5) + j,  tap = kh*3 + kw
@@ -818,6 +839,7 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
     L.nchunk6 = (L.Cin + CK - 1) / CK;
     L.n_ct6 = (L.Cout + 63) / 64;
     const int SP = L.sp6;
+    const float wscale = conv6_weight_scale(L, w, (size_t)L.Cout * L.Cin * 9);
     packed.assign((size_t)L.n_ct6 * L.nchunk6 * 9 * 2 * SP * 64 * 8, 0);
     for (int ct = 0; ct < L.n_ct6; ++ct)
         for (int chunk = 0; chunk < L.nchunk6; ++chunk)
@@ -830,7 +852,7 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
                             if (row >= L.Cout || ci >= L.Cin) continue;
                             const float v = w[((size_t)row * L.Cin + ci) * 9 + tap];
                             uint16_t h[3];
-                            host_split(SP, v, h);
+                            host_split(SP, v, h, wscale);
                             const size_t base = ((((size_t)ct * L.nchunk6 + chunk) * 9 + tap) * 2 + m) * SP;
                             for (int sp = 0; sp < SP; ++sp) packed[((base + sp) * 64 + lane) * 8 + j] = h[sp];
                         }
@@ -846,6 +868,7 @@ void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packe
     L.nchunk6 = ((L.nsteps6s + 2) / 3) * 3;                                   // padded with zero-weight steps to a multiple of 3
     L.n_ct6 = up ? 2 * ((L.Cout + 31) / 32) : (L.Cout + 63) / 64;
     const int SP = L.sp6;
+    const float wscale = conv6_weight_scale(L, w, (size_t)L.Cout * L.Cin * 4);
     packed.assign((size_t)L.n_ct6 * L.nchunk6 * asts6(SP) * 8, 0);
     for (int ct = 0; ct < L.n_ct6; ++ct)
         for (int g = 0; g < L.nsteps6s; ++g)
@@ -865,7 +888,7 @@ void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packe
                                 v = w[(((size_t)row * L.Cin + ci) * 2 + kh) * 2 + kw];
                             }
                             uint16_t h[3];
-                            host_split(SP, v, h);
+                            host_split(SP, v, h, wscale);
                             const size_t base = ((((size_t)ct * L.nchunk6 + g) * 2 + plane) * 2 + m) * SP;
                             for (int sp = 0; sp < SP; ++sp) packed[((base + sp) * 64 + lane) * 8 + j] = h[sp];
                         }
@@ -889,6 +912,7 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.nsteps = L.nchunk6; A.nsteps_real = L.nsteps6s; A.n_ct = L.n_ct6;
     A.range_flag = ctx->net.d_range_flag;
+    A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.tiles_h = (A.GH + STH - 1) / STH; A.tiles_w = (A.GW + STW - 1) / STW;
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;
     if (L.sp6 == 2) {

@@ -130,6 +130,7 @@ struct ConvLayer {
     int tab_B, tab_MT;
     void* wp6 = nullptr;     // weights split into f16 pairs (sp6 == 2) or bf16 triples (sp6 == 3), MFMA A-fragment order (conv6_kernels.hip)
     int sp6 = 2;             // pieces per fp32 operand of the matrix-core path
+    float w6_descale = 1.f;  // f16 scheme: 2^-k of the power-of-two the packed weights carry (conv6_kernels.hip)
     int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks (2x2 layers: K steps), 64-row output tiles of wp6
     int nsteps6s = 0;             // 2x2 layers: K steps that carry weights (nchunk6 is padded to a multiple of 3)
 };
