@@ -298,6 +298,21 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
     }
     QMRI_CHECK_ARG(ctx, B >= 1 && B <= p.maxB, "batch exceeds max_batch of qmri_set_denoiser");
     const size_t HW = (size_t)H * W, nin = HW * C * B, nout = HW * p.desc.out_nc * B;
+    // Both architectures are bias-free convolutions + ReLU (+ skips): net(2^k x) = 2^k net(x) exactly in fp32.  Inputs far from unit
+    // scale are therefore brought to [0.5, 1) by a power of two on the way in and back on the way out, so that the f16 pieces of
+    // the activations stay in their normal range; inputs of ordinary scale -- the [0, 1] images of the
+    // ADMM loop -- are left alone.
+    float in_scale = 1.f, out_scale = 1.f;
+    {
+        double amax = 0.0;
+        for (size_t i = 0; i < nin; ++i) { const double a = std::fabs(in[i]); if (a > amax) amax = a; }
+        if (std::isfinite(amax) && amax > 0.0 && (amax < 0.0625 || amax >= 256.0)) {
+            int e = 0;
+            (void)std::frexp(amax, &e);                             // amax = f * 2^e, f in [0.5, 1)
+            const int k = std::min(100, std::max(-100, -e));
+            in_scale = std::ldexp(1.f, k); out_scale = std::ldexp(1.f, -k);
+        }
+    }
     double* d_io = nullptr;
     QMRI_HIP(ctx, hipMalloc((void**)&d_io, std::max(nin, nout) * sizeof(double)));
     int st = QMRI_OK;
@@ -305,9 +320,9 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
         bool again = false;
         do {
             if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
-            if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32)) != QMRI_OK) break;         // im2single: :72-77
+            if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32, in_scale)) != QMRI_OK) break;   // im2single: :72-77
             if ((st = net_forward(ctx, B)) != QMRI_OK) break;                                      // activations(...): :88
-            if ((st = ew_launch_unpack(ctx, B, p.desc.out_nc, H, W, p.out32, p.in32, p.desc.residual_noise, d_io, 1)) != QMRI_OK) break;
+            if ((st = ew_launch_unpack(ctx, B, p.desc.out_nc, H, W, p.out32, p.in32, p.desc.residual_noise, d_io, 1, out_scale)) != QMRI_OK) break;
             if (hipMemcpyAsync(out, d_io, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
             st = net_range_tripped(ctx, again);

@@ -185,20 +185,20 @@ __global__ __launch_bounds__(NT) void k_diag_final(const LsqrState* __restrict__
 // compact [B][C][W][H] (double or float) -> padded planes (im2single of a double is a cast, denoiseImage_PnP_ADMM.m:72-77)
 template <typename T>
 __global__ __launch_bounds__(NT) void k_pack(size_t count, int C, int plane, int H, int php, int pplane, size_t pbs,
-                                              const T* __restrict__ in, float* __restrict__ out) {
+                                              const T* __restrict__ in, float* __restrict__ out, float scale) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= count) return;
     const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
     const int w = rem / H, h = rem - w * H;
-    out[(size_t)b * pbs + (size_t)c * pplane + (size_t)(w + 1) * php + h + 1] = (float)in[(size_t)b * count + i];
+    out[(size_t)b * pbs + (size_t)c * pplane + (size_t)(w + 1) * php + h + 1] = (float)in[(size_t)b * count + i] * scale;   // (scale: a power of two)
 }
 
 // padded network output -> compact; optional residual I = input - CNN(input) (denoiseImage_PnP_ADMM.m:99-104,111-115)
 template <typename T>
 __global__ __launch_bounds__(NT) void k_unpack(size_t count, int plane, int H, int php, int pplane, size_t out_bs, size_t in_bs,
                                                 const float* __restrict__ out32, const float* __restrict__ in32,
-                                                int residual_noise, T* __restrict__ out) {
+                                                int residual_noise, T* __restrict__ out, float scale) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= count) return;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void k_unpack(size_t count, int plane, int H, i
     const size_t pi = (size_t)c * pplane + (size_t)(w + 1) * php + h + 1;
     float I = out32[(size_t)b * out_bs + pi];
     if (residual_noise) I = in32[(size_t)b * in_bs + pi] - I;
-    out[(size_t)b * count + i] = (T)I;
+    out[(size_t)b * count + i] = (T)(I * scale);
 }
 
 __global__ __launch_bounds__(NT) void k_real_to_complex(size_t count, const double* __restrict__ in, double2* __restrict__ out) {
@@ -247,27 +247,27 @@ int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, con
     return QMRI_OK;
 }
 
-int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst) {
+int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst, float scale) {
     const size_t count = (size_t)C * H * W;
     dim3 grid((unsigned)((count + NT - 1) / NT), B), blk(NT);
     if (src_is_double)
-        k_pack<double><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.hp, (int)dst.plane(), dst.batch_stride(), (const double*)src, dst.base1());
+        k_pack<double><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.hp, (int)dst.plane(), dst.batch_stride(), (const double*)src, dst.base1(), scale);
     else
-        k_pack<float><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.hp, (int)dst.plane(), dst.batch_stride(), (const float*)src, dst.base1());
+        k_pack<float><<<grid, blk, 0, ctx->stream>>>(count, C, H * W, H, dst.hp, (int)dst.plane(), dst.batch_stride(), (const float*)src, dst.base1(), scale);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
 
 int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& out32, const PTensor& in32, int residual_noise,
-                     void* dst, int dst_is_double) {
+                     void* dst, int dst_is_double, float scale) {
     const size_t count = (size_t)C * H * W;
     dim3 grid((unsigned)((count + NT - 1) / NT), B), blk(NT);
     if (dst_is_double)
         k_unpack<double><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.hp, (int)out32.plane(), out32.batch_stride(),
-                                                       in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, (double*)dst);
+                                                       in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, (double*)dst, scale);
     else
         k_unpack<float><<<grid, blk, 0, ctx->stream>>>(count, H * W, H, out32.hp, (int)out32.plane(), out32.batch_stride(),
-                                                      in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, (float*)dst);
+                                                      in32.batch_stride(), out32.base1(), in32.base1(), residual_noise, (float*)dst, scale);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }

@@ -261,9 +261,9 @@ int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H,
                                double* pz, int nblk_z);   // also z = v - u and the partials of ||z||^2 for the next x-update
 int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* x, const double2* gt,
                    double* pd, double* diag_slot, int iters_total, int it);
-int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst);
+int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst, float scale = 1.f);
 int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& out32, const PTensor& in32, int residual_noise,
-                     void* dst, int dst_is_double);
+                     void* dst, int dst_is_double, float scale = 1.f);
 int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out);
 
 // conv engine (conv_kernels.hip)
