@@ -21,6 +21,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md
+# HBM-side bytes per full k_tv_iter launch from two separate rocprofv3 --pmc passes (profiles/r01_i_pmc_lrtv_traffic.txt), raw counters
+TV_ITER_PMC_TRAFFIC_BYTES = (24545 + 39231) * 1024
 
 
 def main():
@@ -51,7 +53,7 @@ def main():
     avg_s = pr["ms_tv_iter"] / max(pr["n_tv_iter"], 1) * 1e-3
     roof = {"kernel": "k_tv_iter (one prox_tv iteration: sol = b - gamma div(r,s), objective shares, dual update + projection + momentum)",
             "bound": "hbm", "achieved": round(bytes_per_launch / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(bytes_per_launch / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+            "frac": round(bytes_per_launch / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": TV_ITER_PMC_TRAFFIC_BYTES, "avg_launch_us": round(avg_s * 1e6, 2),
             "launches_timed": int(pr["n_tv_iter"]), "bytes_per_launch": bytes_per_launch}
     cpu = None
     if not args.no_cpu_baseline:
