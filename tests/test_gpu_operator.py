@@ -123,3 +123,32 @@ def test_lsqr_epi_mask_vs_oracle(engine_mod, oracle, case224):
     assert (itg, flg) == (ito, flo)
     assert rel_err(xg, xo) < 1e-10
     e.close()
+
+
+@pytest.mark.parametrize("N,s,T,S", [(32, 6, 24, 120), (64, 10, 40, 300), (128, 8, 60, 500), (128, 3, 16, 200)])
+def test_other_grid_sizes_operator_lsqr_and_lrtv(engine_mod, oracle, synth, N, s, T, S):
+    """Every grid size the FFT kernels implement (32, 64, 128 beside 224), several channel counts: operator to 1e-12, the LSQR
+    x-update with the oracle's iteration count, a few LRTV iterations with identical counts."""
+    dic = synth.make_dictionary(T=T, n_t1=16, n_t2=12, s=s)
+    fp, k = oracle.spiral_mask(N, S, T)
+    fg, kg = engine_mod.build_spiral(N, S, T)
+    assert np.array_equal(fp, fg) and np.array_equal(k, kg)
+    op = oracle.Operator(N, N, dic["V"], fp, k)
+    e = engine_mod.Engine(0)
+    e.set_operator(N, N, dic["V"], fp, k)
+    rng = np.random.default_rng(N + s)
+    x = rng.standard_normal((N, N, s)) + 1j * rng.standard_normal((N, N, s))
+    y = rng.standard_normal(e.m) + 1j * rng.standard_normal(e.m)
+    assert rel_err(e.forward(x), op.forward(x)) < 1e-12
+    assert rel_err(e.adjoint(y), op.adjoint(y)) < 1e-12
+    yy = op.forward(x) + 0.01 * y
+    z = op.adjoint(yy) * 0.9
+    xg, ig, fg_ = e.xupdate(yy, z, 0.05, 1e-4, 100, x0=op.adjoint(yy))
+    xo, io, fo_, _ = op.lsqr(yy, z, 0.05, tol=1e-4, maxit=100, x0=op.adjoint(yy))
+    assert ig == io and fg_ == fo_
+    assert rel_err(xg, xo) < 1e-10
+    xl, il = e.lrtv(yy, K=1e-3, iters=5)
+    xlo, ilo = oracle.fista_lrtv(op, yy, K=1e-3, iters=5)
+    assert il["iters"] == ilo["iters"] and il["prox_iters_total"] == int(ilo["prox_iters"].sum()) and il["halvings"] == ilo["halvings"]
+    assert rel_err(xl, xlo) < 1e-9
+    e.close()
