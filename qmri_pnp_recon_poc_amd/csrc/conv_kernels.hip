@@ -490,7 +490,7 @@ size_t conv_pack_weights(const ConvLayer& L, const float* w, std::vector<float>&
 
 int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                 const PTensor* add2, int relu_out) {
-    if (L.wp6 && conv6_enabled()) {
+    if (L.wp6 && conv6_enabled() && !ctx->net.force_f32) {
         if (L.kind == CONV_3X3 || L.kind == CONV_3X3N) return conv6_launch(ctx, L, B, in, out, add1, add2, relu_out);
         if (!add1 && !add2 && !relu_out && conv6s_usable(L, in, out)) return conv6s_launch(ctx, L, B, in, out);
     }

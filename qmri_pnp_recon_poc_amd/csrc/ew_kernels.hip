@@ -272,6 +272,21 @@ int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& o
     return QMRI_OK;
 }
 
+// max |x| over a buffer (bit pattern of a non-negative float orders like an unsigned); NaN / Inf give 0x7f800000 or above.
+// Calibration only (qmri_set_denoiser), not on the path.
+__global__ __launch_bounds__(NT) void k_absmax(const float* __restrict__ x, const float* __restrict__ y, size_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT)
+        m = max(m, __float_as_uint(fabsf(y ? x[i] - y[i] : x[i])));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+int ew_launch_absmax(qmri_ctx* ctx, const float* x, const float* y, size_t n, unsigned* d_out) {
+    k_absmax<<<dim3(256), dim3(NT), 0, ctx->stream>>>(x, y, n, d_out);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
 int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out) {
     k_real_to_complex<<<dim3((unsigned)((count + NT - 1) / NT)), dim3(NT), 0, ctx->stream>>>(count, in, out);
     QMRI_HIP(ctx, hipGetLastError());

@@ -162,6 +162,7 @@ struct NetPlan {
     bool counter_by_memset = false;  // graph mode: the queue is reset before every launch instead
     hipGraphExec_t fwd_graph[9] = {};  // captured forward pass per batch size 1..8 (index B), null until the second call
     int fwd_calls[9] = {};
+    bool force_f32 = false;             // calibration (qmri_set_denoiser): run the f32-MFMA kernels whatever the scheme
     unsigned* d_range_flag = nullptr;   // f16 scheme: raised by a conv kernel whose output leaves the f16-splittable range
     int sp6 = 2;                     // scheme the layers are packed for
     std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
@@ -262,6 +263,7 @@ int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H,
 int ew_launch_diag(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B, const double2* x, const double2* gt,
                    double* pd, double* diag_slot, int iters_total, int it);
 int ew_launch_pack(qmri_ctx* ctx, int B, int C, int H, int W, const void* src, int src_is_double, const PTensor& dst, float scale = 1.f);
+int ew_launch_absmax(qmri_ctx* ctx, const float* x, const float* y, size_t n, unsigned* d_out);   // calibration: max |x - y| (y may be NULL) as a bit pattern
 int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& out32, const PTensor& in32, int residual_noise,
                      void* dst, int dst_is_double, float scale = 1.f);
 int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out);

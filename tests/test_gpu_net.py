@@ -181,32 +181,19 @@ def test_single_conv_weight_scaling(engine_mod, oracle, synth, wscale):
     e.close()
 
 
-def test_f16_scheme_absolute_floor_is_documented(engine_mod, oracle, synth):
-    """Activations far below 2.4e-4 carry the f16 split's absolute error of 2^-36 instead of fp32's relative 2^-24 (DESIGN.md
-    section 5.1).  Inputs and weights are rescaled, so this needs an INTERMEDIATE tensor that is tiny against its layer's input:
-    a first layer with 1e-9-scale weights.  The default scheme then loses relative accuracy; QMRI_CONV_SCHEME=bf16x6 keeps it."""
-    import subprocess
-    import sys
+def test_calibration_moves_a_pathological_gain_to_the_bf16_scheme(engine_mod, oracle, synth):
+    """Values far below 2.4e-4 carry the f16 split's absolute error of 2^-36 instead of fp32's relative 2^-24 (DESIGN.md section
+    5.1).  Inputs and weights are rescaled, so this needs an INTERMEDIATE tensor that is tiny against its layer's input -- here a
+    first layer with 1e-9-scale weights.  qmri_set_denoiser's probe (f16 kernels against the f32-MFMA kernels on a unit-scale
+    input) sees the 2e-3 disagreement and packs such a network for the bf16 scheme, so the result is the fp32 network's."""
     w, x = _two_layer_case(synth, 1e-9, 1.0)
     e = engine_mod.Engine(0)
     e.set_denoiser(w, 32, 32, in_nc=10, out_nc=10, nc=(32, 0, 0, 0), nb=2, arch=1)
     yo = oracle.Net(w, in_nc=10, out_nc=10, nc=(32, 0, 0, 0), nb=2, arch=1).denoise(x)
     err = rel_err(e.denoise(x), yo)
-    print(f"1e-7-scale intermediate tensor, f16 x 3: rel_err {err:.2e}")
-    assert err < 1e-2                                                # the floor: 1.5e-11 absolute on 1e-7-scale operands
+    print(f"1e-7-scale intermediate tensor: rel_err {err:.2e}")
+    assert err < 1e-5
     e.close()
-    np.savez(os.path.join(os.environ.get("TMPDIR", "/tmp"), "floor_case.npz"), w=w, x=x, yo=yo)
-    code = ("import os, sys, numpy as np\n"
-            "sys.path.insert(0, %r)\n"
-            "from qmri_pnp_recon_poc_amd import engine as E\n"
-            "g = np.load(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'floor_case.npz'))\n"
-            "e = E.Engine(0)\n"
-            "e.set_denoiser(g['w'], 32, 32, in_nc=10, out_nc=10, nc=(32, 0, 0, 0), nb=2, arch=1)\n"
-            "y = e.denoise(g['x'])\n"
-            "print(float(np.linalg.norm(y - g['yo']) / np.linalg.norm(g['yo'])))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, QMRI_CONV_SCHEME="bf16x6"), timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert float(r.stdout.strip().splitlines()[-1]) < 1e-5
 
 
 def test_denoiser_errors(engine_mod, synth):
