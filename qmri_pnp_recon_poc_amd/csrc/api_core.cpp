@@ -78,7 +78,7 @@ static void free_dev(void* p) { if (p) (void)hipFree(p); }
 void qmri_free_operator(qmri_ctx* ctx) {
     OpHost& o = ctx->op;
     void* ptrs[] = { o.d_Vt, o.d_ent, o.d_perm, o.d_kptr, o.d_tw, o.d_kslot, o.d_ginv, o.d_tmp, o.d_xa, o.d_xb, o.d_ya,
-                     o.ls.st, o.ls.pz, o.ls.yk,
+                     o.ls.st, o.ls.pz, o.ls.yk, o.ls.py,
                      (void*)o.ks.unit, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.sgrp,
                      o.ks.pu[0], o.ks.pu[1], o.ks.pv[0], o.ks.pv[1], o.ks.pinit, o.ks.pR, o.ks.cx, o.ks.cv, o.ks.cd, o.ks.cub,
                      o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.xhat_out, o.ks.stamps,
@@ -351,6 +351,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &o.d_ya, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &ls.st, B));
     QMRI_TRY(dev_alloc(ctx, &ls.pz, B * ls.nblk_z));
+    QMRI_TRY(dev_alloc(ctx, &ls.py, B * (size_t)DC_SORT_BLOCKS));
     for (int par = 0; par < 2; ++par) {
         QMRI_TRY(dev_alloc(ctx, &ks.pu[par], B * 2 * ks.G));
         QMRI_TRY(dev_alloc(ctx, &ks.pv[par], B * ks.G));

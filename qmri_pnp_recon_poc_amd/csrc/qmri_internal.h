@@ -107,11 +107,13 @@ struct LsqrState {
 };
 
 enum { DC_PLAIN = 0, DC_FWD_H_ONLY = 1, DC_DIAG = 3, DC_DIRECT = 4, DC_SPECTRUM = 5 };
+constexpr int DC_SORT_BLOCKS = 64;   // workgroups of k_sort_y per slice (partial sums of |y|^2 added in block order)
 
 struct LsqrDev {
     LsqrState* st;           // [B]
     double* pz;              // [B][nblk_z] partial sums of |z|^2
     double2* yk;             // [B][m]  y in k-sorted order
+    double* py;              // [B][DC_SORT_BLOCKS] partial sums of |y|^2 (k_sort_y)
     int nblk_z;
 };
 
