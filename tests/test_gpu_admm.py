@@ -145,3 +145,20 @@ def test_config2_epi_multi_level_batch_224(engine_mod, oracle, synth, case224):
         err = rel_err(res["X"][sl], xo)
         print(f"config2 slice {sl}: rel_err {err:.2e}, oracle lsqr iters {lo.tolist()}")
         assert err < 1e-4
+
+
+def test_recon_batch_two_workers(engine_mod, oracle, synth):
+    """qmri_recon_batch with two workers (host threads, one context each) -- both on device 0 here, one per GPU on a node: the
+    slice shards are disjoint, every slice comes back in its own slot, results equal the single-worker run bit for bit."""
+    from qmri_pnp_recon_poc_amd import batch
+    dic, X0, fp, k, op, y0, nc, w = _small_case(oracle, synth)
+    s = X0.shape[2]
+    ys = np.stack([synth.awgn_measured(op.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(32, seed=sl), dic)), 30.0, seed=sl)
+                   for sl in range(5)])
+    kw = dict(N=32, M=32, V=dic["V"], frame_ptr=fp, kidx=k, weights=w, in_nc=s, out_nc=s, nc=nc, nb=2, dictionary=dic, iters=4)
+    one = batch.recon_batch([0], ys, slices_per_launch=2, **kw)
+    two = batch.recon_batch([0, 0], ys, slices_per_launch=2, **kw)
+    assert np.array_equal(one["X"], two["X"])
+    assert np.array_equal(one["qmap"], two["qmap"])
+    xo, _, _ = oracle.pnp_admm(op, oracle.Net(w, in_nc=s, out_nc=s, nc=nc, nb=2), ys[4], iters=4)
+    assert rel_err(two["X"][4], xo) < 1e-4
