@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this process -- which never touches the GPU -- starts N worker
+processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU), waits for them and exits with their
+worst return code; rank 0 prints the JSON line.  Under `torch.distributed.run` the ranks are the workers directly.
+
 A "step" is ONE PnP-ADMM iteration (LSQR x-update + normalise + UNetRes denoiser + un-normalise + dual update,
 PnP_ADMM.m:93-146) on one 224 x 224 x 10 spiral-masked TSMI slice (BASELINE.json configs[1]: cut3, T = 200, S = 771,
 30 dB measured AWGN, gamma = 0.05, LSQR tol 1e-4 / maxit 100, single-level 10-channel DRUNet).  Every rank owns
@@ -16,14 +20,22 @@ The JSON line also carries
                   split into two f16 pieces (hi, scaled residual), three MFMA products per fp32-equivalent product; with
                   QMRI_CONV_SCHEME=bf16x6: three bf16 pieces, six products): MFMA FLOP executed per launch (3 x, resp. 6 x
                   the algorithmic 2*Cout*Cin*9*H*W) / mean launch duration measured live with HIP events on the launch
-                  stream, against the 2.5 PFLOP/s dense f16/bf16 MFMA peak; `fp32_equivalent_tflops` is the algorithmic rate
+                  stream, against the 2.5 PFLOP/s dense f16/bf16 MFMA peak; `fp32_equivalent_tflops` is the algorithmic rate;
+                  `traffic` = HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/, corrected as
+                  MI355X_MICROARCH.md section HBM prescribes; tools/pmc_traffic.py)
   cpu_baseline -- the CPU oracle (a C/OpenMP restatement of the shipped algorithm, `kind: port`) timed on this
-                  box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+                  box's host cores on a bounded sample of the same workload (rank 0, N = 1 only): all usable threads and
+                  one thread, per-stage split, diagnostics on (PnP_ADMM.m:106-109), CPU model string
+  parity       -- SURVEY.md section 8(d) metric 3, computed outside the timed region by the same oracle run that is the CPU
+                  baseline sample: mean per-channel PSNR of |x_gpu| against |x_oracle| (peak 1, main_recon_tsmis_FFT.m:362-367),
+                  fraction of pixels whose matched atom (T1/T2) is identical, PD relative error
 `--workload slices` instead times whole slices (100 ADMM iterations + dictionary match) over a per-GPU batch.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,15 +51,12 @@ BF16X6 = os.environ.get("QMRI_CONV_SCHEME", "") == "bf16x6"
 SPLIT_PRODUCTS = 6 if BF16X6 else 3   # MFMA products per fp32-equivalent product (conv6_kernels.hip: bf16 x 6 / f16 x 3)
 SCHEME_TEXT = ("v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate" if BF16X6 else
                "v_mfma_f32_32x32x16_f16, operands split into f16 (hi, scaled residual), 3 products, f32 accumulate")
-# HBM-side bytes per launch of the dominant kernel at the 224 x 224 x 64 level, from two separate rocprofv3 --pmc passes
-# (FETCH_SIZE, WRITE_SIZE; profiles/r01_g_pmc_conv_traffic.txt): 32 803 KB + 11 956 KB, raw counters.  Algorithmic: input with
-# halo 16.3 MB + residual 12.8 MB (every second layer) + output 12.8 MB + weights 0.2 MB per XCD.
-CONV6_PMC_TRAFFIC_BYTES = (32803 + 11956) * 1024
 CONV3X3_FLOP = 2 * 64 * 64 * 9 * 224 * 224      # 3 699 376 128: identical at all four UNetRes levels
 DENOISER_FLOP = 213_253_619_712                 # SURVEY.md section 8d (10-channel UNetRes at 224 x 224)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -57,22 +66,134 @@ def main():
     ap.add_argument("--batch", type=int, default=15, help="slices advanced together on one GPU (workload=slices): the whole per-GPU share in one launch sequence "
                     "(measured 8.8 / 9.7 / 10.1 slices/s at 5 / 8 / 15)")
     ap.add_argument("--solver", choices=["lsqr", "direct"], default="lsqr")
-    ap.add_argument("--dict-k", type=int, nargs=2, default=[384, 256], help="dictionary grid n_t1 n_t2 (K = product)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--dict-k", type=int, nargs=2, default=[384, 256], help="dictionary grid n_t1 n_t2 (K = product; workload=slices)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the parity numbers)")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="ADMM iterations of the CPU sample (0: as many of --steps as fit --cpu-budget-s)")
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="wall-clock bound of the all-threads CPU sample")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo + --one-device: rehearsal of the "
                     "multi-rank path on a single-GPU box; the ranks then share device 0, so the value is not a scaling result)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
-    args = ap.parse_args()
+    ap.add_argument("--plumbing-only", action="store_true", help="rank start-up, rendezvous, barrier and max-over-ranks only: no engine, no GPU "
+                    "(CPU test of the --gpus N path; the line carries value null)")
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: N worker processes of this script, one per GPU.  The parent initialises nothing on the GPU
+# (a process that has must never be replaced or forked into workers), it only waits.
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:            # a rank failed: the others would wait at the barrier for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def psnr_peak1(a, b) -> float:
+    """MATLAB psnr(A, ref) for doubles: peak 1 (main_recon_tsmis_FFT.m:362-367)."""
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return float("inf") if mse == 0.0 else 10.0 * np.log10(1.0 / mse)
+
+
+def parity_numbers(x_gpu, x_cpu, maps_gpu, maps_cpu, iters) -> dict:
+    """SURVEY.md section 8(d) metric 3: GPU output against the CPU restatement's output of the same reconstruction."""
+    s = x_gpu.shape[-1]
+    ps = [psnr_peak1(np.abs(x_gpu[..., c]), np.abs(x_cpu[..., c])) for c in range(s)]
+    same = maps_gpu["dm"] == maps_cpu["dm"]
+    diff = ~same
+    t1g, t1c = maps_gpu["qmap"][..., 0], maps_cpu["qmap"][..., 0]
+    t2g, t2c = maps_gpu["qmap"][..., 1], maps_cpu["qmap"][..., 1]
+    pg, pc = np.abs(maps_gpu["pd"]).astype(np.float64), np.abs(maps_cpu["pd"]).astype(np.float64)
+    finite = [p for p in ps if np.isfinite(p)]
+    return {"admm_iters_compared": int(iters),
+            "tsmi_rel_l2": float(np.linalg.norm((x_gpu - x_cpu).ravel()) / np.linalg.norm(x_cpu.ravel())),
+            "tsmi_psnr_db_mean": round(float(np.mean(finite)), 2) if finite else None,
+            "tsmi_psnr_db_min": round(float(np.min(finite)), 2) if finite else None,
+            "atom_index_identical_frac": round(float(same.mean()), 6),
+            "t1_mae_on_differing_px_s": round(float(np.abs(t1g[diff] - t1c[diff]).mean()), 6) if diff.any() else 0.0,
+            "t2_mae_on_differing_px_s": round(float(np.abs(t2g[diff] - t2c[diff]).mean()), 6) if diff.any() else 0.0,
+            "pd_rel_err": float(np.linalg.norm(pg - pc) / max(np.linalg.norm(pc), 1e-300)),
+            "tolerance": "LSQR tol 1e-4 leaves a stop-rule ambiguity of ~2e-4 per x-update (SURVEY 8 a7): tsmi_rel_l2 <= 1e-3 is parity"}
+
+
+def load_traffic(B: int):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (None when no pass has been recorded)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        return int(t["corrected_bytes_per_launch_per_slice"] * B), t.get("source")
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus = {world}", file=sys.stderr)
     import torch
     import torch.distributed as dist
     if args.one_device:
         local_rank = 0
+    if args.plumbing_only:
+        # the rank plumbing alone (CPU-runnable): rendezvous, barrier, max over ranks, one line from rank 0
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "ADMM iters/sec (224x224x10 TSMI, spiral mask)", "value": None, "unit": "ADMM iters/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "plumbing_only": True, "max_rank_seconds": round(dt, 4)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -95,6 +216,9 @@ def main():
     eng = E.Engine(local_rank)
     eng.set_operator(N, N, dic["V"], fp, k, max_batch=B)
     eng.set_denoiser(weights, N, N, max_batch=B)
+    eng.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    # torch's default stream is the NULL stream: the engine then keeps its own non-blocking stream, which is NOT ordered with
+    # torch's.  Every hand-over between torch work and engine work below is therefore bracketed by a device synchronize.
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def make_y(seed):
@@ -107,20 +231,33 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        eng.synchronize()
+
+    def admm_params(iters):
+        return AdmmParams(0.05, iters, 1e-4, 100, 0 if args.solver == "lsqr" else 1, 0, 0.01, 0)
+
+    def x_from_device(t):
+        return t.cpu().numpy().view(np.complex128).reshape((N, N, s), order="F")
 
     n = N * N * s
-    result = {}
     if args.workload == "admm":
         y = make_y(rank)
+        y_parity = y
         d_y = torch.from_numpy(np.ascontiguousarray(y).view(np.float64)).to(dev)
         d_x = torch.empty(2 * n, dtype=torch.float64, device=dev)
         li = np.zeros(max(args.steps, args.warmup, 1), np.int32)
+        torch.cuda.synchronize()
 
         def run(iters):
-            p = AdmmParams(0.05, iters, 1e-4, 100, 0 if args.solver == "lsqr" else 1, 0, 0.01, 0)
+            p = admm_params(iters)
             st = eng.L.qmri_pnp_admm_dev(eng.h, 1, C.c_void_p(d_y.data_ptr()), C.byref(p), None, None, C.c_void_p(d_x.data_ptr()),
                                          None, li.ctypes.data_as(C.POINTER(C.c_int32)))
             eng._check(st)
+
+        def gpu_x_after(iters):
+            run(iters)
+            eng.synchronize()
+            return x_from_device(d_x)
 
         run(args.warmup)
         barrier()
@@ -128,22 +265,22 @@ def main():
         run(args.steps)
         barrier()
         dt = time.perf_counter() - t0
-        steps_done = args.steps
         lsqr_mean = float(li[: args.steps].mean()) if args.steps else 0.0
         unit_count = args.steps                                  # ADMM iterations per rank
         result_extra = {"lsqr_iters_mean": lsqr_mean}
     else:
         nsl = args.slices_per_gpu
-        eng.set_dictionary(dic["D"], dic["normD"], dic["lut"])
         ys = np.stack([make_y(rank * nsl + i) for i in range(nsl)])
+        y_parity = ys[0]
         d_y = torch.from_numpy(np.ascontiguousarray(ys).view(np.float64)).to(dev)
         d_x = torch.empty((B, 2 * n), dtype=torch.float64, device=dev)
         d_q = torch.empty(N * N * 2, dtype=torch.float32, device=dev)
         d_pd = torch.empty(N * N * 2, dtype=torch.float32, device=dev)
         m = eng.m
+        torch.cuda.synchronize()
 
         def run_slices(count, iters):
-            p = AdmmParams(0.05, iters, 1e-4, 100, 0 if args.solver == "lsqr" else 1, 0, 0.01, 0)
+            p = admm_params(iters)
             for s0 in range(0, count, B):
                 cnt = min(B, count - s0)
                 yptr = d_y.data_ptr() + s0 * m * 16
@@ -151,6 +288,12 @@ def main():
                 for i in range(cnt):
                     eng._check(eng.L.qmri_dict_match_dev(eng.h, C.c_void_p(d_x.data_ptr() + i * n * 16), N * N, C.c_void_p(d_q.data_ptr()),
                                                          C.c_void_p(d_pd.data_ptr()), None, None))
+
+        def gpu_x_after(iters):
+            p = admm_params(iters)
+            eng._check(eng.L.qmri_pnp_admm_dev(eng.h, 1, C.c_void_p(d_y.data_ptr()), C.byref(p), None, None, C.c_void_p(d_x.data_ptr()), None, None))
+            eng.synchronize()
+            return x_from_device(d_x[0])
 
         run_slices(min(B, nsl), max(args.warmup, 1))
         barrier()
@@ -174,9 +317,10 @@ def main():
         eng.profile_enable(2)
         d_in = torch.rand(B * s * N * N, dtype=torch.float32, device=dev)
         d_out = torch.empty(B * s * N * N, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()                                  # d_in is filled on torch's stream, read on the engine's
         for _ in range(3):
             eng._check(eng.L.qmri_net_forward_dev(eng.h, C.c_void_p(d_in.data_ptr()), B, C.c_void_p(d_out.data_ptr())))
-        torch.cuda.synchronize()
+        eng.synchronize()
         pr = eng.profile_get(reset=True)
         eng.profile_enable(0)
         if pr["n_conv3x3"] > 0:
@@ -190,9 +334,11 @@ def main():
                         "flop_per_launch": CONV3X3_FLOP * B}
             else:
                 ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
+                traffic, tsrc = load_traffic(B)
                 roof = {"kernel": f"k_conv6 (implicit-GEMM conv3x3 on {SCHEME_TEXT})",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": CONV6_PMC_TRAFFIC_BYTES * B, "avg_launch_us": round(avg_s * 1e6, 2),
+                        "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches_timed": int(pr["n_conv3x3"]), "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B,
                         "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3), "fp32_equivalent_flop_per_launch": CONV3X3_FLOP * B,
                         # what the chip sustains on toggling operands with every SIMD issuing MFMAs back to back: 22.1 ns per 32x32x16
@@ -209,25 +355,52 @@ def main():
             result_extra["stage_ms_per_iter"] = {"xupdate": round(pr["ms_xupdate"] / it, 4), "denoiser": round(pr["ms_denoiser"] / it, 4),
                                                  "elementwise": round(pr["ms_elementwise"] / it, 4)}
 
-    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ------------------------------
+    # ---- CPU baseline + parity: the oracle on this box's host cores, bounded sample -----------------------
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         O.build()
         fo, ko = O.spiral_mask(N, S, T)
         op = O.Operator(N, N, dic["V"], fo, ko)
         net = O.Net(weights)
-        y0 = make_y(0) if args.workload != "admm" else y
         cores = O.num_threads()
+
+        def oracle_admm(iters):
+            t0 = time.perf_counter()
+            xo, _, lio = O.pnp_admm(op, net, y_parity, gamma=0.05, iters=iters, cg_tol=1e-4, cg_maxit=100, solver=args.solver, want_diag=True)
+            return xo, lio, time.perf_counter() - t0, O.admm_stage_seconds()
+
+        _, _, t_probe, _ = oracle_admm(2)                         # probe (also warms caches and the OpenMP pool)
+        per_iter = t_probe / 2
+        n_cpu = args.cpu_iters if args.cpu_iters > 0 else int(max(3, min(args.steps, args.cpu_budget_s / max(per_iter, 1e-6))))
+        xo, lio, tc, stages = oracle_admm(n_cpu)
         t0 = time.perf_counter()
-        O.pnp_admm(op, net, y0, gamma=0.05, iters=args.cpu_iters, cg_tol=1e-4, cg_maxit=100, solver="lsqr")
-        tc = time.perf_counter() - t0
+        maps_o = O.dict_match(xo, dic["D"], dic["normD"], dic["lut"])
+        t_match = time.perf_counter() - t0
+        O.set_num_threads(1)
+        _, _, t1, _ = oracle_admm(1)
+        O.set_num_threads(cores)
+        stage_ms = {k_: round(v / n_cpu * 1e3, 2) for k_, v in stages.items()}
+        common = {"cores": cores, "kind": "port", "cpu_model": cpu_model(), "one_thread_value": None,
+                  "stage_ms_per_iter": stage_ms, "dict_match_s": round(t_match, 3), "dict_K": int(dic["K"]), "diagnostics": "on (PnP_ADMM.m:106-109)"}
         if args.workload == "admm":
-            cpu = {"value": round(args.cpu_iters / tc, 4), "unit": "ADMM iters/s", "cores": cores, "kind": "port",
-                   "sample": f"first {args.cpu_iters} PnP-ADMM iterations of the same slice (LSQR tol 1e-4 fp64 + UNetRes fp32), {tc:.1f} s"}
+            cpu = {"value": round(n_cpu / tc, 4), "unit": "ADMM iters/s",
+                   "sample": f"first {n_cpu} PnP-ADMM iterations of the same slice (LSQR tol 1e-4 fp64 + UNetRes fp32, diagnostics on), {tc:.1f} s; "
+                             f"one thread: 1 iteration, {t1:.1f} s", **common}
+            cpu["one_thread_value"] = round(1.0 / t1, 4)
         else:
-            cpu = {"value": round(args.cpu_iters / tc / args.steps, 6), "unit": "slices/s", "cores": cores, "kind": "port",
-                   "sample": f"{args.cpu_iters} PnP-ADMM iterations of one slice extrapolated to {args.steps} per slice, match excluded, {tc:.1f} s"}
+            per_slice = tc / n_cpu * args.steps + t_match
+            cpu = {"value": round(1.0 / per_slice, 6), "unit": "slices/s",
+                   "sample": f"{n_cpu} PnP-ADMM iterations of slice 0 ({tc:.1f} s) extrapolated to {args.steps} per slice + its dictionary match "
+                             f"({t_match:.2f} s); one thread: 1 iteration, {t1:.1f} s", **common}
+            cpu["one_thread_value"] = round(1.0 / (t1 * args.steps + t_match * cores), 6)
+        # parity on the slice that was timed, after the same number of iterations the oracle ran
+        xg = gpu_x_after(n_cpu)
+        maps_g = eng.dict_match(xg)
+        parity = parity_numbers(xg, xo, maps_g, maps_o, n_cpu)
+        if args.workload == "admm" and n_cpu <= len(li):
+            parity["lsqr_iteration_counts_identical"] = bool(np.array_equal(li[:n_cpu], lio[:n_cpu]))
 
     if rank == 0:
         total_units = unit_count * world
@@ -239,18 +412,27 @@ def main():
                    "parallelism": f"slice-parallel x{world} (no collective)"}
             ms_per_step = dt / max(args.steps, 1) * 1e3
         else:
-            metric, unit = "slices/sec (120-slice synthetic batch: 100 ADMM iterations + dictionary match per slice)", "slices/s"
+            metric = f"slices/sec ({unit_count * world}-slice synthetic batch: {args.steps} ADMM iterations + dictionary match per slice)"
+            unit = "slices/s"
             cfg = {"workload": f"cut3 {unit_count}-slice batch per GPU, spiral mask, PnP-ADMM + UNetRes + dictionary match K={int(dic['K'])}",
-                   "solver": args.solver, "admm_iters": args.steps, "dc_dtype": "f64", "parallelism": f"slice-parallel x{world} (no collective)"}
+                   "solver": args.solver, "admm_iters": args.steps, "dc_dtype": "f64",
+                   "denoiser_arith": "f32 results: all convs on " + SCHEME_TEXT, "parallelism": f"slice-parallel x{world} (no collective)"}
             ms_per_step = dt / max(unit_count, 1) * 1e3
         out = {"metric": metric, "value": round(total_units / dt, 4), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-               "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
+               "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu, "parity": parity}
         out.update(result_extra)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -79,6 +79,7 @@ def lib():
         L.orc_net_forward.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, fp]
         L.orc_denoise.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
         L.orc_pnp_admm.argtypes = [vp, vp, dp, C.POINTER(AdmmParams), dp, dp, dp, dp, ip]
+        L.orc_admm_stage_seconds.argtypes = [dp]
         L.orc_dict_match.argtypes = [dp, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_double,
                                      fp, fp, fp, ip, fp]
         L.orc_norm_tv.restype = C.c_double
@@ -244,6 +245,13 @@ def pnp_admm(op: Operator, net: Net, y, gamma=0.05, iters=100, cg_tol=1e-4, cg_m
     lib().orc_pnp_admm(op.h, net.h, _dp(yin), C.byref(p), _dp(x0in), _dp(gtin), _dp(x), _dp(diag), _ip(li))
     xo = x.view(np.complex128).reshape((op.N, op.M, op.s), order="F")
     return xo, (diag.reshape(iters, 2) if diag is not None else None), li
+
+
+def admm_stage_seconds() -> dict:
+    """Wall-clock split of the most recent pnp_admm call (bench.py cpu_baseline)."""
+    t = np.zeros(4, np.float64)
+    lib().orc_admm_stage_seconds(_dp(t))
+    return {"xupdate": float(t[0]), "diagnostics": float(t[1]), "denoiser": float(t[2]), "elementwise": float(t[3])}
 
 
 def norm_tv(I):

@@ -10,6 +10,12 @@
  * Parameters main_recon_tsmis_FFT.m:285-292; noise map build_noise_map.m:19 (constant plane).
  */
 #include "orc_internal.h"
+#include <omp.h>
+
+/* wall-clock split of the most recent orc_pnp_admm call (bench.py cpu_baseline; not thread-safe, one call at a time):
+ * [0] lsqr x-update, [1] the two diagnostics, [2] denoiser incl. casts, [3] normalise / un-normalise / dual update */
+static double g_stage_s[4];
+void orc_admm_stage_seconds(double* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_stage_s[i]; }
 
 void orc_pnp_admm(const orc_op* op, const orc_net* net, const double* y, const orc_admm_params* p,
                   const double* x0, const double* gt, double* x_out, double* diag_out,
@@ -37,13 +43,17 @@ void orc_pnp_admm(const orc_op* op, const orc_net* net, const double* y, const o
         if (gt) { for (size_t i = 0; i < n2; ++i) ngt += gt[i] * gt[i]; ngt = sqrt(ngt); }
     }
 
+    for (int i = 0; i < 4; ++i) g_stage_s[i] = 0.0;
     for (int it = 0; it < p->iters; ++it) {
         /* Step 1: x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2 */
+        double t0 = omp_get_wtime();
         for (size_t i = 0; i < n2; ++i) z[i] = v[i] - u[i];
         int li = 0, lf = 0;
         if (p->solver == 0) orc_lsqr_xupdate(op, y, z, p->gamma, p->cg_tol, p->cg_maxit, x, &li, &lf, NULL);
         else orc_direct_xupdate(op, y, z, p->gamma, x);
         if (lsqr_iters_out) lsqr_iters_out[it] = li;
+        double t1 = omp_get_wtime();
+        g_stage_s[0] += t1 - t0;
 
         if (p->want_diag && diag_out) {                         /* :106-107 */
             orc_forward(op, x, ym);
@@ -54,6 +64,8 @@ void orc_pnp_admm(const orc_op* op, const orc_net* net, const double* y, const o
             else diag_out[2 * it + 1] = NAN;
         }
 
+        t0 = omp_get_wtime();
+        g_stage_s[1] += t0 - t1;
         /* Step 2: v = real(x + uold); normalise to [0,1] over the whole stack (:174-184) */
         double lo = INFINITY, hi = -INFINITY;
         for (size_t i = 0; i < n; ++i) {
@@ -66,11 +78,16 @@ void orc_pnp_admm(const orc_op* op, const orc_net* net, const double* y, const o
         for (size_t i = 0; i < n; ++i) w[i] = (w[i] - lo) / range;
         if (p->multi_level)                                     /* cat(3, v, noise_map) :132 */
             for (size_t i = 0; i < plane; ++i) w[n + i] = p->noise_std;
+        t1 = omp_get_wtime();
+        g_stage_s[3] += t1 - t0;
         orc_denoise(net, w, N, M, Cin, 1, p->residual_noise, wo);   /* net(v) */
+        t0 = omp_get_wtime();
+        g_stage_s[2] += t0 - t1;
         /* undo normalisation :138,187-192 ; v becomes real */
         for (size_t i = 0; i < n; ++i) { v[2 * i] = wo[i] * range + lo; v[2 * i + 1] = 0.0; }
         /* Step 3: uold = uold + x - v */
         for (size_t i = 0; i < n2; ++i) u[i] = u[i] + x[i] - v[i];
+        g_stage_s[3] += omp_get_wtime() - t0;
     }
     free(v); free(u); free(z); free(ym); free(w); free(wo);
 }

@@ -93,6 +93,8 @@ void orc_pnp_admm(const orc_op* op, const orc_net* net, const double* y, const o
                   const double* x0 /* nullable => adjoint(y) */, const double* gt /* nullable */,
                   double* x_out, double* diag_out /* iters x 2, nullable */,
                   int32_t* lsqr_iters_out /* iters, nullable */);
+/* seconds the most recent orc_pnp_admm call spent in {lsqr x-update, diagnostics, denoiser, elementwise} */
+void orc_admm_stage_seconds(double* out4);
 
 /* ---- a13: dictionary match -------------------------------------------------------------------- */
 /* mrf_dtm_cpu.m:50-54,74-98,136-160.  X: Npix x s complex double (col-major: X[p + Npix*c]).

@@ -326,7 +326,9 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         sgrp[ns] = (int32_t)grp.size();
         ks.ns = ns; ks.G = (int)bslot.size() - 1;
         ks.vcap = ((T * s + 10 + 15) / 16) * 16;       // (+10: the channel loops of the kernels are unrolled to 10)
-        if ((size_t)ks.vcap * 8 + (size_t)s * M * 16 > 96 * 1024) {
+        bool v_fits = false;
+        QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, &v_fits));
+        if (!v_fits) {     // T = 1000, s = 10 (cut0, main_recon_tsmis_FFT.m:41-44) needs 80 KB of the CU's 160 KB; T*s <~ 14 900 fits
             qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
             return QMRI_ERR_UNSUPPORTED;
         }

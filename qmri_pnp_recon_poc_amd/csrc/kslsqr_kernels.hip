@@ -506,8 +506,16 @@ __global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* 
     }
 }
 
-int allow_big_lds(qmri_ctx* ctx, const void* fn) {
-    QMRI_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+constexpr size_t KS_LDS_TOTAL = 160 * 1024;   // LDS of one CU (MI355X_MICROARCH: a single workgroup may declare all of it)
+
+// Dynamic LDS (the row's spectrum lines + V) a kernel may use = the CU's 160 KB minus its static arrays.  V for the
+// longest cut of the reference (cut0: T = 1000, s = 10, main_recon_tsmis_FFT.m:41-44) is 80 KB.
+int allow_big_lds(qmri_ctx* ctx, const void* fn, size_t* max_dyn = nullptr) {
+    hipFuncAttributes fa;
+    QMRI_HIP(ctx, hipFuncGetAttributes(&fa, fn));
+    const size_t dyn = KS_LDS_TOTAL - std::min(KS_LDS_TOTAL, (size_t)fa.sharedSizeBytes);
+    QMRI_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    if (max_dyn) *max_dyn = dyn;
     return QMRI_OK;
 }
 
@@ -519,7 +527,32 @@ int launch_final_t(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, doubl
     return QMRI_OK;
 }
 
+template <int N, int R1, int R2>
+int lds_fits_t(qmri_ctx* ctx, int s, int M, int vcap, bool* ok) {
+    const size_t vb = (size_t)vcap * 8;
+    const void* fns[5] = {(const void*)k_ks_init_a<N>, (const void*)k_ks_a, (const void*)k_ks_b<true>, (const void*)k_ks_b<false>,
+                          (const void*)k_ks_final_w<R1, R2>};
+    const size_t need[5] = {(size_t)s * M * 16 + vb, vb, vb, vb, vb};
+    *ok = true;
+    for (int i = 0; i < 5; ++i) {
+        size_t dyn = 0;
+        QMRI_TRY(allow_big_lds(ctx, fns[i], &dyn));
+        if (need[i] > dyn) *ok = false;
+    }
+    return QMRI_OK;
+}
+
 }  // namespace
+
+// Does V (vcap doubles) fit next to the other LDS arrays of every k-space LSQR kernel for this grid?
+int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok) {
+    switch (N) {
+        case 224: return lds_fits_t<224, 16, 14>(ctx, s, M, vcap, ok);
+        case 128: return lds_fits_t<128, 16, 8>(ctx, s, M, vcap, ok);
+        case 64: return lds_fits_t<64, 8, 8>(ctx, s, M, vcap, ok);
+        default: return lds_fits_t<32, 8, 4>(ctx, s, M, vcap, ok);
+    }
+}
 
 static int ks_attrs(qmri_ctx* ctx) {
     if (ctx->ks_lds_attr[0]) return QMRI_OK;

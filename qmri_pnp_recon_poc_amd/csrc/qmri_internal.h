@@ -249,6 +249,7 @@ int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, d
 int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
 int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
 int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);   // tmp <- conj-domain inverse w-pass of xhat
+int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok);   // V (vcap doubles) fits the LDS of every k-space LSQR kernel
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
                      double2* tmp, double2* x_out);
 // y (ABI order) -> k-sorted order, plus ||y||^2 into state

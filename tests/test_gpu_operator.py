@@ -152,3 +152,39 @@ def test_other_grid_sizes_operator_lsqr_and_lrtv(engine_mod, oracle, synth, N, s
     assert il["iters"] == ilo["iters"] and il["prox_iters_total"] == int(ilo["prox_iters"].sum()) and il["halvings"] == ilo["halvings"]
     assert rel_err(xl, xlo) < 1e-9
     e.close()
+
+
+@pytest.mark.parametrize("mask", ["spiral", "epi"])
+@pytest.mark.parametrize("T", [100, 300, 500, 1000])
+def test_every_cut_operator_and_lsqr_224(engine_mod, oracle, synth, T, mask):
+    """main_recon_tsmis_FFT.m:41-44 lists cut0..cut4 = T 1000/500/300/200/100 as a one-variable switch: every cut must run
+    (T = 200 is the module fixture).  cut0's V (1000 x 10 doubles = 80 KB) sits in LDS next to the row spectra of the k-space
+    LSQR kernels.  Operator to 1e-12 (fp64 both sides), LSQR x-update with the oracle's iteration count and flag, x to 1e-10."""
+    N, s = 224, 10
+    dic = synth.make_dictionary(T=T, n_t1=32, n_t2=16, s=s)
+    if mask == "spiral":
+        fp, k = oracle.spiral_mask(N, 771, T)
+        fg, kg = engine_mod.build_spiral(N, 771, T)
+    else:
+        fp, k = oracle.epi_mask(N, N, 1 / 65, T)
+        fg, kg = engine_mod.build_epi(N, N, 1 / 65, T)
+        assert fp[-1] == 3 * 224 * T
+    assert np.array_equal(fp, fg) and np.array_equal(k, kg)
+    op = oracle.Operator(N, N, dic["V"], fp, k)
+    e = engine_mod.Engine(0)
+    e.set_operator(N, N, dic["V"], fp, k)
+    assert e.m == op.m == fp[-1]
+    rng = np.random.default_rng(T)
+    x = rng.standard_normal((N, N, s)) + 1j * rng.standard_normal((N, N, s))
+    y = rng.standard_normal(e.m) + 1j * rng.standard_normal(e.m)
+    assert rel_err(e.forward(x), op.forward(x)) < 1e-12
+    assert rel_err(e.adjoint(y), op.adjoint(y)) < 1e-12
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=1), dic)
+    yy = synth.awgn_measured(op.forward(X0), 30.0, seed=T)
+    x0 = op.adjoint(yy)
+    z = 0.9 * x0
+    xo, io, fo, _ = op.lsqr(yy, z, 0.05, 1e-4, 100, x0)
+    xg, ig, fg_ = e.xupdate(yy, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    assert (ig, fg_) == (io, fo)
+    assert rel_err(xg, xo) < 1e-10
+    e.close()
