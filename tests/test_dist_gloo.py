@@ -39,3 +39,26 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert outs[0]["slices"] == list(range(0, 8)) and outs[1]["slices"] == list(range(8, 15))
     assert abs(outs[0]["dt"] - outs[1]["dt"]) < 1e-9 and outs[0]["dt"] >= 0.2     # max over ranks, identical on both
     assert outs[0]["maxlen"] == 8.0
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher must itself become 2 ranks (the parent never touches the GPU, it starts
+    N workers with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and relays rank 0's line).  --plumbing-only keeps the engine out,
+    so the rank start-up, rendezvous, barrier and max-over-ranks run here without a GPU; tests/test_gpu_bench.py runs the
+    real two-rank bench on the GPU box."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # one JSON line, from rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["plumbing_only"] is True and out["steps"] == 3
+    assert out["max_rank_seconds"] >= 0.02                 # the slower rank (rank 1 sleeps 20 ms) sets the time
+    # a failing rank must take the job down with a non-zero exit code, not hang it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--no-roofline", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0                           # no GPU here: the workers refuse (no CPU path), the parent reports it
