@@ -11,8 +11,10 @@
  * The blocked loop only bounds MATLAB's temporary; results do not depend on it, so block_size is accepted
  * and the same per-pixel arithmetic is applied to every pixel.
  * Arithmetic made explicit (MATLAB's BLAS order is unspecified): ip accumulates c = 0..s-1 as an fmaf chain,
- * |ip|^2 = fmaf(im,im,re*re), mt = sqrtf(|ip|^2).  The same chain is what a f32 MFMA executes, so the
- * product's atom indices can be compared bit-exactly.
+ * abs(ip) = sqrtf(fmaf(im,im,re*re)) in single, and the maximum is taken over those single-precision magnitudes as
+ * max(abs(ip)) does (:92): two atoms whose |ip|^2 differ in the last bits but whose magnitudes round to the same single
+ * are a tie, and the first index wins.  The same chain is what a f32 MFMA executes, so the product's atom indices can
+ * be compared bit-exactly.
  */
 #include "orc_internal.h"
 
@@ -36,11 +38,11 @@ void orc_dict_match(const double* X, int Npix, int s, const float* D, const floa
                 re = fmaf(d, xr[c], re);
                 im = fmaf(d, -xi[c], im);                                /* conj(x) */
             }
-            const float mag2 = fmaf(im, im, re * re);
-            if (mag2 > best) { best = mag2; bj = j; bre = re; bim = im; }
+            const float mag = sqrtf(fmaf(im, im, re * re));             /* abs(ip) :92 */
+            if (mag > best) { best = mag; bj = j; bre = re; bim = im; }  /* strict: the first index wins ties */
         }
         if (dm) dm[p] = bj + 1;
-        if (mt) mt[p] = sqrtf(best);
+        if (mt) mt[p] = best;
         if (pd) { pd[2 * p] = bre / normD[bj]; pd[2 * p + 1] = bim / normD[bj]; }
         if (qmap)
             for (int q = 0; q < Q; ++q) {

@@ -99,8 +99,9 @@ void orc_admm_stage_seconds(double* out4);
 /* ---- a13: dictionary match -------------------------------------------------------------------- */
 /* mrf_dtm_cpu.m:50-54,74-98,136-160.  X: Npix x s complex double (col-major: X[p + Npix*c]).
  * D: K x s (col-major D[j + K*c]) fp32, normD K, lut K x Q col-major.  Outputs nullable.
- * Arithmetic: ip = fmaf chain over c = 0..s-1 (the k-ordered chain of a f32 MFMA), |ip|^2 =
- * fmaf(im,im,re*re), strict '>' so the first index wins ties (MATLAB max). dm is 1-based. */
+ * Arithmetic: ip = fmaf chain over c = 0..s-1 (the k-ordered chain of a f32 MFMA), abs(ip) =
+ * sqrtf(fmaf(im,im,re*re)), maximum over those magnitudes with strict '>' so the first index wins ties
+ * (MATLAB max(abs(ip))). dm is 1-based. */
 void orc_dict_match(const double* X, int Npix, int s, const float* D, const float* normD,
                     const float* lut, int K, int Q, double block_size, float* qmap, float* pd,
                     float* mt, int32_t* dm, float* Xfit);

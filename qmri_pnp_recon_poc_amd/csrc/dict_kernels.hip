@@ -12,6 +12,11 @@
 // reduces |ip|^2 to a running (max, argmax) in the epilogue.  A f32 MFMA accumulates k in order with one
 // fma per product, so ip is bit-identical to a sequential fmaf chain over c = 0..s-1 -- the arithmetic the
 // oracle spells out -- and the argmax can be checked bit-exactly.
+// max(abs(ip)) compares single-precision MAGNITUDES: two atoms whose |ip|^2 differ in the last bits but whose
+// sqrtf rounds to the same single tie, and the first index wins (:92).  The loop keeps that semantics without a
+// square root per candidate: beside the best magnitude it holds `thr`, the largest |ip|^2 whose correctly rounded
+// square root is still that magnitude; a candidate beats the incumbent iff its |ip|^2 exceeds thr.  The square
+// root (and the 1-4 neighbours of thr) are evaluated only when the incumbent changes.
 //
 // Work split: one workgroup (4 waves) per 32-pixel tile; wave w takes atom tiles w, w+4, ...; the four
 // (max, argmax) candidates per pixel are merged through LDS preferring the lower index on ties.
@@ -22,6 +27,16 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NT = 256;
 constexpr int MAXPAIR = 8;      // s <= 16
+
+// largest float whose correctly rounded square root is still s = sqrtf(m2)  (a handful of floats share one root)
+__device__ __forceinline__ float sqrt_preimage_top(float m2, float s) {
+    float t = m2;
+    for (int it = 0; it < 8; ++it) {
+        const float n = __uint_as_float(__float_as_uint(t) + 1u);      // next float up (t >= 0)
+        if (__fsqrt_rn(n) == s) t = n; else break;
+    }
+    return t;
+}
 
 // D packed as MFMA A-fragments: pack[tile][pair q][lane] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s)
 template <int NPAIR>
@@ -46,7 +61,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
         bre[q] = (float)v.x;                   // single(x)  mrf_dtm_cpu.m:54
         bim[q] = -(float)v.y;                  // conj
     }
-    float best = -1.0f, cre = 0.f, cim = 0.f;
+    float best = -1.0f, thr = -1.0f, cre = 0.f, cim = 0.f;      // best = abs(ip) of the incumbent, thr: see the header
     int bidx = 0;
     for (int t = wave; t < ntiles; t += 4) {
         const float* ap = pack + ((size_t)t * NPAIR) * 64 + lane;
@@ -64,7 +79,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             const float re = are[r], im = aim[r];
             const float m2 = __builtin_fmaf(im, im, re * re);
             const int atom = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D row of the 32x32 MFMA tile
-            if (m2 > best) { best = m2; bidx = atom; cre = re; cim = im; }
+            if (m2 > thr) { best = __fsqrt_rn(m2); thr = sqrt_preimage_top(m2, best); bidx = atom; cre = re; cim = im; }
         }
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
         if (bidx >= K) bidx = 0;       // cannot happen: padded atoms are all-zero and never beat a real one
         const float nd = normD[bidx];
         if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
-        if (mt) mt[p] = sqrtf(best);                                 // :150-154
+        if (mt) mt[p] = best;                                        // :150-154
         if (pd) { pd[2 * (size_t)p] = cre / nd; pd[2 * (size_t)p + 1] = cim / nd; }     // :96,:144-148
         if (qmap)
             for (int q = 0; q < Q; ++q) {

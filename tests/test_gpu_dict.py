@@ -38,3 +38,44 @@ def test_dict_match_edge_cases(engine_mod, oracle, synth):
     assert g["qmap"][1, 1, 1] == 0.0
     assert np.array_equal(g["pd"], o["pd"])                         # same bits (no NaNs involved)
     e.close()
+
+
+def test_dict_match_magnitude_ties(engine_mod, oracle):
+    """max(abs(ip)) compares single-precision magnitudes (mrf_dtm_cpu.m:92): atoms whose |ip|^2 differ in the last bits but whose
+    abs is the same single tie, first index wins.  The constructed fixture (tools/gen_matlab_rows.py) and a stress case where
+    thousands of atoms sit within a few ulps of the maximum -- the kernel's threshold bookkeeping against the oracle's plain
+    sqrtf-per-candidate loop, bit for bit."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "matlab_rows_dictmatch.npz"))
+    ones, lut = np.ones(6, np.float32), np.zeros((6, 2), np.float32)
+    e = engine_mod.Engine(0)
+    for D, want in ((g["Dt"], 2), (g["Dt2"], 1)):
+        e.set_dictionary(D, ones, lut)
+        r = e.dict_match(g["xt"])
+        assert r["dm"][0] == want and r["mt"][0] == np.float32(1.0)
+    # stress: K atoms = one direction + perturbations of a few ulps, in random order; 40 x 40 pixels along nearby directions
+    rng = np.random.default_rng(9)
+    K, s = 6000, 10
+    base = rng.standard_normal(s).astype(np.float32)
+    base /= np.linalg.norm(base)
+    D = np.repeat(base[None, :], K, axis=0)
+    bits = D.view(np.int32) + rng.integers(-3, 4, size=D.shape, dtype=np.int32)
+    D = bits.view(np.float32).copy()
+    nd = np.ones(K, np.float32)
+    lut = np.stack([np.arange(K), np.arange(K)], axis=1).astype(np.float32)
+    X = (base[None, None, :] * (1.0 + rng.random((40, 40, 1)))) * np.exp(1j * rng.random((40, 40, 1)) * 6.28)
+    X = X + 1e-7 * rng.standard_normal(X.shape)
+    e.set_dictionary(D, nd, lut)
+    gq = e.dict_match(X)
+    oq = oracle.dict_match(X, D, nd, lut)
+    assert np.array_equal(gq["dm"], oq["dm"]) and np.array_equal(gq["mt"], oq["mt"]) and np.array_equal(gq["pd"], oq["pd"])
+    # and the semantics matter on this input: an argmax over |ip|^2 picks a different atom for a good share of the pixels
+    x32 = X.reshape(-1, s).astype(np.complex64)
+    re = np.zeros((K, x32.shape[0]), np.float32); im = np.zeros_like(re)
+    for c in range(s):
+        re = (re + D[:, c:c + 1] * x32[:, c].real[None, :]).astype(np.float32)
+        im = (im - D[:, c:c + 1] * x32[:, c].imag[None, :]).astype(np.float32)
+    print("pixels where argmax |ip|^2 (numpy, unfused) differs from max(abs(ip)):",
+          float(np.mean((np.argmax(re * re + im * im, axis=0) + 1) != gq["dm"].ravel())))
+    e.close()
