@@ -110,8 +110,15 @@ int qmri_onnx_read_unetres(const char* path, qmri_net_desc* desc_out, float* wei
                            size_t* nfloats_out);
 /* out = denoiseImage_PnP_ADMM(in, net, true, residual_noise): in H x W x C x B doubles -> out H x W x out_nc x B. */
 int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C, int B, double* out);
-/* raw network forward on device fp32 tensors [B][C][W][H] (no casts); the dominant kernel chain */
+/* raw network forward on device fp32 tensors [B][C][W][H] (no casts); the dominant kernel chain.  Precondition of the default
+ * (f16-split) arithmetic: inputs at ordinary scale, as the [0, 1] images of PnP_ADMM.m:121 are; the call synchronises, reads the
+ * range guard and -- like qmri_denoise / qmri_pnp_admm -- repeats itself on the bf16 scheme if an activation left the f16 range. */
 int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, float* d_out);
+/* Which arithmetic the convolutions run on: *scheme_out = 2 (f16 pieces, 3 MFMA products per fp32 product) or 3 (bf16 pieces, 6
+ * products: no range limits, twice the matrix time); *fallbacks_out = how often a run-time guard has moved the network from 2
+ * to 3 since qmri_set_denoiser (a call that trips the guard is repeated transparently: a 2x slower call is visible here).
+ * Either pointer may be NULL. */
+int qmri_denoiser_scheme(const qmri_ctx* ctx, int* scheme_out, int* fallbacks_out);
 
 /* ---- PnP-ADMM: x = PnP_ADMM(y, param), PnP_ADMM.m:1 ----------------------------------------------- */
 enum { QMRI_SOLVER_LSQR = 0, QMRI_SOLVER_DIRECT = 1 };

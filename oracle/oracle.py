@@ -57,7 +57,9 @@ def usable_cpus() -> int:
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(build())
+        # QMRI_ORACLE_LIB: load another build of the same sources instead (tests run the suite's oracle calls once against
+        # `make asan`'s liboracle_asan.so, in a child process started with libasan preloaded)
+        L = C.CDLL(os.environ.get("QMRI_ORACLE_LIB") or build())
         vp, ip, dp, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
         L.orc_spiral_mask.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, C.c_int]
         L.orc_epi_mask.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, ip, ip, C.c_int]

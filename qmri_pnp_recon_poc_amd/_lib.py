@@ -19,7 +19,7 @@ SYMBOLS = [
     "qmri_abi_version", "qmri_create", "qmri_destroy", "qmri_last_error", "qmri_set_stream", "qmri_synchronize",
     "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
     "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
-    "qmri_net_forward_dev", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
+    "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_onnx_read_unetres",
     "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi",
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
     L.qmri_denoise.argtypes = [vp, dp, i, i, i, i, dp]
     L.qmri_onnx_read_unetres.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qmri_net_forward_dev.argtypes = [vp, vp, i, vp]
+    L.qmri_denoiser_scheme.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.qmri_pnp_admm.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_pnp_admm_dev.argtypes = [vp, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_lrtv.argtypes = [vp, vp, C.POINTER(LrtvParams), vp, C.POINTER(LrtvInfo)]

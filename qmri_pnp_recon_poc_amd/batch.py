@@ -31,7 +31,8 @@ def recon_batch(devices, Y, N, M, V, frame_ptr, kidx, weights, in_nc=10, out_nc=
     L = _lib.lib()
     Y = np.ascontiguousarray(Y, dtype=np.complex128)
     nsl, m = Y.shape
-    V = np.asarray(V, dtype=np.float64)
+    from .engine import real_dictionary_array
+    V = real_dictionary_array(V, "V", np.float64)
     T, s = V.shape
     Vf = np.ascontiguousarray(V.ravel(order="F"))
     fp = np.ascontiguousarray(frame_ptr, dtype=np.int32)
@@ -48,7 +49,7 @@ def recon_batch(devices, Y, N, M, V, frame_ptr, kidx, weights, in_nc=10, out_nc=
     pb.weights, pb.weights_nbytes = w.ctypes.data_as(f), w.nbytes
     keep = []
     if dictionary is not None:
-        D = np.ascontiguousarray(np.asarray(dictionary["D"], np.float32).ravel(order="F"))
+        D = np.ascontiguousarray(real_dictionary_array(dictionary["D"], "dict.D", np.float32).ravel(order="F"))
         lut = np.asarray(dictionary["lut"], np.float32)
         lf = np.ascontiguousarray(lut.ravel(order="F"))
         nd = np.ascontiguousarray(dictionary["normD"], dtype=np.float32)

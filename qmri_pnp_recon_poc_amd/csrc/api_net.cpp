@@ -45,6 +45,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     for (hipGraphExec_t g : p.fwd_graph) if (g) (void)hipGraphExecDestroy(g);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
     if (p.d_range_flag) (void)hipFree(p.d_range_flag);
+    if (p.h_range_flag) (void)hipHostFree(p.h_range_flag);
     p = NetPlan();
 }
 
@@ -114,7 +115,9 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     QMRI_HIP(ctx, hipMemcpy(&f, p.d_range_flag, sizeof f, hipMemcpyDeviceToHost));
     if (!f) return QMRI_OK;
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
+    if (p.h_range_flag) *p.h_range_flag = 0;
     QMRI_TRY(net_set_scheme(ctx, 3));
+    p.fallbacks += 1;
     tripped = true;
     return QMRI_OK;
 }
@@ -209,6 +212,8 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     if (p.sp6 == 2 && !conv6_weights_fit_f16(weights, nbytes / 4)) p.sp6 = 3;     // weights beyond the f16 range: bf16 scheme
     QMRI_HIP(ctx, hipMalloc((void**)&p.d_range_flag, sizeof(unsigned)));
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof(unsigned)));
+    QMRI_HIP(ctx, hipHostMalloc((void**)&p.h_range_flag, sizeof(unsigned), hipHostMallocDefault));
+    *p.h_range_flag = 0;
     const float* w = weights;
     const int nb = desc->nb;
     const size_t B = (size_t)max_batch;
@@ -335,9 +340,24 @@ extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, flo
     NetPlan& p = ctx->net;
     if (!p.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
     QMRI_CHECK_ARG(ctx, d_in && d_out && B >= 1 && B <= p.maxB, "qmri_net_forward_dev arguments / batch > max_batch");
-    QMRI_TRY(ew_launch_pack(ctx, B, p.desc.in_nc, p.H, p.W, d_in, 0, p.in32));
-    QMRI_TRY(net_forward(ctx, B));
-    QMRI_TRY(ew_launch_unpack(ctx, B, p.desc.out_nc, p.H, p.W, p.out32, p.in32, 0, d_out, 0));
+    for (int attempt = 0; attempt < 2; ++attempt) {        // (second pass only after the f16 range guard switched the scheme)
+        QMRI_TRY(ew_launch_pack(ctx, B, p.desc.in_nc, p.H, p.W, d_in, 0, p.in32));
+        QMRI_TRY(net_forward(ctx, B));
+        QMRI_TRY(ew_launch_unpack(ctx, B, p.desc.out_nc, p.H, p.W, p.out32, p.in32, 0, d_out, 0));
+        if (p.sp6 != 2) break;                              // (the bf16 scheme has no range to guard: stays asynchronous)
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool again = false;
+        QMRI_TRY(net_range_tripped(ctx, again));
+        if (!again) break;
+    }
+    return QMRI_OK;
+}
+
+extern "C" int qmri_denoiser_scheme(const qmri_ctx* ctx, int* scheme_out, int* fallbacks_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    if (!ctx->net.ready) return QMRI_ERR_STATE;
+    if (scheme_out) *scheme_out = ctx->net.sp6;
+    if (fallbacks_out) *fallbacks_out = ctx->net.fallbacks;
     return QMRI_OK;
 }
 
@@ -452,6 +472,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     std::vector<int32_t> it_b(B);
     o.xhat_valid = false;                                  // x was just set: its spectrum is not known yet
     const bool diag = prm->want_diag && diag_out;
+    bool range_trip = false;
     for (int it = 0; it < prm->iters; ++it) {
         // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
         tm.start();
@@ -460,6 +481,9 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
             QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr,
                                    diag ? o.d_pd : nullptr));          // (the data-fidelity partials come with the solve)
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
+            // qmri_lsqr_run has just waited for the LSQR state, which is behind the previous iteration's forward in the stream: its
+            // range guard is on the host.  A tripped guard ends this attempt at once instead of after all iterations.
+            if (it > 0 && net.sp6 == 2 && *net.h_range_flag) { range_trip = true; break; }
         } else {
             QMRI_TRY(dc_launch_direct(ctx, op, B, o.d_z, o.d_chat, prm->gamma, o.d_tmp, o.d_x));
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = 0;
@@ -478,6 +502,8 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_elementwise);
         tm.start();
         QMRI_TRY(net_forward(ctx, B));
+        if (net.sp6 == 2)   // the range guard of this forward, read at the next x-update's synchronisation point (or at the end)
+            QMRI_HIP(ctx, hipMemcpyAsync(net.h_range_flag, net.d_range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
         tm.start();
@@ -486,8 +512,9 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_elementwise);
         ctx->prof.admm_iters += 1;
     }
+    if (!range_trip)
     QMRI_HIP(ctx, hipMemcpyAsync(d_x_out, o.d_x, nb, hipMemcpyDeviceToDevice, ctx->stream));                 // returns x, not v
-    if (prm->want_diag && diag_out && prm->iters > 0)
+    if (prm->want_diag && diag_out && prm->iters > 0 && !range_trip)
         QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (prm->iters > 0) {
@@ -513,7 +540,11 @@ extern "C" int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_param
     if (x0) { d_x0 = o.d_xb; QMRI_HIP(ctx, hipMemcpyAsync(d_x0, x0, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream)); }
     if (gt) {
         QMRI_HIP(ctx, hipMalloc((void**)&d_gt, n * sizeof(double2)));
-        QMRI_HIP(ctx, hipMemcpyAsync(d_gt, gt, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        if (hipMemcpyAsync(d_gt, gt, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            (void)hipFree(d_gt);
+            qmri_set_error(ctx, "copy of gt_tsmi to the device failed");
+            return QMRI_ERR_HIP;
+        }
     }
     int st = qmri_pnp_admm_dev(ctx, 1, o.d_ya, p, d_x0, d_gt, o.d_xa, diag_out, lsqr_iters_out);
     if (st == QMRI_OK) {

@@ -22,6 +22,7 @@
 //              requested two steps ahead and kept in registers for one
 // Tensors stay fp32 padded planes in HBM (qmri_internal.h PTensor), so this kernel is interchangeable with k_conv.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -703,7 +704,7 @@ template <int CFG> constexpr size_t conv6_lds(int SP) {
     return (size_t)(NABUF * ast6(SP) + 2 * SP * 2 * ((((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 1) + Cfg6<CFG>::TH + 2)) * 16;
 }
 
-static int g_launch_counter = 0;     // diagnostic: running number of k_conv6 launches (all configurations)
+static std::atomic<int> g_launch_counter{0};     // diagnostic: running number of k_conv6 launches (all configurations, all contexts)
 
 template <int CFG, int SP>
 int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
@@ -727,7 +728,7 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
-    A.launch_idx = g_launch_counter++;
+    A.launch_idx = g_launch_counter.fetch_add(1, std::memory_order_relaxed);
     A.detail = (stamp_launch < 0 || A.launch_idx == stamp_launch) ? 1 : 0;
     if (!ctx->conv6_attr[CFG][SP - 2]) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>(SP)));

@@ -397,7 +397,9 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
     static const bool stamps6 = getenv("QMRI_CONV_STAMP_LAUNCH") != nullptr;   // the buffer then belongs to k_conv6
     A.stamps = stamps6 ? nullptr : (unsigned long long*)ctx->net.d_stamps;
     // persistent grid: exactly as many workgroups as are resident at once (measured occupancy x CU count)
-    static int occ[2] = {0, 0}, ncu = 0;
+    // (per context, not function-local statics: qmri_recon_batch runs one host thread + context per device)
+    int& ncu = ctx->conv_ncu;
+    int* occ = ctx->conv_occ[(int)KIND];
     if (!ncu) {
         hipDeviceProp_t prop;
         QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));

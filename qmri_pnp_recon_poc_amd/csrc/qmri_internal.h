@@ -166,6 +166,8 @@ struct NetPlan {
     int fwd_calls[9] = {};
     bool force_f32 = false;             // calibration (qmri_set_denoiser): run the f32-MFMA kernels whatever the scheme
     unsigned* d_range_flag = nullptr;   // f16 scheme: raised by a conv kernel whose output leaves the f16-splittable range
+    unsigned* h_range_flag = nullptr;   // pinned host copy, refreshed after every forward of the ADMM loop (checked at the loop's next sync point)
+    int fallbacks = 0;                  // times a run-time guard moved the network from the f16 to the bf16 scheme since qmri_set_denoiser
     int sp6 = 2;                     // scheme the layers are packed for
     std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
@@ -232,6 +234,8 @@ struct qmri_ctx {
     bool conv6_attr[3][2] = {{false, false}, {false, false}, {false, false}};   // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
+    int conv_ncu = 0;                   // f32-MFMA conv kernels (conv_kernels.hip): CU count and resident workgroups per CU by (kind, MT)
+    int conv_occ[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 };
 
 OpDev qmri_opdev(const qmri_ctx* ctx);

@@ -32,6 +32,20 @@ def _cbuf(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.complex128).ravel(order="F"))
 
 
+def real_dictionary_array(a, name: str, dtype):
+    """`dict.D` / `dict.V` as the real array the kernels take.  MATLAB may hold them complex-typed (the reference takes
+    real(dict.V), main_recon_tsmis_FFT.m:129, and real(dict.D(...)), main_synthesize_tsmis.m:89, explicitly, while
+    mrf_dtm_cpu.m:91 multiplies by dict.D as stored): a complex-typed array whose imaginary part is zero is accepted, one
+    with a non-zero imaginary part is refused -- it is never silently truncated."""
+    a = np.asarray(a)
+    if np.iscomplexobj(a):
+        if np.any(a.imag != 0):
+            raise ValueError(f"{name} is complex with a non-zero imaginary part: the dictionary match implements real atoms "
+                             f"(dict.D real, as in the reference's real_fisp dictionaries); pass real({name}) if that is what is meant")
+        a = a.real
+    return np.asarray(a, dtype=dtype)
+
+
 def build_spiral(N: int, S: int, T: int):
     """setup_subsampling_spiralgrided.m:7-34 -> (frame_ptr[T+1], kidx[m]) int32 (0-based column-major k)."""
     L = _lib.lib()
@@ -112,7 +126,7 @@ class Engine:
 
     # -- operator ----------------------------------------------------------------------------------
     def set_operator(self, N, M, V, frame_ptr, kidx, max_batch=1):
-        V = np.asarray(V, dtype=np.float64)
+        V = real_dictionary_array(V, "V", np.float64)
         if V.ndim != 2:
             raise ValueError("V must be T x s")
         T, s = V.shape
@@ -164,6 +178,12 @@ class Engine:
         self.net_desc = d
         self.net_hw = (int(H), int(W))
 
+    def denoiser_scheme(self):
+        """(scheme, fallbacks): 2 = f16 x 3 products, 3 = bf16 x 6 products; how often a run-time guard switched 2 -> 3."""
+        sc, fb = C.c_int(0), C.c_int(0)
+        self._check(self.L.qmri_denoiser_scheme(self.h, C.byref(sc), C.byref(fb)))
+        return sc.value, fb.value
+
     def denoise(self, x):
         """I = denoiseImage_PnP_ADMM(x, net, true, residual_noise): x [H,W,C] or [H,W,C,B] double."""
         x = np.asarray(x, dtype=np.float64)
@@ -202,7 +222,7 @@ class Engine:
 
     # -- dictionary ----------------------------------------------------------------------------------
     def set_dictionary(self, D, normD, lut):
-        D = np.asarray(D, dtype=np.float32)
+        D = real_dictionary_array(D, "dict.D", np.float32)
         lut = np.asarray(lut, dtype=np.float32)
         K, s = D.shape
         Q = lut.shape[1]

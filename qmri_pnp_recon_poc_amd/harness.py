@@ -49,7 +49,10 @@ def load_dictionary(path):
     if "dict" not in d:
         raise KeyError(f"{path} holds no variable 'dict'")
     s = d["dict"]
-    out = {"V": np.real(np.asarray(s.V)).astype(np.float64), "D": np.asarray(s.D), "lut": np.asarray(s.lut, dtype=np.float32)}
+    from .engine import real_dictionary_array
+    # V: real(dict.V) as :129 takes it.  D: used as stored by mrf_dtm_cpu.m:91 -- a complex-typed D must have a zero imaginary part
+    out = {"V": np.real(np.asarray(s.V)).astype(np.float64), "D": real_dictionary_array(s.D, "dict.D", np.float32),
+           "lut": np.asarray(s.lut, dtype=np.float32)}
     out["normD"] = np.asarray(s.normD, dtype=np.float32).ravel() if hasattr(s, "normD") else np.linalg.norm(out["D"], axis=1).astype(np.float32)
     return out
 
@@ -204,7 +207,7 @@ def save_training_pickle(path, X_slices, channels_to_save=None):
 # the script's main flow
 # ------------------------------------------------------------------------------------------------------------
 def recon_tsmis(dictionary, X0, qmap0, weights=None, recon_method="PnP_ADMM", subsampling_pattern="Spiral",
-                spiral_sampling_curve=771, epi_sampling_rate=0.05, measurements_type="noisy", measurements_noise=30,
+                spiral_sampling_curve=771, epi_sampling_rate=1 / 65, measurements_type="noisy", measurements_noise=30,
                 denoiser_type="single_level", noise_map_std=0.01, residual_noise=False, iters=100, seed=0, Y=None, device=0,
                 net_arch=None, lrtv_iters=None):
     """main_recon_tsmis_FFT.m:216-374 on already loaded (and cropped) arrays.

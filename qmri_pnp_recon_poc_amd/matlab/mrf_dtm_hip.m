@@ -6,7 +6,14 @@ datadims = size(data.X);
 T = datadims(end);
 Npix = prod(datadims(1:end-1));
 Q = size(dict.lut, 2);
-qmri_mex('set_dictionary', single(dict.D), single(dict.normD(:)), single(dict.lut));
+D = dict.D;
+if ~isreal(D)   % mrf_dtm_cpu.m:91 multiplies by dict.D as stored; the GPU match implements real atoms
+    if any(imag(D(:)) ~= 0)
+        error('qmri:mrf_dtm_hip:complexDictionary', 'dict.D has a non-zero imaginary part; the GPU dictionary match takes real atoms (use mrf_dtm_cpu, or pass real(dict.D) if that is what is meant)');
+    end
+    D = real(D);
+end
+qmri_mex('set_dictionary', single(D), single(real(dict.normD(:))), single(real(dict.lut)));
 [qmap, pd, mt, dm] = qmri_mex('dict_match', complex(double(reshape(data.X, [Npix, T]))), Q);
 if par.f.qout,  out.qmap = reshape(qmap, [datadims(1:end-1), Q]);  out.mask = true(datadims(1:end-1)); end
 if par.f.pdout, out.pd = reshape(pd, [datadims(1:end-1), 1]); end

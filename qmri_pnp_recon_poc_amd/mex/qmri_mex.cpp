@@ -157,6 +157,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             for (int i = 0; i < 6; ++i) mxSetFieldByNumber(plhs[1], 0, i, mxCreateDoubleScalar(v[i]));
         }
     } else if (c == "set_dictionary") {              // qmri_mex('set_dictionary', D(single KxS), normD(single), lut(single KxQ))
+        // a complex mxArray holds interleaved (re,im) pairs: reading it as K x s reals would match against garbage atoms.
+        // mrf_dtm_hip.m passes real(D) after checking that imag(D) is zero; anything else is refused here.
+        for (int a = 1; a <= 3; ++a)
+            if (nrhs <= a || mxIsComplex(prhs[a]) || !mxIsSingle(prhs[a]))
+                mexErrMsgIdAndTxt("qmri:set_dictionary:type", "D, normD and lut must be real single arrays (argument %d is not)", a);
+        if (mxGetNumberOfElements(prhs[2]) != mxGetM(prhs[1]) || mxGetM(prhs[3]) != mxGetM(prhs[1]))
+            mexErrMsgIdAndTxt("qmri:set_dictionary:size", "normD must have K elements and lut K rows (K = rows of D)");
         check(qmri_set_dictionary(ctx(), (int)mxGetM(prhs[1]), (int)mxGetN(prhs[1]), (int)mxGetN(prhs[3]),
                                   (const float*)mxGetData(prhs[1]), (const float*)mxGetData(prhs[2]), (const float*)mxGetData(prhs[3])));
     } else if (c == "dict_match") {                  // [qmap, pd, mt, dm] = qmri_mex('dict_match', X(Npix x s complex double), Q)

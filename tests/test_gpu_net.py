@@ -51,12 +51,36 @@ def test_f16_range_guard_falls_back_to_bf16_scheme(engine_mod):
     e = engine_mod.Engine(0)
     e.set_denoiser(g["weights"], 32, 32, in_nc=10, out_nc=10, nc=nc, nb=nb)
     x = g["x"].transpose(1, 2, 0).astype(np.float64)
+    assert e.denoiser_scheme() == (2, 0)                            # f16 x 3, no fallback so far (visible to the caller)
     for c in (3.0e3, 1.0e7):                                        # inside the range / input and activations far outside
         y = e.denoise(c * x).transpose(2, 0, 1)
         assert np.all(np.isfinite(y))
         assert rel_err(y, c * g["y"].astype(np.float64)) < 2e-5
     y = e.denoise(x).transpose(2, 0, 1)                             # (stays on the bf16 scheme; still right)
     assert rel_err(y, g["y"]) < 2e-5
+    e.close()
+
+
+def test_raw_forward_entry_point_is_guarded_too(engine_mod):
+    """qmri_net_forward_dev (no casts, no input rescaling) with an input far beyond the f16 range: the call reads the range
+    guard, repeats itself on the bf16 scheme and reports the switch through qmri_denoiser_scheme -- not QMRI_OK with NaNs."""
+    import ctypes as C
+    import torch
+    g = np.load(os.path.join(GOLDEN, "unetres_tiny_10ch.npz"))
+    nc, nb = tuple(int(v) for v in g["nc"]), int(g["nb"])
+    e = engine_mod.Engine(0)
+    e.set_denoiser(g["weights"], 32, 32, in_nc=10, out_nc=10, nc=nc, nb=nb)
+    assert e.denoiser_scheme() == (2, 0)
+    xin = np.ascontiguousarray(g["x"].transpose(0, 2, 1))           # [C][W][H]: the raw entry point's layout
+    for c, want in ((1.0, (2, 0)), (1.0e7, (3, 1)), (1.0, (3, 1))):
+        d_in = torch.from_numpy((c * xin).astype(np.float32)).cuda()
+        d_out = torch.empty_like(d_in)
+        torch.cuda.synchronize()
+        e._check(e.L.qmri_net_forward_dev(e.h, C.c_void_p(d_in.data_ptr()), 1, C.c_void_p(d_out.data_ptr())))
+        e.synchronize()
+        y = d_out.cpu().numpy().transpose(0, 2, 1)
+        assert np.all(np.isfinite(y)) and rel_err(y, c * g["y"].astype(np.float64)) < 2e-5
+        assert e.denoiser_scheme() == want
     e.close()
 
 

@@ -77,3 +77,91 @@ def test_shard_slices():
         assert sorted(sum(parts, [])) == list(range(nsl))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert shard_slices(120, 8, 3) == list(range(45, 60))
+
+
+def test_mex_shim_compiles_against_stub_header():
+    """SYNTAX / TYPE CHECK ONLY: mex/qmri_mex.cpp through g++ -fsyntax-only against tests/stubs/mex.h (a declarations-only
+    stand-in written from MathWorks' published C Matrix API; the image has no MATLAB).  It proves the gateway's calls into
+    include/qmri.h and into the mx* API are well-formed C++; it does not build, link or run a MEX file."""
+    r = subprocess.run(["g++", "-fsyntax-only", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"),
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "qmri_pnp_recon_poc_amd", "mex", "qmri_mex.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = open(os.path.join(ROOT, "qmri_pnp_recon_poc_amd", "mex", "qmri_mex.cpp")).read()
+    assert 'c == "set_dictionary"' in src and "mxIsComplex(prhs[a])" in src        # a complex D is refused, not reinterpreted
+
+
+def test_complex_dictionary_is_refused_not_truncated(tmp_path, synth):
+    """dict.D / V complex-typed: a zero imaginary part is accepted, a non-zero one raises on every route (Engine.set_dictionary,
+    Engine.set_operator, batch.recon_batch, harness.load_dictionary) -- never a silent np.asarray(..., float32) truncation."""
+    import scipy.io
+    from qmri_pnp_recon_poc_amd import engine, harness, batch
+    dic = synth.make_dictionary(T=40, n_t1=6, n_t2=5)
+    Dz = dic["D"].astype(np.complex64)                                  # complex-typed, imaginary part zero: fine
+    assert np.array_equal(engine.real_dictionary_array(Dz, "dict.D", np.float32), dic["D"])
+    Dc = Dz.copy(); Dc[3, 2] += 0.25j
+    with pytest.raises(ValueError, match="non-zero imaginary"):
+        engine.real_dictionary_array(Dc, "dict.D", np.float32)
+    with pytest.raises(ValueError, match="non-zero imaginary"):
+        engine.real_dictionary_array(dic["V"] + 1e-3j, "V", np.float64)
+    # file route: dict.D stored complex in the .mat
+    for D, ok in ((Dz, True), (Dc, False)):
+        path = tmp_path / f"dict_{ok}.mat"
+        scipy.io.savemat(path, {"dict": {"V": dic["V"] + 0j, "D": D, "normD": dic["normD"], "lut": dic["lut"]}})
+        if ok:
+            out = harness.load_dictionary(str(path))
+            assert out["D"].dtype == np.float32 and np.array_equal(out["D"], dic["D"]) and out["V"].dtype == np.float64
+        else:
+            with pytest.raises(ValueError, match="non-zero imaginary"):
+                harness.load_dictionary(str(path))
+    # batch route validates before it touches a device
+    fp, k = engine.build_spiral(32, 60, 40)
+    with pytest.raises(ValueError, match="non-zero imaginary"):
+        batch.recon_batch([0], np.zeros((1, int(fp[-1])), complex), N=32, M=32, V=dic["V"], frame_ptr=fp, kidx=k,
+                          weights=np.zeros(4, np.float32), dictionary={"D": Dc, "normD": dic["normD"], "lut": dic["lut"]})
+
+
+ASAN_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle as O
+from qmri_pnp_recon_poc_amd import synth
+N, T, s, S = 32, 24, 6, 120
+dic = synth.make_dictionary(T=T, n_t1=12, n_t2=8, s=s)
+X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=0), dic)
+fp, k = O.spiral_mask(N, S, T); fe, ke = O.epi_mask(N, N, 1 / 8, T)
+op = O.Operator(N, N, dic["V"], fp, k); ope = O.Operator(N, N, dic["V"], fe, ke)
+y = synth.awgn_measured(op.forward(X0), 30.0, seed=0)
+x = op.adjoint(y); ope.adjoint(ope.forward(X0))
+op.lsqr(y, 0.9 * x, 0.05, 1e-4, 100, x); op.direct(y, 0.9 * x, 0.05)
+for multi in (0, 1):
+    nc = (8, 16, 16, 32)
+    w = synth.structured_weights(in_nc=s + multi, out_nc=s, nc=nc, nb=2, seed=3, eps=0.05)
+    net = O.Net(w, in_nc=s + multi, out_nc=s, nc=nc, nb=2)
+    xo, d, li = O.pnp_admm(op, net, y, iters=3, multi_level=bool(multi), gt=X0, want_diag=True)
+O.dict_match(xo, dic["D"], dic["normD"], dic["lut"], want_xfit=True)
+O.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=1), dic["D"], dic["normD"], dic["lut"])
+O.fista_lrtv(op, y, K=1e-3, iters=3)
+print("ASAN_RUN_OK", O.admm_stage_seconds()["denoiser"] > 0)
+"""
+
+
+def test_oracle_under_address_and_ub_sanitizer(tmp_path):
+    """The oracle built with `make asan` (-fsanitize=address,undefined; GPU sanitizers are unavailable on the pool) driven through
+    every entry point the suites use -- masks, operator, LSQR, closed form, network, ADMM (both denoiser types), dictionary match,
+    synthesis, LRTV -- in a child process with libasan preloaded.  Any report fails the test."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-C", odir, "-s", "asan"], check=True)
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan_rt = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
+        pytest.skip("libasan runtime not found")
+    script = tmp_path / "asan_run.py"
+    script.write_text(ASAN_SCRIPT % ROOT)
+    env = dict(os.environ, QMRI_ORACLE_LIB=os.path.join(odir, "_build", "liboracle_asan.so"),
+               LD_PRELOAD=asan_rt + (":" + ubsan_rt if os.path.exists(ubsan_rt) else ""),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=77", UBSAN_OPTIONS="halt_on_error=1:exitcode=78:print_stacktrace=1",
+               OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ASAN_RUN_OK True" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
