@@ -51,6 +51,7 @@ struct Conv6Args {
     int out_hp, out_plane; long out_bs, add1_bs, add2_bs;
     int nchunk, n_ct, tiles_h, tiles_w, relu_out;
     int vec4;                     // epilogue may use aligned float4 accesses (H % 4 == 0 and line-aligned tensors)
+    int wt;                       // write-through (sc1) output stores, see store4()
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
@@ -119,6 +120,15 @@ template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], float (&b)
                    "+v"(b[0][4]), "+v"(b[0][5]), "+v"(b[0][6]), "+v"(b[0][7])
                  : "n"(N)
                  : "memory");
+}
+
+// Output stores.  A plain store leaves its line dirty in the XCD's L2, and the end-of-kernel release then writes all of them back
+// before the next (dependent) kernel may start: 12.8 MB per layer at the 224 x 224 level, i.e. a kernel boundary of 3.3 us instead
+// of the 1.7-1.9 us of a boundary with nothing dirty (MI355X_MICROARCH.md, price list row "boundary").  Write-through (sc1) stores
+// send the bytes to memory as they are issued -- while other workgroups still compute -- and leave nothing for the boundary.
+__device__ __forceinline__ void store4(float* p, f32x4 x, int wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+    else *(f32x4*)p = x;
 }
 
 // wave-uniform pointer, guaranteed to live in SGPRs (the "s" operands of the loads above)
@@ -443,7 +453,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 const int co = e / (PXT / 4), rem = e - co * (PXT / 4);
                 f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-                if (off[k] != ~0u) *(f32x4*)(A.out + (size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]) = x;
+                if (off[k] != ~0u) store4(A.out + (size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k], x, A.wt);
                 if constexpr (SP == 2) bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);   // (also NaN)
             }
         } else {
@@ -513,6 +523,7 @@ struct Conv6sArgs {
     int nsteps_real;                      // carry zero weights and repeat the last step's activations
     unsigned* range_flag;                 // as in Conv6Args
     float descale_hi, descale_lo;
+    int wt;                               // as in Conv6Args
 };
 
 template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[3], f32x4 (&b)[2]) {
@@ -686,12 +697,12 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
                 const int w = rem / (STH / 4), h = 4 * (rem - w * (STH / 4));
                 const int cog = ct * 64 + co, oh = gh0 + h, ow = gw0 + w;
                 if (cog < A.Cout && oh < A.GH && ow < A.GW)
-                    *(f32x4*)(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) = x;
+                    store4(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1), x, A.wt);
             } else {
                 const int iw = rem / (2 * STH / 4), hh = 4 * (rem - iw * (2 * STH / 4));   // hh = 2*ih + kh
                 const int kw = ct & 1, cog = (ct >> 1) * 32 + co, ih = gh0 + (hh >> 1), iwg = gw0 + iw;
                 if (cog < A.Cout && ih < A.GH && iwg < A.GW)
-                    *(f32x4*)(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(2 * iwg + kw + 1) * A.out_hp + (2 * gh0 + hh + 1)) = x;
+                    store4(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(2 * iwg + kw + 1) * A.out_hp + (2 * gh0 + hh + 1), x, A.wt);
             }
         }
         if constexpr (SP == 2) { if (bad && A.range_flag) *A.range_flag = 1u; }
@@ -725,6 +736,8 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.vec4 = (in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
               (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp))) ? 1 : 0;
     A.range_flag = ctx->net.d_range_flag;
+    static const int wt_stores = getenv("QMRI_CONV_WT") ? atoi(getenv("QMRI_CONV_WT")) : 1;
+    A.wt = wt_stores;
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
@@ -913,6 +926,8 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.nsteps = L.nchunk6; A.nsteps_real = L.nsteps6s; A.n_ct = L.n_ct6;
     A.range_flag = ctx->net.d_range_flag;
+    static const int wt_stores = getenv("QMRI_CONV_WT") ? atoi(getenv("QMRI_CONV_WT")) : 1;
+    A.wt = wt_stores;
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.tiles_h = (A.GH + STH - 1) / STH; A.tiles_w = (A.GW + STW - 1) / STW;
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;

@@ -28,13 +28,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NT = 256;
 constexpr int MAXPAIR = 8;      // s <= 16
 
-// largest float whose correctly rounded square root is still s = sqrtf(m2)  (a handful of floats share one root)
+// largest float whose correctly rounded square root is still s = sqrtf(m2)  (two or three floats share one root).
+// sqrtf() is the correctly rounded square root under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt (the __fsqrt_rn
+// intrinsic is NOT: without OCML_BASIC_ROUNDED_OPERATIONS it is the 1-ulp native instruction) -- bit-identical to glibc's sqrtf.
+// x rounds to s iff sqrt(x) < s + ulp(s)/2 =: mid (a tie is impossible: mid has 25 significant bits, mid^2 an odd 50th one, and x
+// only 24), i.e. iff x < mid^2, which is exact in double precision: the answer is the largest float below mid^2.
 __device__ __forceinline__ float sqrt_preimage_top(float m2, float s) {
-    float t = m2;
-    for (int it = 0; it < 8; ++it) {
-        const float n = __uint_as_float(__float_as_uint(t) + 1u);      // next float up (t >= 0)
-        if (__fsqrt_rn(n) == s) t = n; else break;
+    if (!(s >= 1e-30f && s <= 1e30f)) {                                 // zero, tiny, infinite or NaN: walk (never in practice)
+        float t = m2;
+        for (int it = 0; it < 4; ++it) {
+            const float n = __uint_as_float(__float_as_uint(t) + 1u);  // next float up (t >= 0)
+            if (sqrtf(n) == s) t = n; else break;
+        }
+        return t;
     }
+    const float half_ulp = __uint_as_float((__float_as_uint(s) & 0x7F800000u) - (24u << 23));   // 2^(e-24) for s = 1.f x 2^e
+    const double mid = (double)s + (double)half_ulp;
+    const double b = mid * mid;                                         // exact
+    float t = (float)b;                                                 // nearest float; step down if it did not land below b
+    if ((double)t >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
     return t;
 }
 
@@ -74,12 +86,17 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             are = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bre[q], are, 0, 0, 0);
             aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bim[q], aim, 0, 0, 0);
         }
+        float m2[16], tmax;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float re = are[r], im = aim[r];
-            const float m2 = __builtin_fmaf(im, im, re * re);
-            const int atom = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D row of the 32x32 MFMA tile
-            if (m2 > thr) { best = __fsqrt_rn(m2); thr = sqrt_preimage_top(m2, best); bidx = atom; cre = re; cim = im; }
+        for (int r = 0; r < 16; ++r) m2[r] = __builtin_fmaf(aim[r], aim[r], are[r] * are[r]);
+        tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
+                     fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
+        if (tmax > thr) {          // some atom of this tile beats the incumbent (rare once the scan has passed the neighbourhood of the match)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                                  // ascending atom index: the first of equal magnitudes stays
+                const int atom = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D row of the 32x32 MFMA tile
+                if (m2[r] > thr) { best = sqrtf(m2[r]); thr = sqrt_preimage_top(m2[r], best); bidx = atom; cre = are[r]; cim = aim[r]; }
+            }
         }
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index

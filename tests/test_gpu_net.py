@@ -65,22 +65,31 @@ def test_raw_forward_entry_point_is_guarded_too(engine_mod):
     """qmri_net_forward_dev (no casts, no input rescaling) with an input far beyond the f16 range: the call reads the range
     guard, repeats itself on the bf16 scheme and reports the switch through qmri_denoiser_scheme -- not QMRI_OK with NaNs."""
     import ctypes as C
-    import torch
+    engine_mod.Engine(0).close()                                    # (libqmri and with it the HIP runtime are mapped now)
+    path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+    hip = C.CDLL(path)                                              # device buffers from the HIP runtime libqmri itself uses
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     g = np.load(os.path.join(GOLDEN, "unetres_tiny_10ch.npz"))
     nc, nb = tuple(int(v) for v in g["nc"]), int(g["nb"])
     e = engine_mod.Engine(0)
     e.set_denoiser(g["weights"], 32, 32, in_nc=10, out_nc=10, nc=nc, nb=nb)
     assert e.denoiser_scheme() == (2, 0)
     xin = np.ascontiguousarray(g["x"].transpose(0, 2, 1))           # [C][W][H]: the raw entry point's layout
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_in), xin.size * 4) == 0 and hip.hipMalloc(C.byref(d_out), xin.size * 4) == 0
     for c, want in ((1.0, (2, 0)), (1.0e7, (3, 1)), (1.0, (3, 1))):
-        d_in = torch.from_numpy((c * xin).astype(np.float32)).cuda()
-        d_out = torch.empty_like(d_in)
-        torch.cuda.synchronize()
-        e._check(e.L.qmri_net_forward_dev(e.h, C.c_void_p(d_in.data_ptr()), 1, C.c_void_p(d_out.data_ptr())))
+        h_in = np.ascontiguousarray((c * xin).astype(np.float32))
+        h_out = np.empty_like(h_in)
+        assert hip.hipMemcpy(d_in, h_in.ctypes.data_as(C.c_void_p), h_in.nbytes, 1) == 0          # hipMemcpyHostToDevice
+        e._check(e.L.qmri_net_forward_dev(e.h, d_in, 1, d_out))
         e.synchronize()
-        y = d_out.cpu().numpy().transpose(0, 2, 1)
+        assert hip.hipMemcpy(h_out.ctypes.data_as(C.c_void_p), d_out, h_out.nbytes, 2) == 0       # hipMemcpyDeviceToHost
+        y = h_out.transpose(0, 2, 1)
         assert np.all(np.isfinite(y)) and rel_err(y, c * g["y"].astype(np.float64)) < 2e-5
         assert e.denoiser_scheme() == want
+    hip.hipFree(d_in); hip.hipFree(d_out)
     e.close()
 
 
