@@ -54,6 +54,7 @@ struct Conv6Args {
     int wt;                       // write-through (sc1) output stores, see store4()
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
+    int ntiles;                   // k_conv6p: tiles of the launch (n_ct * tiles_h * tiles_w * B)
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
     unsigned* range_flag;         // f16 scheme: set to 1 when an output leaves the range the next layer's f16 split can carry
     float descale_hi, descale_lo; // f16 scheme: the layer's weights are packed times 2^k (largest |w| in [1, 2)): 2^-k and 2^-k / 2^11
@@ -105,6 +106,7 @@ __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__buil
 // releases ("+v"), so no consumer can be scheduled above it.
 // (scalar base + 32-bit per-lane byte offset: the offsets are loop invariant, the base advances per step)
 __device__ __forceinline__ void gload4(u32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gload4r(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 __device__ __forceinline__ void gload1(float& dst, unsigned off, const void* base) { asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], float (&b)[1][8]) {
     asm volatile("s_waitcnt vmcnt(%13)"
@@ -498,6 +500,382 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 template <int CFG, int SP> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP>(A); }
 
 // =====================================================================================================================
+// k_conv6p : persistent, software-pipelined form of k_conv6 (f16 x 3 scheme) for launches with several tiles per CU -- slice
+// batches (qmri_pnp_admm_dev with nslices > 1, qmri_recon_batch, bench.py --workload slices).
+//
+// In k_conv6 a workgroup is a serial prologue (first operands: 3.3 us) -> loop (11 us) -> epilogue (2.4-4.5 us), one workgroup per
+// CU by LDS size, so with 11.5 tiles per CU (15 slices) the matrix cores idle for a third of the time.  Here one workgroup per CU
+// walks tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...:
+//   * the loader waves treat the (tile, step) sequence as ONE stream: the requests that k_conv6 clamps "past the end" are the
+//     next tile's first operands, so every tile after the first starts with its operands already in LDS;
+//   * the MFMA waves, after a tile's last step, put the accumulators into an LDS tile `ot` of its own (158 KB of LDS in all) and
+//     start the next tile at once;
+//   * the loader waves run the finished tile's epilogue -- LDS tile + residual operands, ReLU, range guard, write-through stores --
+//     in the issue gaps of the next tile's first 8 steps, 1/8 of the tile per step; the residual operands are requested two
+//     steps ahead like every other operand (first two slices during the finished tile's own last two steps).
+// Vector-memory operations of a wave complete in issue order and stores count like loads, so the loaders' one counted wait per
+// step, vmcnt(2 * NLOAD), stays exactly as in k_conv6: at that point at least 2 * NLOAD younger operations have been issued
+// (the operand requests of the two steps in between), and any epilogue load / store among them only makes the wait conservative.
+// The last tile of a workgroup is finished by all eight waves as in k_conv6.
+// Requirements (conv6_launch checks them, k_conv6 runs otherwise): f16 scheme, Cout % 64 == 0, nchunk even and >= 4, aligned
+// tensors (vec4), no split-K.
+// =====================================================================================================================
+struct Tile6 { int ct, oh0, ow0, b; };
+
+template <int CFG> __device__ __forceinline__ Tile6 tile6(const Conv6Args& A, int t) {
+    Tile6 r;
+    r.ct = t % A.n_ct; t /= A.n_ct;
+    const int th = t % A.tiles_h; t /= A.tiles_h;
+    const int tw = t % A.tiles_w;
+    r.b = t / A.tiles_w;
+    r.oh0 = th * Cfg6<CFG>::TH; r.ow0 = tw * Cfg6<CFG>::TW;
+    return r;
+}
+
+// STAMP: diagnostic build of the same kernel that records 100 MHz wall-clock stamps of four sampled workgroups (tools/conv6p_stamps.py)
+#define P_STAMP(kind, idx)                                                                                       \
+    do {                                                                                                         \
+        if constexpr (STAMP) {                                                                                   \
+            if (A.stamps && A.detail && (threadIdx.x & 255) == 0 && (idx) < 256) {                               \
+                const int sw_ = (blockIdx.x == 0) ? 0 : (blockIdx.x == 37) ? 1 : (blockIdx.x == 101) ? 2 : (blockIdx.x == 200) ? 3 : -1; \
+                if (sw_ >= 0) A.stamps[(sw_ * 8 + (kind)) * 256 + (idx)] = wall_clock64();                       \
+            }                                                                                                    \
+        }                                                                                                        \
+    } while (0)
+
+template <int CFG, int NRES, bool STAMP>
+__global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
+    constexpr int SP = 2;
+    constexpr int AST = ast6(SP);
+    typedef Cfg6<CFG> C;
+    constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT;
+    constexpr int IH = TH + 2, IW = TW + 2;
+    constexpr int IHP = ((IH + 7) / 16) * 16 + 8;
+    constexpr int NPX = IHP * (IW - 1) + IH;
+    constexpr int NLP = IH * IW;
+    constexpr int NBI = 2 * NLP;
+    constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);
+    constexpr int NAQ = (AST + NLD6 - 1) / NLD6;
+    static_assert(NAQ == 3 && NBQ == 1, "gwait() is written for 3 + 8 loads per step");
+    constexpr int NLOAD = NAQ + 8 * NBQ;
+    constexpr int PXT = TH * TW, PP = PXT + 4;
+    constexpr int GPC = PXT / 4;                                    // float4 groups per output channel of the tile
+    constexpr int NG = 64 * GPC;                                    // ... of the tile
+    constexpr int EPS = 8;                                          // steps of the next tile that carry the epilogue
+    constexpr int GQL = NG / NLD6, GPS = GQL / EPS;                 // groups per loader thread: per tile, per step
+    constexpr int COSTEP = NLD6 / GPC;                              // consecutive groups of a thread are this many channels apart
+    static_assert(GQL * NLD6 == NG && GPS * EPS == GQL && COSTEP * GPC == NLD6 && TH % 4 == 0, "epilogue split");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
+    uint4* Bbuf = Abuf + NABUF * AST;                               // [2][SP][2 k-halves][NPX]
+    float* ot = (float*)(Bbuf + 2 * SP * 2 * NPX);                  // [64][PP] output tile, NOT aliased: read while the next tile computes
+    const int tid = threadIdx.x;
+    const int nsteps = 3 * A.nchunk, ntiles = A.ntiles, tstride = gridDim.x;
+    int tile = blockIdx.x;
+    Tile6 last = tile6<CFG>(A, tile);                               // the tile whose output is in `ot` when the loop ends
+
+    if (tid >= NT6 - NLD6) {
+        // ------------------------------------------------------------------ loaders
+        const int lt = tid - (NT6 - NLD6);
+        __builtin_amdgcn_s_setprio(2);
+        unsigned aoff[NAQ], boff[3];
+#pragma unroll
+        for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            int item = part * (NBQ * NLD6) + lt;
+            if (item >= NBI) item = 0;
+            const int h2 = item / NLP, px = item - h2 * NLP;
+            const int dw = px / IH, dh = px - dw * IH;
+            boff[part] = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
+        }
+        // this thread's share of a tile's epilogue: GQL float4 groups at a fixed (w, h), channels co0 + COSTEP * k
+        const int erem = lt % GPC, eco0 = lt / GPC;
+        const int ew = erem / (TH / 4), eh = 4 * (erem - ew * (TH / 4));
+        const float* otp = ot + eco0 * PP + 4 * erem;               // + k * COSTEP * PP
+        u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
+        float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
+        f32x4 rr0[GPS][NRES > 0 ? NRES : 1], rr1[GPS][NRES > 0 ? NRES : 1], rr2[GPS][NRES > 0 ? NRES : 1];   // residual operands, same rotation
+        Tile6 cur = last, nx = last, pv = last;
+        const uint4 *wsrc_c, *wsrc_n;
+        const float *isrc_c, *isrc_n;
+        auto bases = [&](const Tile6& t, const uint4*& w, const float*& in) __attribute__((always_inline)) {
+            w = A.wp + (size_t)t.ct * A.nchunk_all * 3 * AST;
+            in = A.in + (size_t)t.b * A.in_bs + (size_t)t.ow0 * A.in_hp + t.oh0;
+        };
+        bases(cur, wsrc_c, isrc_c);
+        wsrc_n = wsrc_c; isrc_n = isrc_c;
+        bool bad = false;
+        // step / chunk indices are relative to the current tile; indices past its end address the next tile (or, after the last
+        // tile, this one again: harmless re-reads into free buffers, as in k_conv6)
+#define PLOAD_A(g_, ra_)                                                                                         \
+        {                                                                                                        \
+            const int gg_ = (g_);                                                                                \
+            const uint4* ws = uniform_ptr((gg_ < nsteps) ? wsrc_c + (size_t)gg_ * AST : wsrc_n + (size_t)(gg_ - nsteps) * AST); \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) gload4(ra_[q], aoff[q], ws);                         \
+        }
+#define PSTORE_A(g_, ra_)                                                                                        \
+        {                                                                                                        \
+            uint4* ad = Abuf + ((g_) % NABUF) * AST;                                                             \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; ad[(i < AST) ? i : 0] = __builtin_bit_cast(uint4, ra_[q]); } \
+        }
+#define PLOAD_B(c_, part_, rb_)                                                                                  \
+        {                                                                                                        \
+            const int cc_ = (c_);                                                                                \
+            const float* bs_ = uniform_ptr((cc_ < A.nchunk) ? isrc_c + (size_t)cc_ * CK * A.in_plane            \
+                                                            : isrc_n + (size_t)(cc_ - A.nchunk) * CK * A.in_plane); \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) gload1(rb_[0][j], boff[part_], uniform_ptr(bs_ + (size_t)j * A.in_plane)); \
+        }
+#define PSTORE_B(c_, part_, rb_)                                                                                 \
+        {                                                                                                        \
+            uint4* bd = Bbuf + ((c_) & 1) * (SP * 2 * NPX);                                                      \
+            int item = (part_) * (NBQ * NLD6) + lt;                                                              \
+            if (item >= NBI) item = 0;                                                                           \
+            const int h2 = item / NLP, px = item - h2 * NLP;                                                     \
+            const int dw = px / IH, dh = px - dw * IH;                                                           \
+            const int e = h2 * NPX + dw * IHP + dh;                                                              \
+            uint4 s0, s1;                                                                                        \
+            split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x);                                                      \
+            split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y);                                                      \
+            split_pair_h(rb_[0][4], rb_[0][5], s0.z, s1.z);                                                      \
+            split_pair_h(rb_[0][6], rb_[0][7], s0.w, s1.w);                                                      \
+            bd[e] = s0;                                                                                          \
+            bd[2 * NPX + e] = s1;                                                                                \
+        }
+        // residual operands of epilogue slice j_ (groups GPS*j_ ...) of tile t_: requested into set rr_.  Issued in EVERY step (a
+        // step that has nothing to prefetch repeats slice 0 of the current tile): one unconditional instruction sequence, so the
+        // destination registers of in-flight loads are never merged across branches (no copies of in-flight registers)
+#define PREQ_RES(t_, j_, rr_)                                                                                    \
+        if constexpr (NRES > 0) {                                                                                \
+            const int oh_ = (t_).oh0 + eh, ow_ = (t_).ow0 + ew;                                                  \
+            const bool okhw_ = oh_ < A.H && ow_ < A.W;                                                           \
+            const unsigned ob_ = okhw_ ? (unsigned)(((size_t)((t_).ct * 64 + eco0) * A.out_plane + (size_t)(ow_ + 1) * A.out_hp + (oh_ + 1)) * 4) : 4u; \
+            _Pragma("unroll") for (int q = 0; q < GPS; ++q) {                                                    \
+                const size_t ko_ = (size_t)((j_) * GPS + q) * COSTEP * A.out_plane;                              \
+                gload4r(rr_[q][0], ob_, uniform_ptr(A.add1 + (size_t)(t_).b * A.add1_bs + ko_));                 \
+                if constexpr (NRES > 1) gload4r(rr_[q][1], ob_, uniform_ptr(A.add2 + (size_t)(t_).b * A.add2_bs + ko_)); \
+            }                                                                                                    \
+        }
+        // epilogue slice j_ of tile t_ (its accumulators are in `ot`): LDS tile + residual operands (set rr_), ReLU, guard, store
+#define PEPI(t_, j_, rr_)                                                                                        \
+        {                                                                                                        \
+            const int oh_ = (t_).oh0 + eh, ow_ = (t_).ow0 + ew;                                                  \
+            const bool okhw_ = oh_ < A.H && ow_ < A.W;                                                           \
+            float* ob_ = A.out + (size_t)(t_).b * A.out_bs + (size_t)((t_).ct * 64 + eco0) * A.out_plane + (size_t)(ow_ + 1) * A.out_hp + (oh_ + 1); \
+            _Pragma("unroll") for (int q = 0; q < GPS; ++q) {                                                    \
+                const int k_ = (j_) * GPS + q;                                                                   \
+                f32x4 x = *(const f32x4*)(otp + k_ * COSTEP * PP);                                               \
+                if constexpr (NRES > 0) x = x + rr_[q][0];                                                       \
+                if constexpr (NRES > 1) x = x + rr_[q][1];                                                       \
+                if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); } \
+                if (okhw_) store4(ob_ + (size_t)k_ * COSTEP * A.out_plane, x, 1);                                \
+                bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);  \
+            }                                                                                                    \
+        }
+        // prologue of the first tile, as in k_conv6
+        PLOAD_A(0, ra0) PLOAD_B(0, 0, rb0)
+        PLOAD_A(1, ra1) PLOAD_B(0, 1, rb1)
+        PLOAD_A(1, ra2) PLOAD_B(0, 2, rb2)
+        gwait<2 * NLOAD>(ra0, rb0);
+        PSTORE_A(0, ra0) PSTORE_B(0, 0, rb0)
+        gwait<NLOAD>(ra1, rb1);
+        PSTORE_A(1, ra1) PSTORE_B(0, 1, rb1)
+        gwait<0>(ra2, rb2);
+        PSTORE_B(0, 2, rb2)
+        PLOAD_A(2, ra1) PLOAD_B(1, 0, rb1) PREQ_RES(cur, 0, rr1)    // (the residual sets in the steady-state order: operands, then residual)
+        PLOAD_A(3, ra2) PLOAD_B(1, 1, rb2) PREQ_RES(cur, 0, rr2)
+        lds_barrier6();                                             // barrier 0 of the first tile
+        // Iteration g + k_ of the current tile (g = 3 * c0): requests A(g+k_+4), part (k_+2)%3 of B(c0 + (k_+2)/3 + 1) and the
+        // residual operands of one epilogue slice into set rq; waits for set rs (requested two iterations ago); stores A(g+k_+2),
+        // part k_ of B(c0+1); in steps 0..7 of every tile but the first runs epilogue slice g+k_ of the previous tile with the
+        // residual operands of set rs.  Residual requests: steps 0..5 ask for slices 2..7 of the previous tile, the tile's last
+        // two steps for slices 0 and 1 of the tile itself (consumed by steps 0 and 1 of the next tile).
+#define PITER(k_, rs_a, rs_b, rs_r, rq_a, rq_b, rq_r)                                                            \
+        {                                                                                                        \
+            constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
+            const int gs_ = g + (k_);                                                                            \
+            __builtin_amdgcn_s_setprio(2);                                                                       \
+            PLOAD_A(gs_ + 4, rq_a) PLOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                          \
+            {                                                                                                    \
+                const bool fromprev_ = have_prev && gs_ < EPS - 2;                                               \
+                const Tile6 tq_ = fromprev_ ? pv : cur;                                                          \
+                const int jq_ = fromprev_ ? gs_ + 2 : ((gs_ == nsteps - 1) ? 1 : 0);                             \
+                PREQ_RES(tq_, jq_, rq_r)                                                                         \
+            }                                                                                                    \
+            __builtin_amdgcn_s_setprio(0);                                                                       \
+            P_STAMP(2, sidx);                                                                                    \
+            gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
+            if constexpr (NRES > 0) { _Pragma("unroll") for (int q = 0; q < GPS; ++q) { asm volatile("" : "+v"(rs_r[q][0])); if constexpr (NRES > 1) asm volatile("" : "+v"(rs_r[q][1])); } } \
+            P_STAMP(3, sidx);                                                                                    \
+            PSTORE_A(gs_ + 2, rs_a) PSTORE_B(c0 + 1, part_, rs_b)                                                \
+            P_STAMP(4, sidx);                                                                                    \
+            if (have_prev && gs_ < EPS) PEPI(pv, gs_, rs_r)                                                      \
+            P_STAMP(5, sidx);                                                                                    \
+            lds_barrier6();                                                                                      \
+            P_STAMP(6, sidx);                                                                                    \
+            if constexpr (STAMP) ++sidx;                                                                         \
+        }
+        // ONE loop over the chunks of all tiles of this workgroup (no alternative code paths around in-flight registers)
+        bool have_prev = false;
+        int sidx = 0;                                               // (STAMP builds: running step number)
+        bool has_next = tile + tstride < ntiles;
+        if (has_next) { nx = tile6<CFG>(A, tile + tstride); bases(nx, wsrc_n, isrc_n); }
+        for (int g = 0, c0 = 0;;) {
+            PITER(0, ra1, rb1, rr1, ra0, rb0, rr0)
+            PITER(1, ra2, rb2, rr2, ra1, rb1, rr1)
+            PITER(2, ra0, rb0, rr0, ra2, rb2, rr2)
+            g += 3; ++c0;
+            if (c0 == A.nchunk) {                                   // tile boundary (scalar bookkeeping only)
+                pv = cur;
+                if (!has_next) break;
+                tile += tstride;
+                cur = nx; wsrc_c = wsrc_n; isrc_c = isrc_n;
+                have_prev = true;
+                g = 0; c0 = 0;
+                has_next = tile + tstride < ntiles;
+                if (has_next) { nx = tile6<CFG>(A, tile + tstride); bases(nx, wsrc_n, isrc_n); }
+            }
+        }
+        last = pv;
+        gwait<0>(ra0, rb0); gwait<0>(ra1, rb1); gwait<0>(ra2, rb2);   // (requests past the end are still in flight)
+        if constexpr (NRES > 0) {
+#pragma unroll
+            for (int q = 0; q < GPS; ++q) { asm volatile("" : "+v"(rr0[q][0]), "+v"(rr1[q][0]), "+v"(rr2[q][0])); if constexpr (NRES > 1) asm volatile("" : "+v"(rr0[q][1]), "+v"(rr1[q][1]), "+v"(rr2[q][1])); }
+        }
+        if (bad && A.range_flag) *A.range_flag = 1u;
+#undef PITER
+#undef PLOAD_A
+#undef PSTORE_A
+#undef PLOAD_B
+#undef PSTORE_B
+#undef PREQ_RES
+#undef PEPI
+    } else {
+        // ---------------------------------------------------------------------- MFMA waves
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h2 = lane >> 5;
+        int pbh, pbw, m0;
+        C::wave_map(wave, pbh, pbw, m0);
+        const int pxl = (pbw + (li >> 3)) * IHP + pbh + (li & 7);
+        f32x16 acc[MW][NCT], accl[MW][NCT];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.f; accl[m][n][r] = 0.f; }
+        lds_barrier6();                                             // barrier 0 of the first tile
+        int sidx = 0;
+        while (true) {
+            for (int c = 0; c < A.nchunk; ++c) {
+                const uint4* ab = Abuf + lane;
+                const uint4* bb = Bbuf + (c & 1) * (SP * 2 * NPX) + h2 * NPX + pxl;
+                u32x4 bf[2][NCT][SP], af[2][MW][SP];
+                auto frag_a = [&](int T, int set, int m, int sp) __attribute__((always_inline)) {
+                    const int kh = T / 3, kw = T - 3 * kh;
+                    af[set][m][sp] = __builtin_bit_cast(u32x4, ab[kh * AST + ((kw * 2 + (m0 + m)) * SP + sp) * 64]);
+                };
+                auto frag_b = [&](int T, int set, int n, int sp) __attribute__((always_inline)) {
+                    const int kh = T / 3, kw = T - 3 * kh;
+                    bf[set][n][sp] = __builtin_bit_cast(u32x4, bb[sp * 2 * NPX + kw * IHP + kh + 8 * n]);
+                };
+                auto frags = [&](int T, int set) __attribute__((always_inline)) {
+                    frag_a(T, set, 0, 0); frag_b(T, set, 0, 0); frag_a(T, set, 0, 1); frag_b(T, set, 0, 1);
+#pragma unroll
+                    for (int n = 1; n < NCT; ++n) { frag_b(T, set, n, 0); frag_b(T, set, n, 1); }
+#pragma unroll
+                    for (int m = 1; m < MW; ++m) { frag_a(T, set, m, 0); frag_a(T, set, m, 1); }
+                };
+                frags(0, 0);
+                if (c == 0 && tile != (int)blockIdx.x) {            // a further tile: start from zero (the previous tile's sums are in `ot`)
+#pragma unroll
+                    for (int m = 0; m < MW; ++m)
+#pragma unroll
+                        for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.f; accl[m][n][r] = 0.f; }
+                }
+#pragma unroll
+                for (int T = 0; T < 9; ++T) {
+                    const int cu = T & 1;
+                    if (T < 8) frags(T + 1, cu ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MW; ++m)
+#pragma unroll
+                        for (int n = 0; n < NCT; ++n) {
+                            acc[m][n] = mfma_h(af[cu][m][0], bf[cu][n][0], acc[m][n]);
+                            f32x16 l_ = accl[m][n];
+                            l_ = mfma_h(af[cu][m][1], bf[cu][n][0], l_);
+                            l_ = mfma_h(af[cu][m][0], bf[cu][n][1], l_);
+                            accl[m][n] = l_;
+                        }
+                    if (T % 3 == 2) {
+                        if (T == 8 && c == A.nchunk - 1) {
+                            // the tile's last step: accumulators -> `ot` before the barrier that lets the loaders read it.  (The
+                            // loaders finished reading the previous tile's `ot` in step 7 of this tile, several barriers ago.)
+#pragma unroll
+                            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) {
+                                        const int co = (m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                                        ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = acc[m][n][r] * A.descale_hi + accl[m][n][r] * A.descale_lo;
+                                    }
+                        }
+                        P_STAMP(0, sidx);
+                        lds_barrier6();
+                        P_STAMP(1, sidx);
+                        if constexpr (STAMP) ++sidx;
+                    }
+                }
+            }
+            tile += tstride;
+            if (tile >= ntiles) break;
+        }
+        last = tile6<CFG>(A, tile - tstride);
+    }
+
+    // ---- the workgroup's last tile: all eight waves, as in k_conv6 (`ot` is complete: the loop's last barrier follows its stores)
+    {
+        const int ct = last.ct, oh0 = last.oh0, ow0 = last.ow0, b = last.b;
+        const bool has1 = NRES > 0, has2 = NRES > 1;
+        bool bad = false;
+        constexpr int GQ = NG / NT6;
+        static_assert(NG % NT6 == 0, "epilogue");
+        unsigned off[GQ];
+        f32x4 r1[GQ], r2[GQ];
+#pragma unroll
+        for (int k = 0; k < GQ; ++k) {
+            const int e = k * NT6 + tid;
+            const int co = e / GPC, rem = e - co * GPC, w = rem / (TH / 4), h = 4 * (rem - w * (TH / 4));
+            const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
+            const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
+            off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
+            r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
+        }
+        if (has1) {
+#pragma unroll
+            for (int k = 0; k < GQ; ++k) r1[k] = *(const f32x4*)(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 1u));
+        }
+        if (has2) {
+#pragma unroll
+            for (int k = 0; k < GQ; ++k) r2[k] = *(const f32x4*)(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 1u));
+        }
+#pragma unroll
+        for (int k = 0; k < GQ; ++k) {
+            const int e = k * NT6 + tid;
+            const int co = e / GPC, rem = e - co * GPC;
+            f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
+            if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+            if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
+            bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);
+        }
+        if (bad && A.range_flag) *A.range_flag = 1u;
+    }
+}
+
+// =====================================================================================================================
 // k_conv6s : the 2x2 / stride-2 layers on the same operand-splitting schemes.
 //   DOWN  Conv2d(k=2, s=2)           out[co][oh][ow]       = sum_ci,kh,kw w[co][ci][kh][kw] in[ci][2oh+kh][2ow+kw]
 //   UP    ConvTranspose2d(k=2, s=2)  out[co][2ih+kh][2iw+kw] = sum_ci     w[ci][co][kh][kw] in[ci][ih][iw]
@@ -715,6 +1093,10 @@ template <int CFG> constexpr size_t conv6_lds(int SP) {
     return (size_t)(NABUF * ast6(SP) + 2 * SP * 2 * ((((Cfg6<CFG>::TH + 2 + 7) / 16) * 16 + 8) * (Cfg6<CFG>::TW + 1) + Cfg6<CFG>::TH + 2)) * 16;
 }
 
+template <int CFG> constexpr size_t conv6p_lds() {
+    return conv6_lds<CFG>(2) + (size_t)64 * (Cfg6<CFG>::TH * Cfg6<CFG>::TW + 4) * 4;
+}
+
 static std::atomic<int> g_launch_counter{0};     // diagnostic: running number of k_conv6 launches (all configurations, all contexts)
 
 template <int CFG, int SP>
@@ -756,9 +1138,80 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     return QMRI_OK;
 }
 
+// persistent form (k_conv6p): one workgroup per CU walks the launch's tiles; returns QMRI_OK and sets *done when it ran
+template <int CFG, int NRES>
+int launch6p_t(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1, const PTensor* add2,
+               int relu_out) {
+    typedef Cfg6<CFG> C;
+    Conv6Args A{};
+    A.in = in.base1(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.base1();
+    A.add1 = add1 ? add1->base1() : nullptr; A.add2 = add2 ? add2->base1() : nullptr;
+    A.Cout = L.Cout; A.W = in.W; A.H = in.H;
+    A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
+    A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
+    A.add1_bs = add1 ? (long)add1->Cal * add1->plane() : 0;
+    A.add2_bs = add2 ? (long)add2->Cal * add2->plane() : 0;
+    A.nchunk = L.nchunk6; A.nchunk_all = L.nchunk6; A.ksplit = 1; A.out_ks = 0; A.n_ct = L.n_ct6;
+    A.tiles_h = (in.H + C::TH - 1) / C::TH; A.tiles_w = (in.W + C::TW - 1) / C::TW;
+    A.ntiles = A.n_ct * A.tiles_h * A.tiles_w * B;
+    A.relu_out = relu_out; A.vec4 = 1; A.wt = 1;
+    A.range_flag = ctx->net.d_range_flag;
+    A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
+    static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
+    A.stamps = (unsigned long long*)ctx->net.d_stamps; A.launch_idx = g_launch_counter.fetch_add(1, std::memory_order_relaxed);
+    A.detail = (A.stamps && A.launch_idx == stamp_launch) ? 1 : 0;
+    if (!ctx->conv6p_attr[CFG][NRES]) {
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6p<CFG, NRES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6p_lds<CFG>()));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6p<CFG, NRES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6p_lds<CFG>()));
+        ctx->conv6p_attr[CFG][NRES] = true;
+    }
+    const int grid = std::min(A.ntiles, ctx->conv_ncu);
+    if (A.detail) {                                                 // diagnostic build of the same kernel (tools/conv6p_stamps.py)
+        k_conv6p<CFG, NRES, true><<<dim3(grid), dim3(NT6), conv6p_lds<CFG>(), ctx->stream>>>(A);
+        QMRI_HIP(ctx, hipGetLastError());
+        return QMRI_OK;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
+    if (e0) hipExtLaunchKernelGGL((k_conv6p<CFG, NRES, false>), dim3(grid), dim3(NT6), (std::uint32_t)conv6p_lds<CFG>(), ctx->stream, e0, e1, 0, A);
+    else k_conv6p<CFG, NRES, false><<<dim3(grid), dim3(NT6), conv6p_lds<CFG>(), ctx->stream>>>(A);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
+template <int CFG>
+int launch6p(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1, const PTensor* add2,
+             int relu_out, bool* done) {
+    typedef Cfg6<CFG> C;
+    *done = false;
+    static const int persist = getenv("QMRI_CONV_PERSIST") ? atoi(getenv("QMRI_CONV_PERSIST")) : 1;
+    if (!persist || L.sp6 != 2 || L.Cout % 64 != 0 || L.nchunk6 < 4 || L.nchunk6 % 2 != 0 || (add2 && !add1)) return QMRI_OK;
+    const bool vec4 = in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
+                      (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp));
+    if (!vec4) return QMRI_OK;
+    if (!ctx->conv_ncu) {
+        hipDeviceProp_t prop;
+        QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->conv_ncu = prop.multiProcessorCount;
+    }
+    const long ntiles = (long)L.n_ct6 * ((in.H + C::TH - 1) / C::TH) * ((in.W + C::TW - 1) / C::TW) * B;
+    if (ntiles <= ctx->conv_ncu) return QMRI_OK;                   // at most one tile per CU: nothing to pipeline, k_conv6 is the same work
+    *done = true;
+    if (add2) return launch6p_t<CFG, 2>(ctx, L, B, in, out, add1, add2, relu_out);
+    if (add1) return launch6p_t<CFG, 1>(ctx, L, B, in, out, add1, add2, relu_out);
+    return launch6p_t<CFG, 0>(ctx, L, B, in, out, add1, add2, relu_out);
+}
+
 template <int CFG>
 int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
             const PTensor* add2, int relu_out, int ksplit = 1, float* partial = nullptr, long out_ks = 0) {
+    if constexpr (CFG < 2) {
+        if (ksplit == 1 && !partial) {
+            bool done = false;
+            QMRI_TRY(launch6p<CFG>(ctx, L, B, in, out, add1, add2, relu_out, &done));
+            if (done) return QMRI_OK;
+        }
+    }
     return (L.sp6 == 2) ? launch6<CFG, 2>(ctx, L, B, in, out, add1, add2, relu_out, ksplit, partial, out_ks)
                         : launch6<CFG, 3>(ctx, L, B, in, out, add1, add2, relu_out, ksplit, partial, out_ks);
 }
