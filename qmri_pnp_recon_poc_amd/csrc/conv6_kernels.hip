@@ -106,6 +106,26 @@ __device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__buil
 // releases ("+v"), so no consumer can be scheduled above it.
 // (scalar base + 32-bit per-lane byte offset: the offsets are loop invariant, the base advances per step)
 __device__ __forceinline__ void gload4(u32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
+// Buffer forms: descriptor (4 SGPRs) per tensor, per-lane byte offset (VGPR) + scalar byte offset (SGPR): a request costs the
+// wave ONE instruction plus whatever the scalar offset costs, instead of a 64-bit pointer per request.  num_records = 2^32 - 1:
+// the range check sees only the per-lane offset; the tensors here are far below 4 GB (conv6_launch checks).
+__device__ __forceinline__ u32x4 make_srd(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    u32x4 r;
+    r[0] = (unsigned)v; r[1] = (unsigned)(v >> 32) & 0xFFFFu; r[2] = 0xFFFFFFFFu; r[3] = 0x00020000u;
+    return r;
+}
+// a wave-uniform 32-bit value the compiler may hold in a VGPR -> SGPR (the "s" operands below); the s_nop covers the 5 wait
+// states between a VALU write of an SGPR and a vector-memory instruction reading it
+__device__ __forceinline__ unsigned usgpr(unsigned v) {
+    unsigned r = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("s_nop 4" : "+s"(r));
+    return r;
+}
+__device__ __forceinline__ void bload4(u32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
+__device__ __forceinline__ void bload4f(f32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
+__device__ __forceinline__ void bload1(float& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
+__device__ __forceinline__ void bstore4(f32x4 x, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(x), "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void gload4r(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 __device__ __forceinline__ void gload1(float& dst, unsigned off, const void* base) { asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], float (&b)[1][8]) {
@@ -538,7 +558,7 @@ template <int CFG> __device__ __forceinline__ Tile6 tile6(const Conv6Args& A, in
         if constexpr (STAMP) {                                                                                   \
             if (A.stamps && A.detail && (threadIdx.x & 255) == 0 && (idx) < 256) {                               \
                 const int sw_ = (blockIdx.x == 0) ? 0 : (blockIdx.x == 37) ? 1 : (blockIdx.x == 101) ? 2 : (blockIdx.x == 200) ? 3 : -1; \
-                if (sw_ >= 0) A.stamps[(sw_ * 8 + (kind)) * 256 + (idx)] = wall_clock64();                       \
+                if (sw_ >= 0) A.stamps[(sw_ * 10 + (kind)) * 256 + (idx)] = wall_clock64();                       \
             }                                                                                                    \
         }                                                                                                        \
     } while (0)
@@ -576,99 +596,110 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 
     if (tid >= NT6 - NLD6) {
         // ------------------------------------------------------------------ loaders
+        // A loader wave is INSTRUCTION-ISSUE bound (stamps: with 64-bit pointer arithmetic per request it needed 1.0-1.5 us per step
+        // against 0.76 us of matrix work).  Every request is therefore a buffer instruction: one descriptor per tensor, the
+        // per-lane part of the address in a loop-invariant VGPR, everything that moves (tile, chunk, step, epilogue slice) in the
+        // 32-bit scalar offset; LDS addresses are loop-invariant VGPRs + immediates.
         const int lt = tid - (NT6 - NLD6);
         __builtin_amdgcn_s_setprio(2);
-        unsigned aoff[NAQ], boff[3];
+        const u32x4 srdW = make_srd(A.wp), srdI = make_srd(A.in), srdO = make_srd(A.out);
+        const u32x4 srdR1 = make_srd(NRES > 0 ? (const void*)A.add1 : (const void*)A.out), srdR2 = make_srd(NRES > 1 ? (const void*)A.add2 : (const void*)A.out);
+        constexpr unsigned ASTB = AST * 16;                         // bytes of A per step
+        const unsigned plane4 = (unsigned)A.in_plane * 4u, oplane4 = (unsigned)A.out_plane * 4u;
+        const unsigned chunkB = CK * plane4;                        // bytes between chunks of the input
+        unsigned aoff[NAQ], boff[3][8];                             // per-lane byte offsets of this thread's requests
 #pragma unroll
-        for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
+        for (int q = 0; q < NAQ; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);      // (AST == NAQ * NLD6)
+        static_assert(AST == NAQ * NLD6, "A requests");
+        unsigned ldsB[3];                                           // LDS byte offset (inside one B buffer) of the item each part stores
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
             int item = part * (NBQ * NLD6) + lt;
             if (item >= NBI) item = 0;
             const int h2 = item / NLP, px = item - h2 * NLP;
             const int dw = px / IH, dh = px - dw * IH;
-            boff[part] = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
+            const unsigned b0 = (unsigned)(((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) boff[part][j] = b0 + (unsigned)j * plane4;
+            ldsB[part] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
         }
-        // this thread's share of a tile's epilogue: GQL float4 groups at a fixed (w, h), channels co0 + COSTEP * k
+        unsigned char* const ldsA = (unsigned char*)Abuf + lt * 16;                    // + buffer * ASTB + q * NLD6 * 16 (immediates)
+        unsigned char* const ldsBb = (unsigned char*)Bbuf;
+        // this thread's share of a tile's epilogue: GQL float4 groups at a fixed (w, h), channels eco0 + COSTEP * k
         const int erem = lt % GPC, eco0 = lt / GPC;
         const int ew = erem / (TH / 4), eh = 4 * (erem - ew * (TH / 4));
-        const float* otp = ot + eco0 * PP + 4 * erem;               // + k * COSTEP * PP
+        const unsigned evoff = (unsigned)(((size_t)eco0 * A.out_plane + (size_t)(ew + 1) * A.out_hp + (eh + 1)) * 4);   // + scalar (tile, slice)
+        const unsigned char* const otp = (const unsigned char*)(ot + eco0 * PP + 4 * erem);        // + k * COSTEP * PP * 4
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
         float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
         f32x4 rr0[GPS][NRES > 0 ? NRES : 1], rr1[GPS][NRES > 0 ? NRES : 1], rr2[GPS][NRES > 0 ? NRES : 1];   // residual operands, same rotation
-        Tile6 cur = last, nx = last, pv = last;
-        const uint4 *wsrc_c, *wsrc_n;
-        const float *isrc_c, *isrc_n;
-        auto bases = [&](const Tile6& t, const uint4*& w, const float*& in) __attribute__((always_inline)) {
-            w = A.wp + (size_t)t.ct * A.nchunk_all * 3 * AST;
-            in = A.in + (size_t)t.b * A.in_bs + (size_t)t.ow0 * A.in_hp + t.oh0;
+        // scalar byte offsets of a tile inside the weights / the input / the output (and residual) tensors
+        struct TOff { unsigned w, i, o, r1, r2; int oh0, ow0; };
+        auto toff = [&](const Tile6& t) __attribute__((always_inline)) {
+            TOff r;
+            r.w = (unsigned)t.ct * (unsigned)A.nchunk_all * 3u * ASTB;
+            r.i = (unsigned)(((size_t)t.b * A.in_bs + (size_t)t.ow0 * A.in_hp + t.oh0) * 4);
+            const unsigned px = (unsigned)(((size_t)t.ct * 64 * A.out_plane + (size_t)t.ow0 * A.out_hp + t.oh0) * 4);
+            r.o = (unsigned)((size_t)t.b * A.out_bs * 4) + px;
+            r.r1 = (unsigned)((size_t)t.b * A.add1_bs * 4) + px;
+            r.r2 = (unsigned)((size_t)t.b * A.add2_bs * 4) + px;
+            r.oh0 = t.oh0; r.ow0 = t.ow0;
+            return r;
         };
-        bases(cur, wsrc_c, isrc_c);
-        wsrc_n = wsrc_c; isrc_n = isrc_c;
+        TOff cur = toff(last), nx = cur, pv = cur;
         bool bad = false;
         // step / chunk indices are relative to the current tile; indices past its end address the next tile (or, after the last
         // tile, this one again: harmless re-reads into free buffers, as in k_conv6)
 #define PLOAD_A(g_, ra_)                                                                                         \
         {                                                                                                        \
             const int gg_ = (g_);                                                                                \
-            const uint4* ws = uniform_ptr((gg_ < nsteps) ? wsrc_c + (size_t)gg_ * AST : wsrc_n + (size_t)(gg_ - nsteps) * AST); \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) gload4(ra_[q], aoff[q], ws);                         \
+            const unsigned so_ = (gg_ < nsteps) ? cur.w + (unsigned)gg_ * ASTB : nx.w + (unsigned)(gg_ - nsteps) * ASTB; \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) bload4(ra_[q], aoff[q], srdW, so_);                  \
         }
-#define PSTORE_A(g_, ra_)                                                                                        \
+#define PSTORE_A(buf_, ra_)   /* buf_: compile-time A buffer */                                                  \
         {                                                                                                        \
-            uint4* ad = Abuf + ((g_) % NABUF) * AST;                                                             \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; ad[(i < AST) ? i : 0] = __builtin_bit_cast(uint4, ra_[q]); } \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) *(uint4*)(ldsA + (buf_) * ASTB + q * NLD6 * 16) = __builtin_bit_cast(uint4, ra_[q]); \
         }
 #define PLOAD_B(c_, part_, rb_)                                                                                  \
         {                                                                                                        \
             const int cc_ = (c_);                                                                                \
-            const float* bs_ = uniform_ptr((cc_ < A.nchunk) ? isrc_c + (size_t)cc_ * CK * A.in_plane            \
-                                                            : isrc_n + (size_t)(cc_ - A.nchunk) * CK * A.in_plane); \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) gload1(rb_[0][j], boff[part_], uniform_ptr(bs_ + (size_t)j * A.in_plane)); \
+            const unsigned so_ = (cc_ < A.nchunk) ? cur.i + (unsigned)cc_ * chunkB : nx.i + (unsigned)(cc_ - A.nchunk) * chunkB; \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_[0][j], boff[part_][j], srdI, so_);          \
         }
 #define PSTORE_B(c_, part_, rb_)                                                                                 \
         {                                                                                                        \
-            uint4* bd = Bbuf + ((c_) & 1) * (SP * 2 * NPX);                                                      \
-            int item = (part_) * (NBQ * NLD6) + lt;                                                              \
-            if (item >= NBI) item = 0;                                                                           \
-            const int h2 = item / NLP, px = item - h2 * NLP;                                                     \
-            const int dw = px / IH, dh = px - dw * IH;                                                           \
-            const int e = h2 * NPX + dw * IHP + dh;                                                              \
+            unsigned char* bd = ldsBb + ((c_) & 1) * (SP * 2 * NPX * 16) + ldsB[part_];                          \
             uint4 s0, s1;                                                                                        \
             split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x);                                                      \
             split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y);                                                      \
             split_pair_h(rb_[0][4], rb_[0][5], s0.z, s1.z);                                                      \
             split_pair_h(rb_[0][6], rb_[0][7], s0.w, s1.w);                                                      \
-            bd[e] = s0;                                                                                          \
-            bd[2 * NPX + e] = s1;                                                                                \
+            if ((part_) * (NBQ * NLD6) + lt < NBI) { *(uint4*)bd = s0; *(uint4*)(bd + 2 * NPX * 16) = s1; }      \
         }
         // residual operands of epilogue slice j_ (groups GPS*j_ ...) of tile t_: requested into set rr_.  Issued in EVERY step (a
         // step that has nothing to prefetch repeats slice 0 of the current tile): one unconditional instruction sequence, so the
         // destination registers of in-flight loads are never merged across branches (no copies of in-flight registers)
 #define PREQ_RES(t_, j_, rr_)                                                                                    \
         if constexpr (NRES > 0) {                                                                                \
-            const int oh_ = (t_).oh0 + eh, ow_ = (t_).ow0 + ew;                                                  \
-            const bool okhw_ = oh_ < A.H && ow_ < A.W;                                                           \
-            const unsigned ob_ = okhw_ ? (unsigned)(((size_t)((t_).ct * 64 + eco0) * A.out_plane + (size_t)(ow_ + 1) * A.out_hp + (oh_ + 1)) * 4) : 4u; \
+            const bool okhw_ = (t_).oh0 + eh < A.H && (t_).ow0 + ew < A.W;                                       \
+            const unsigned vo_ = okhw_ ? evoff : 0u;                                                             \
             _Pragma("unroll") for (int q = 0; q < GPS; ++q) {                                                    \
-                const size_t ko_ = (size_t)((j_) * GPS + q) * COSTEP * A.out_plane;                              \
-                gload4r(rr_[q][0], ob_, uniform_ptr(A.add1 + (size_t)(t_).b * A.add1_bs + ko_));                 \
-                if constexpr (NRES > 1) gload4r(rr_[q][1], ob_, uniform_ptr(A.add2 + (size_t)(t_).b * A.add2_bs + ko_)); \
+                const unsigned ko_ = (unsigned)((j_) * GPS + q) * COSTEP * oplane4;                              \
+                bload4f(rr_[q][0], vo_, srdR1, usgpr((t_).r1 + ko_));                                            \
+                if constexpr (NRES > 1) bload4f(rr_[q][1], vo_, srdR2, usgpr((t_).r2 + ko_));                    \
             }                                                                                                    \
         }
         // epilogue slice j_ of tile t_ (its accumulators are in `ot`): LDS tile + residual operands (set rr_), ReLU, guard, store
 #define PEPI(t_, j_, rr_)                                                                                        \
         {                                                                                                        \
-            const int oh_ = (t_).oh0 + eh, ow_ = (t_).ow0 + ew;                                                  \
-            const bool okhw_ = oh_ < A.H && ow_ < A.W;                                                           \
-            float* ob_ = A.out + (size_t)(t_).b * A.out_bs + (size_t)((t_).ct * 64 + eco0) * A.out_plane + (size_t)(ow_ + 1) * A.out_hp + (oh_ + 1); \
+            const bool okhw_ = (t_).oh0 + eh < A.H && (t_).ow0 + ew < A.W;                                       \
             _Pragma("unroll") for (int q = 0; q < GPS; ++q) {                                                    \
                 const int k_ = (j_) * GPS + q;                                                                   \
-                f32x4 x = *(const f32x4*)(otp + k_ * COSTEP * PP);                                               \
+                f32x4 x = *(const f32x4*)(otp + k_ * (COSTEP * PP * 4));                                         \
                 if constexpr (NRES > 0) x = x + rr_[q][0];                                                       \
                 if constexpr (NRES > 1) x = x + rr_[q][1];                                                       \
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); } \
-                if (okhw_) store4(ob_ + (size_t)k_ * COSTEP * A.out_plane, x, 1);                                \
+                if (okhw_) bstore4(x, evoff, srdO, usgpr((t_).o + (unsigned)k_ * COSTEP * oplane4));             \
                 bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);  \
             }                                                                                                    \
         }
@@ -695,10 +726,13 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
             const int gs_ = g + (k_);                                                                            \
             __builtin_amdgcn_s_setprio(2);                                                                       \
-            PLOAD_A(gs_ + 4, rq_a) PLOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                          \
+            PLOAD_A(gs_ + 4, rq_a)                                                                               \
+            P_STAMP(7, sidx);                                                                                    \
+            PLOAD_B(c0 + dc2_ + 1, part2_, rq_b)                                                                 \
+            P_STAMP(8, sidx);                                                                                    \
             {                                                                                                    \
                 const bool fromprev_ = have_prev && gs_ < EPS - 2;                                               \
-                const Tile6 tq_ = fromprev_ ? pv : cur;                                                          \
+                const TOff tq_ = fromprev_ ? pv : cur;                                                           \
                 const int jq_ = fromprev_ ? gs_ + 2 : ((gs_ == nsteps - 1) ? 1 : 0);                             \
                 PREQ_RES(tq_, jq_, rq_r)                                                                         \
             }                                                                                                    \
@@ -707,7 +741,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
             if constexpr (NRES > 0) { _Pragma("unroll") for (int q = 0; q < GPS; ++q) { asm volatile("" : "+v"(rs_r[q][0])); if constexpr (NRES > 1) asm volatile("" : "+v"(rs_r[q][1])); } } \
             P_STAMP(3, sidx);                                                                                    \
-            PSTORE_A(gs_ + 2, rs_a) PSTORE_B(c0 + 1, part_, rs_b)                                                \
+            PSTORE_A(((k_) + 2) % 3, rs_a) PSTORE_B(c0 + 1, part_, rs_b)   /* step g+k_+2 lives in A buffer (g+k_+2) % 3, g % 3 == 0 */ \
             P_STAMP(4, sidx);                                                                                    \
             if (have_prev && gs_ < EPS) PEPI(pv, gs_, rs_r)                                                      \
             P_STAMP(5, sidx);                                                                                    \
@@ -719,7 +753,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         bool have_prev = false;
         int sidx = 0;                                               // (STAMP builds: running step number)
         bool has_next = tile + tstride < ntiles;
-        if (has_next) { nx = tile6<CFG>(A, tile + tstride); bases(nx, wsrc_n, isrc_n); }
+        if (has_next) nx = toff(tile6<CFG>(A, tile + tstride));
         for (int g = 0, c0 = 0;;) {
             PITER(0, ra1, rb1, rr1, ra0, rb0, rr0)
             PITER(1, ra2, rb2, rr2, ra1, rb1, rr1)
@@ -729,14 +763,14 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
                 pv = cur;
                 if (!has_next) break;
                 tile += tstride;
-                cur = nx; wsrc_c = wsrc_n; isrc_c = isrc_n;
+                cur = nx;
                 have_prev = true;
                 g = 0; c0 = 0;
                 has_next = tile + tstride < ntiles;
-                if (has_next) { nx = tile6<CFG>(A, tile + tstride); bases(nx, wsrc_n, isrc_n); }
+                if (has_next) nx = toff(tile6<CFG>(A, tile + tstride));
             }
         }
-        last = pv;
+        last = tile6<CFG>(A, tile);
         gwait<0>(ra0, rb0); gwait<0>(ra1, rb1); gwait<0>(ra2, rb2);   // (requests past the end are still in flight)
         if constexpr (NRES > 0) {
 #pragma unroll

@@ -21,10 +21,11 @@ def sgpr_hazards(lines, name):
     bad = 0
     real = [(i, l.strip()) for i, l in enumerate(lines) if l.strip() and not l.strip().startswith(';') and not l.strip().startswith('.')]
     for k, (i, t) in enumerate(real):
-        if not t.startswith('global_load') or ' s[' not in t: continue
-        m = re.search(r's\[(\d+):(\d+)\]', t)
-        if not m: continue
-        need = {int(m.group(1)), int(m.group(2))}
+        if not (t.startswith('global_load') or t.startswith('buffer_load') or t.startswith('buffer_store') or t.startswith('global_store')): continue
+        need = set()
+        for m in re.finditer(r's\[(\d+):(\d+)\]', t): need |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r'(?<![\w\[])s(\d+)\b', t): need.add(int(m.group(1)))
+        if not need: continue
         slots = 0
         for j in range(k - 1, max(k - 12, -1), -1):
             u = real[j][1]
@@ -49,7 +50,7 @@ def audit(lines, name):
         if t.startswith(';;#ASMEND'): inasm = False; continue
         if not t or t.startswith(';') or t.startswith('.'): continue
         if 'scratch_' in t: scratch += 1
-        if inasm and t.startswith('global_load'):
+        if inasm and (t.startswith('global_load') or t.startswith('buffer_load')):
             pending.append((i, regs(t.split()[1].rstrip(','))))
             nload += 1
             continue

@@ -28,7 +28,7 @@ y = eng.denoise(x)
 buf = np.zeros((4096 * 11,), np.uint64)
 eng.L.qmri_debug_conv_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 assert eng.L.qmri_debug_conv_stamps(eng.h, buf.ctypes.data, 0) == 0
-s = buf[:4 * 8 * 256].reshape(4, 8, 256).astype(np.int64)
+s = buf[:4 * 10 * 256].reshape(4, 10, 256).astype(np.int64)
 names = ['mfma arrive', 'mfma exit', 'ld issued', 'ld waited', 'ld stored', 'ld arrive', 'ld exit']
 for wg in range(4):
     n = int((s[wg, 0] > 0).sum())
@@ -42,6 +42,8 @@ for wg in range(4):
     print('   loader step: issue %.2f, wait for operands %.2f, split+store %.2f, epilogue slice %.2f us (median; epilogue over the steps that have one: %.2f)'
           % (np.median(li[1:] - le[:-1]) / 100.0, np.median(lw - li) / 100.0, np.median(ls - lw) / 100.0, np.median(la - ls) / 100.0,
              np.median((la - ls)[(la - ls) > 5]) / 100.0 if ((la - ls) > 5).any() else 0.0))
+    iA, iB = s[wg, 7, :n], s[wg, 8, :n]
+    print('   issue phase: A requests %.2f, B requests %.2f, residual requests %.2f us (median)' % (np.median(iA[1:] - le[:-1]) / 100.0, np.median(iB - iA) / 100.0, np.median(li - iB) / 100.0))
     if wg == 0:
         print('   step: mfma_busy  mfma_wait | ld_issue ld_wait ld_store ld_epi ld_barrier_wait   (us)')
         for i in range(1, min(n, 40)):
