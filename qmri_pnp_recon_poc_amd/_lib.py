@@ -81,9 +81,11 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # QMRI_LIBQMRI: another build of the same library (A/B timing of two builds on one box, tools/ab_build.sh); default: in-tree
+    path = os.environ.get("QMRI_LIBQMRI") or LIB_PATH
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
         raise ImportError(f"libqmri.so lacks symbols declared in include/qmri.h: {missing}")

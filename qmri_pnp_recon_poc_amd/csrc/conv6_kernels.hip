@@ -222,9 +222,14 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         // ------------------------------------------------------------------ loaders
         const int lt = tid - (NT6 - NLD6);
         __builtin_amdgcn_s_setprio(2);                             // requests first: the MFMA waves have work queued anyway
-        const uint4* wsrc = A.wp + ((size_t)ct * A.nchunk_all + (size_t)ks * A.nchunk) * 3 * AST;   // steps of a cout tile are contiguous
-        const float* isrc = A.in + (size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0;   // halo origin = padded (oh0, ow0)
-        unsigned aoff[NAQ], boff[3];                               // loop-invariant byte offsets of this thread's requests (B: channel 0 of its 8)
+        // A loader wave is instruction-issue bound (tools/conv6p_stamps.py), so every request is a buffer instruction: one
+        // descriptor per tensor, the per-lane part of the address in a loop-invariant VGPR, whatever moves in the 32-bit scalar offset
+        const u32x4 srdW = make_srd(A.wp), srdI = make_srd(A.in);
+        constexpr unsigned ASTB = AST * 16;                         // bytes of A per step
+        const unsigned plane4 = (unsigned)A.in_plane * 4u, chunkB = CK * plane4;
+        const unsigned wbase = (unsigned)(((size_t)ct * A.nchunk_all + (size_t)ks * A.nchunk) * 3 * ASTB);   // steps of a cout tile are contiguous
+        const unsigned ibase = (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0) * 4);   // halo origin = padded (oh0, ow0)
+        unsigned aoff[NAQ], boff[3][8], ldsB[3];                   // loop-invariant byte offsets of this thread's requests / LDS stores
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
 #pragma unroll
@@ -233,7 +238,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             if (item >= NBI) item = 0;
             const int h2 = item / NLP, px = item - h2 * NLP;
             const int dw = px / IH, dh = px - dw * IH;
-            boff[part] = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
+            const unsigned b0 = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) boff[part][j] = b0 + (unsigned)j * plane4;   // the 8 channels differ by a plane
+            ldsB[part] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
         }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
         float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
@@ -244,48 +252,37 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         // (Requests past the end are clamped, not skipped: branch-free code lets the compiler count vmcnt exactly.)
 #define LOAD_A(g_, ra_)                                                                                          \
         {                                                                                                        \
-            const uint4* ws = uniform_ptr(wsrc + (size_t)(((g_) < nsteps) ? (g_) : nsteps - 1) * AST);           \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) gload4(ra_[q], aoff[q], ws);                                        \
+            const unsigned so_ = wbase + (unsigned)(((g_) < nsteps) ? (g_) : nsteps - 1) * ASTB;                 \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) bload4(ra_[q], aoff[q], srdW, so_);                  \
         }
-#define STORE_A(g_, ra_)       /* (past the end: a free buffer receives the clamped request; surplus threads repeat entry 0) */ \
+#define STORE_A(buf_, ra_)     /* buf_ = step % NABUF, a compile-time constant; surplus threads repeat entry 0 (clamped request) */ \
         {                                                                                                        \
-            uint4* ad = Abuf + ((g_) % NABUF) * AST;                                                             \
+            uint4* ad = Abuf + (buf_) * AST;                                                                     \
             _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; ad[(i < AST) ? i : 0] = __builtin_bit_cast(uint4, ra_[q]); } \
         }
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
-            const int cc = ((c_) < A.nchunk) ? (c_) : A.nchunk - 1;                                              \
-            const float* bs_ = uniform_ptr(isrc + (size_t)cc * CK * A.in_plane);                                 \
-            /* the 8 channels differ by a plane: the step goes into the scalar base, not into 8 more offset registers */ \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) gload1(rb_[0][j], boff[part_], uniform_ptr(bs_ + (size_t)j * A.in_plane)); \
+            const unsigned so_ = ibase + (unsigned)(((c_) < A.nchunk) ? (c_) : A.nchunk - 1) * chunkB;           \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_[0][j], boff[part_][j], srdI, so_);          \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
         {                                                                                                        \
-            uint4* bd = Bbuf + ((c_) & 1) * (SP * 2 * NPX);                                                      \
-            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                                    \
-                int item = (part_) * (NBQ * NLD6) + lt + NLD6 * q;                                               \
-                if (item >= NBI) item = 0;                                                                       \
-                {                                                                                                \
-                    const int h2 = item / NLP, px = item - h2 * NLP;                                             \
-                    const int dw = px / IH, dh = px - dw * IH;                                                   \
-                    const int e = h2 * NPX + dw * IHP + dh;                                                      \
-                    uint4 s0, s1, s2;                                                                            \
-                    if constexpr (SP == 3) {                                                                     \
-                        split_pair(rb_[q][0], rb_[q][1], s0.x, s1.x, s2.x);                                      \
-                        split_pair(rb_[q][2], rb_[q][3], s0.y, s1.y, s2.y);                                      \
-                        split_pair(rb_[q][4], rb_[q][5], s0.z, s1.z, s2.z);                                      \
-                        split_pair(rb_[q][6], rb_[q][7], s0.w, s1.w, s2.w);                                      \
-                    } else {                                                                                     \
-                        split_pair_h(rb_[q][0], rb_[q][1], s0.x, s1.x);                                          \
-                        split_pair_h(rb_[q][2], rb_[q][3], s0.y, s1.y);                                          \
-                        split_pair_h(rb_[q][4], rb_[q][5], s0.z, s1.z);                                          \
-                        split_pair_h(rb_[q][6], rb_[q][7], s0.w, s1.w);                                          \
-                    }                                                                                            \
-                    bd[e] = s0;                  /* split planes are 2*NPX entries apart */                       \
-                    bd[2 * NPX + e] = s1;                                                                        \
-                    if constexpr (SP == 3) bd[4 * NPX + e] = s2;                                                 \
-                }                                                                                                \
+            unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_];              \
+            uint4 s0, s1, s2;                                                                                    \
+            if constexpr (SP == 3) {                                                                             \
+                split_pair(rb_[0][0], rb_[0][1], s0.x, s1.x, s2.x);                                              \
+                split_pair(rb_[0][2], rb_[0][3], s0.y, s1.y, s2.y);                                              \
+                split_pair(rb_[0][4], rb_[0][5], s0.z, s1.z, s2.z);                                              \
+                split_pair(rb_[0][6], rb_[0][7], s0.w, s1.w, s2.w);                                              \
+            } else {                                                                                             \
+                split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x);                                                  \
+                split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y);                                                  \
+                split_pair_h(rb_[0][4], rb_[0][5], s0.z, s1.z);                                                  \
+                split_pair_h(rb_[0][6], rb_[0][7], s0.w, s1.w);                                                  \
             }                                                                                                    \
+            *(uint4*)bd = s0;                    /* split planes are 2*NPX entries apart */                       \
+            *(uint4*)(bd + 2 * NPX * 16) = s1;                                                                   \
+            if constexpr (SP == 3) *(uint4*)(bd + 4 * NPX * 16) = s2;                                            \
         }
         // prologue: all of B(chunk 0), A(0) and A(1); then the requests for the stores of iterations 0 and 1.
         // (All of the first chunk is requested at once -- one memory latency, not three.)
@@ -316,7 +313,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             C6_STAMP(2, g + (k_) + 1);                                                                           \
             gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
             C6_STAMP(3, g + (k_) + 1);                                                                           \
-            STORE_A(g + (k_) + 2, rs_a) STORE_B(c0 + 1, part_, rs_b)                                             \
+            STORE_A(((k_) + 2) % NABUF, rs_a) STORE_B(c0 + 1, part_, rs_b)   /* step g+k_+2, g % 3 == 0 */        \
             C6_STAMP(1, g + (k_) + 1);                                                                           \
             lds_barrier6();                                                                                      \
         }
