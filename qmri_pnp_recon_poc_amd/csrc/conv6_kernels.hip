@@ -79,10 +79,13 @@ template <> struct Cfg6<2> {     // 64 px, waves = 2 cout halves x 2 pixel block
 constexpr int NABUF = 3;         // LDS buffers of A (one step each): step g lives in buffer g % 3 = its kh; a step's weights are complete one
                                  // barrier before the step starts, so the MFMA waves can request its first fragments across that barrier
 
+// (STAMP: diagnostic instantiation only -- the production kernels carry no stamp code)
 #define C6_STAMP(role, k)                                                                        \
     do {                                                                                         \
-        if (A.stamps && A.detail && (threadIdx.x & 255) == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && (k) < 128)   \
-            A.stamps[((blockIdx.x / 13) * 4 + (role)) * 128 + (k)] = wall_clock64();            \
+        if constexpr (STAMP) {                                                                   \
+            if (A.stamps && A.detail && (threadIdx.x & 255) == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && (k) < 128)   \
+                A.stamps[((blockIdx.x / 13) * 4 + (role)) * 128 + (k)] = wall_clock64();        \
+        }                                                                                        \
     } while (0)
 
 __device__ __forceinline__ void lds_barrier6() {
@@ -177,15 +180,23 @@ __device__ __forceinline__ void split_pair(float xa, float xb, unsigned& p0, uns
 
 // x = hi + lo' / 2^11 with hi = f16(x), lo' = f16((x - hi) * 2^11): 22 significant bits plus the sign of lo'
 // (x - hi is exact in fp32; lo' rounds at 2^-22 |x|); two values packed per dword, low half = first
+// gfx950: v_cvt_pk_f16_f32 rounds and packs two values in one instruction; x - hi is taken as fma(hi, -1, x) so that it becomes one
+// v_fma_mix_f32 reading the f16 half directly (exact either way): 6 VALU instructions per pair instead of 12.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, unsigned& p1) {
-    const _Float16 a0 = (_Float16)xa, b0 = (_Float16)xb;
-    const _Float16 a1 = (_Float16)((xa - (float)a0) * LO_SCALE), b1 = (_Float16)((xb - (float)b0) * LO_SCALE);
-    p0 = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, b0) << 16);
-    p1 = (unsigned)__builtin_bit_cast(unsigned short, a1) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+    const f16x2 hi = __builtin_convertvector((f32x2){xa, xb}, f16x2);
+    const float ra = __builtin_fmaf((float)hi[0], -1.0f, xa), rb = __builtin_fmaf((float)hi[1], -1.0f, xb);
+    const f16x2 lo = __builtin_convertvector((f32x2){ra * LO_SCALE, rb * LO_SCALE}, f16x2);
+    p0 = __builtin_bit_cast(unsigned, hi);
+    p1 = __builtin_bit_cast(unsigned, lo);
 }
 constexpr float F16_RANGE = 60000.f;  // |activation| above this cannot be split (f16 max 65504): reported through range_flag
 
-template <int CFG, int SP>
+// (Measured and removed: streaming the residual operand into an LDS tile during the last 8 steps of the loop, so that the epilogue
+//  finds it on chip.  The loop is bound by the loader waves (tools/conv6p_stamps.py), so what the epilogue saved the loop lost:
+//  634.9 vs 634.9 ADMM it/s, residual layers 21.3 us either way against 17.8 us for layers without a residual operand.)
+template <int CFG, int SP, bool STAMP>
 __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int AST = ast6(SP);
     typedef Cfg6<CFG> C;
@@ -343,7 +354,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.f; if constexpr (SP == 2) accl[m][n][r] = 0.f; }
 
-    if (A.stamps && tid == 0 && blockIdx.x == 0) { A.stamps[8192 + (A.launch_idx & 127) * 4] = wall_clock64(); A.stamps[8192 + (A.launch_idx & 127) * 4 + 3] = (unsigned long long)(CFG * 1000 + nsteps); }
+    if constexpr (STAMP) { if (A.stamps && tid == 0 && blockIdx.x == 0) { A.stamps[8192 + (A.launch_idx & 127) * 4] = wall_clock64(); A.stamps[8192 + (A.launch_idx & 127) * 4 + 3] = (unsigned long long)(CFG * 1000 + nsteps); } }
     C6_STAMP(0, 0);
     lds_barrier6();                                                 // barrier 0
     for (int c = 0; c < A.nchunk; ++c) {
@@ -413,14 +424,16 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             if (T % 3 == 2) {
                 const int g = 3 * c + T / 3;
                 C6_STAMP(0, g + 1);
-                if (A.stamps && A.detail && tid == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && g + 65 < 128)
-                    A.stamps[((blockIdx.x / 13) * 4 + 0) * 128 + g + 65] = __builtin_readcyclecounter();
+                if constexpr (STAMP) {
+                    if (A.stamps && A.detail && tid == 0 && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 8 && g + 65 < 128)
+                        A.stamps[((blockIdx.x / 13) * 4 + 0) * 128 + g + 65] = __builtin_readcyclecounter();
+                }
                 lds_barrier6();                                     // barrier g+1
             }
         }
     }
     C6_STAMP(0, nsteps + 1);
-    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 1] = wall_clock64();
+    if constexpr (STAMP) { if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 1] = wall_clock64(); }
 
     // ---- accumulators -> LDS tile ot[cout][pixel] (the B buffers are free now).  C/D layout: col = lane&31 (pixel),
     // row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -511,10 +524,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         if constexpr (SP == 2) { if (bad && A.range_flag) *A.range_flag = 1u; }   // (every writer stores the same value)
     }
     C6_STAMP(0, nsteps + 2);
-    if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64();
+    if constexpr (STAMP) { if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64(); }
 }
 
-template <int CFG, int SP> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP>(A); }
+template <int CFG, int SP, bool STAMP = false> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP, STAMP>(A); }
 
 // =====================================================================================================================
 // k_conv6p : persistent, software-pipelined form of k_conv6 (f16 x 3 scheme) for launches with several tiles per CU -- slice
@@ -1156,15 +1169,24 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
     A.launch_idx = g_launch_counter.fetch_add(1, std::memory_order_relaxed);
     A.detail = (stamp_launch < 0 || A.launch_idx == stamp_launch) ? 1 : 0;
+    const size_t lds = conv6_lds<CFG>(SP);
     if (!ctx->conv6_attr[CFG][SP - 2]) {
-        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6_lds<CFG>(SP)));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->conv6_attr[CFG][SP - 2] = true;
     }
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));                  // (profile level 2 only)
-    if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP>), dim3(grid), dim3(NT6), (std::uint32_t)conv6_lds<CFG>(SP), ctx->stream, e0, e1, 0, A);
-    else k_conv6<CFG, SP><<<dim3(grid), dim3(NT6), conv6_lds<CFG>(SP), ctx->stream>>>(A);
+    if constexpr (SP == 2 && CFG < 2) {
+        if (A.stamps) {                                             // QMRI_CONV_STAMPS: the diagnostic instantiation (tools/conv6_stamps.py)
+            QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_conv6<CFG, SP, true><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+            QMRI_HIP(ctx, hipGetLastError());
+            return QMRI_OK;
+        }
+    }
+    if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP>), dim3(grid), dim3(NT6), (std::uint32_t)lds, ctx->stream, e0, e1, 0, A);
+    else k_conv6<CFG, SP><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
