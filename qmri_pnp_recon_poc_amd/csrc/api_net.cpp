@@ -46,6 +46,9 @@ void qmri_free_net(qmri_ctx* ctx) {
     if (p.d_c6part) (void)hipFree(p.d_c6part);
     if (p.d_range_flag) (void)hipFree(p.d_range_flag);
     if (p.h_range_flag) (void)hipHostFree(p.h_range_flag);
+    if (p.d_act_slots) (void)hipFree(p.d_act_slots);
+    if (p.d_act_count) (void)hipFree(p.d_act_count);
+    if (p.d_act_ref) (void)hipFree(p.d_act_ref);
     p = NetPlan();
 }
 
@@ -84,6 +87,7 @@ static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const floa
     QMRI_TRY(pack_layer6(ctx, L, w));                      // the same weights, split for the bf16 / f16 matrix-core kernels
     const int taps = (kind == CONV_3X3) ? 9 : 4;
     w += (size_t)Cin * Cout * taps;
+    L.index = (int)ctx->net.layers.size();
     ctx->net.layers.push_back(L);
     return QMRI_OK;
 }
@@ -157,7 +161,10 @@ static int net_calibrate_scheme(qmri_ctx* ctx) {
         p.force_f32 = false;
         if (rc != QMRI_OK) break;
         if (hipMemcpyAsync(d_ref, p.out32.p, nout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = QMRI_ERR_HIP; break; }
-        if ((rc = net_forward_padded(ctx, 1)) != QMRI_OK) break;    // the f16 kernels
+        p.act_record = true;                                         // ... which also record every layer's magnitude (ACT_LOW guard)
+        rc = net_forward_padded(ctx, 1);                             // the f16 kernels
+        p.act_record = false;
+        if (rc != QMRI_OK) break;
         if ((rc = ew_launch_absmax(ctx, d_ref, nullptr, nout, d_m)) != QMRI_OK) break;
         if ((rc = ew_launch_absmax(ctx, p.out32.p, d_ref, nout, d_m + 1)) != QMRI_OK) break;
         unsigned m[2] = {0, 0}, flag = 0;
@@ -281,8 +288,18 @@ static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, const PTensor
     return QMRI_OK;
 }
 
+static int net_forward_layers(qmri_ctx* ctx, int B);
+
 // network forward on the context's padded tensors: in32 -> out32
 static int net_forward_padded(qmri_ctx* ctx, int B) {
+    const bool report = !ctx->net.force_f32;                        // (the calibration's f32 pass reports nothing)
+    if (report) QMRI_TRY(conv6_act_begin(ctx, (int)ctx->net.layers.size()));
+    QMRI_TRY(net_forward_layers(ctx, B));
+    if (report) QMRI_TRY(conv6_act_end(ctx));                       // low-magnitude guard of the f16 scheme (conv6_kernels.hip, ACT_LOW)
+    return qmri_prof_chain_finish(ctx);
+}
+
+static int net_forward_layers(qmri_ctx* ctx, int B) {
     NetPlan& p = ctx->net;
     const int nb = p.desc.nb;
     size_t li = 0;
@@ -295,7 +312,7 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
             QMRI_TRY(run_conv(ctx, p.layers[l], B, *in, *out, nullptr, nullptr, l != nl - 1));
             in = out;
         }
-        return qmri_prof_chain_finish(ctx);
+        return QMRI_OK;
     }
     // UNetRes.forward, network_unet.py:106-117
     QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.in32, p.x[0], nullptr, nullptr, 0));                       // x1 = m_head(x0)
@@ -309,7 +326,7 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
         QMRI_TRY(run_resblocks(ctx, li, nb, B, p.a[l - 1], p.a[l - 1], p.t[l - 1], &p.x[l - 1]));
     }
     QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[0], p.out32, nullptr, nullptr, 0));                      // m_tail(x + x1)
-    return qmri_prof_chain_finish(ctx);
+    return QMRI_OK;
 }
 
 // The forward pass is a fixed sequence of ~65 dependent launches with fixed arguments.  With QMRI_GRAPH=1 it is captured

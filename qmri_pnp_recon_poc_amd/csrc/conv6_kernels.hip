@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "qmri_internal.h"
 #include <hip/hip_ext.h>
 
@@ -44,6 +45,8 @@ constexpr int CK = 16;           // input channels per chunk = K of one MFMA
 constexpr int ast6(int SP) { return 3 * 2 * SP * 64; }   // uint4 per step of A: 3 taps x 2 cout tiles x SP splits x 64 lanes
 constexpr float LO_SCALE = 2048.f;    // f16 scheme: the low piece is stored as (x - hi) * 2^11, so it is normal whenever x is
 
+struct ActMax { float* slots; int* count; int layer; };   // where a launch reports its largest |output| (see ACT_LOW); layer < 0: it does not
+
 struct Conv6Args {
     const float* in; const uint4* wp; float* out; const float* add1; const float* add2;
     int Cout, W, H;
@@ -57,6 +60,7 @@ struct Conv6Args {
     int ntiles;                   // k_conv6p: tiles of the launch (n_ct * tiles_h * tiles_w * B)
     int launch_idx, detail;       // diagnostic: running launch number; record the per-step stamps of this launch
     unsigned* range_flag;         // f16 scheme: set to 1 when an output leaves the range the next layer's f16 split can carry
+    ActMax am;                    // f16 scheme: where this launch reports the largest |output| (see ACT_LOW)
     float descale_hi, descale_lo; // f16 scheme: the layer's weights are packed times 2^k (largest |w| in [1, 2)): 2^-k and 2^-k / 2^11
     unsigned long long* stamps;   // diagnostic (QMRI_CONV_STAMPS): [16 workgroups][2 roles][128] barrier-arrival times, 100 MHz clock
 };
@@ -192,6 +196,45 @@ __device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, u
     p1 = __builtin_bit_cast(unsigned, lo);
 }
 constexpr float F16_RANGE = 60000.f;  // |activation| above this cannot be split (f16 max 65504): reported through range_flag
+// The low side of the f16 split: an activation below 2^-14 has a subnormal hi piece, i.e. an ABSOLUTE error of ~2^-36 instead of a
+// relative one of 2^-22.  That is harmless while the tensor it belongs to has ordinary magnitudes (the error is relative to the
+// tensor's largest entries, as in any fp32 dot product) and harmful when a WHOLE layer output is tiny -- the next layer then
+// amplifies the absolute error.  Every kernel of the f16 scheme therefore reports the largest |output| of its tensor: one value per
+// wave into a slot array (plain stores, no atomics, no fences), reduced per layer by k_act_check at the end of the forward pass.
+// What "tiny" means is calibrated per layer: the set-up probe of qmri_set_denoiser (f16 kernels against f32-MFMA kernels, end to end)
+// has shown the network accurate with each layer at the magnitude the probe produced, and records those magnitudes; a forward pass
+// raises bit 1 of the range flag when a layer comes out below ACT_LOW AND more than ACT_DROP below its calibrated magnitude -- this
+// image makes the layer collapse where the probe did not.  (Layers that are tiny for every input -- the deep levels of the
+// synthetic bench network sit at 1e-8 -- were already tiny under the probe and are covered by its end-to-end comparison.)
+// The callers answer the bit like the overflow bit: the network is re-packed for the bf16 scheme and the call is repeated.
+constexpr float ACT_LOW = 0x1p-12f;   // 2.4e-4: below it the f16 pieces carry less than fp32's relative accuracy
+constexpr float ACT_DROP = 0x1p-10f;  // ... and this far below the calibrated magnitude of the layer
+constexpr int ACT_MAXSLOT = 1 << 17;  // slots per layer (one per wave of the reporting launch)
+// largest of a wave's non-negative values, as its bit pattern in an SGPR: four DPP steps on the VALU inside each row of 16 lanes
+// (no LDS round trips at the very end of a kernel), then the four rows through v_readlane and scalar max (non-negative floats
+// order like their bit patterns)
+__device__ __forceinline__ unsigned wave_max_bits(float v) {
+    int x = __builtin_bit_cast(int, v);
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));   // row_mirror
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const int c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return (unsigned)max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ void act_report(const ActMax& am, float tmax, int waves_per_block) {
+    if (am.layer < 0) return;
+    tmax = __builtin_bit_cast(float, wave_max_bits(tmax));
+    const int wave = threadIdx.x >> 6;
+    const long slot = (long)blockIdx.x * waves_per_block + wave;
+    if ((threadIdx.x & 63) == 0 && slot < ACT_MAXSLOT) am.slots[(size_t)am.layer * ACT_MAXSLOT + slot] = tmax;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const long n = (long)gridDim.x * waves_per_block;
+        am.count[am.layer] = (int)(n < ACT_MAXSLOT ? n : ACT_MAXSLOT);
+    }
+}
 
 // (Measured and removed: streaming the residual operand into an LDS tile during the last 8 steps of the loop, so that the epilogue
 //  finds it on chip.  The loop is bound by the loader waves (tools/conv6p_stamps.py), so what the epilogue saved the loop lost:
@@ -456,6 +499,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     {
         const bool has1 = A.add1 != nullptr, has2 = A.add2 != nullptr;
         bool bad = false;
+        float tmax = 0.f;
         if (A.vec4) {
             constexpr int NG = 64 * PXT / 4, GQ = NG / NT6;         // float4 groups of the tile; per thread
             static_assert(NG % NT6 == 0 && TH % 4 == 0, "epilogue");
@@ -486,7 +530,11 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
                 if (off[k] != ~0u) store4(A.out + (size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k], x, A.wt);
-                if constexpr (SP == 2) bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);   // (also NaN)
+                if constexpr (SP == 2) {
+                    const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+                    bad |= !(gm <= F16_RANGE);                      // (also NaN)
+                    if (off[k] != ~0u) tmax = fmaxf(tmax, gm);
+                }
             }
         } else {
             constexpr int NE = 64 * PXT, EQ = NE / NT6;             // tile elements; elements per thread
@@ -518,10 +566,13 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 float x = (ot[co * PP + rem] + r1[k]) + r2[k];
                 if (A.relu_out) x = fmaxf(x, 0.f);
                 if (off[k] != ~0u) A.out[(size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]] = x;
-                if constexpr (SP == 2) bad |= !(fabsf(x) <= F16_RANGE);
+                if constexpr (SP == 2) { bad |= !(fabsf(x) <= F16_RANGE); if (off[k] != ~0u) tmax = fmaxf(tmax, fabsf(x)); }
             }
         }
-        if constexpr (SP == 2) { if (bad && A.range_flag) *A.range_flag = 1u; }   // (every writer stores the same value)
+        if constexpr (SP == 2) {
+            if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+            act_report(A.am, tmax, NT6 / 64);
+        }
     }
     C6_STAMP(0, nsteps + 2);
     if constexpr (STAMP) { if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64(); }
@@ -603,6 +654,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
     const int nsteps = 3 * A.nchunk, ntiles = A.ntiles, tstride = gridDim.x;
     int tile = blockIdx.x;
     Tile6 last = tile6<CFG>(A, tile);                               // the tile whose output is in `ot` when the loop ends
+    float tmaxp = 0.f;                                              // largest |output| this thread has stored (ACT_LOW)
 
     if (tid >= NT6 - NLD6) {
         // ------------------------------------------------------------------ loaders
@@ -710,7 +762,11 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
                 if constexpr (NRES > 1) x = x + rr_[q][1];                                                       \
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); } \
                 if (okhw_) bstore4(x, evoff, srdO, usgpr((t_).o + (unsigned)k_ * COSTEP * oplane4));             \
-                bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);  \
+                {                                                                                                \
+                    const float gm_ = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));   \
+                    bad |= !(gm_ <= F16_RANGE);                                                                  \
+                    if (okhw_) tmaxp = fmaxf(tmaxp, gm_);                                                        \
+                }                                                                                                \
             }                                                                                                    \
         }
         // prologue of the first tile, as in k_conv6
@@ -786,7 +842,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 #pragma unroll
             for (int q = 0; q < GPS; ++q) { asm volatile("" : "+v"(rr0[q][0]), "+v"(rr1[q][0]), "+v"(rr2[q][0])); if constexpr (NRES > 1) asm volatile("" : "+v"(rr0[q][1]), "+v"(rr1[q][1]), "+v"(rr2[q][1])); }
         }
-        if (bad && A.range_flag) *A.range_flag = 1u;
+        if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
 #undef PITER
 #undef PLOAD_A
 #undef PSTORE_A
@@ -913,9 +969,12 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
             if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
             if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
-            bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);
+            const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            bad |= !(gm <= F16_RANGE);
+            if (off[k] != ~0u) tmaxp = fmaxf(tmaxp, gm);
         }
-        if (bad && A.range_flag) *A.range_flag = 1u;
+        if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+        act_report(A.am, tmaxp, NT6 / 64);
     }
 }
 
@@ -946,6 +1005,7 @@ struct Conv6sArgs {
     unsigned* range_flag;                 // as in Conv6Args
     float descale_hi, descale_lo;
     int wt;                               // as in Conv6Args
+    ActMax am;                            // as in Conv6Args
 };
 
 template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[3], f32x4 (&b)[2]) {
@@ -1109,25 +1169,32 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         constexpr int NG = OROWS * OPX / 4, GQ = NG / NT6;
         static_assert(NG % NT6 == 0, "epilogue");
         bool bad = false;
+        float tmax = 0.f;
 #pragma unroll
         for (int k = 0; k < GQ; ++k) {
             const int e = k * NT6 + tid;
             const int co = e / (OPX / 4), rem = e - co * (OPX / 4);
             const f32x4 x = *(const f32x4*)(ot + co * PPs + 4 * rem);
-            if constexpr (SP == 2) bad |= !(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) <= F16_RANGE);
+            const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            if constexpr (SP == 2) bad |= !(gm <= F16_RANGE);
             if (KIND == 0) {
                 const int w = rem / (STH / 4), h = 4 * (rem - w * (STH / 4));
                 const int cog = ct * 64 + co, oh = gh0 + h, ow = gw0 + w;
+                if (cog < A.Cout && oh < A.GH && ow < A.GW) tmax = fmaxf(tmax, gm);
                 if (cog < A.Cout && oh < A.GH && ow < A.GW)
                     store4(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1), x, A.wt);
             } else {
                 const int iw = rem / (2 * STH / 4), hh = 4 * (rem - iw * (2 * STH / 4));   // hh = 2*ih + kh
                 const int kw = ct & 1, cog = (ct >> 1) * 32 + co, ih = gh0 + (hh >> 1), iwg = gw0 + iw;
+                if (cog < A.Cout && ih < A.GH && iwg < A.GW) tmax = fmaxf(tmax, gm);
                 if (cog < A.Cout && ih < A.GH && iwg < A.GW)
                     store4(A.out + (size_t)b * A.out_bs + (size_t)cog * A.out_plane + (size_t)(2 * iwg + kw + 1) * A.out_hp + (2 * gh0 + hh + 1), x, A.wt);
             }
         }
-        if constexpr (SP == 2) { if (bad && A.range_flag) *A.range_flag = 1u; }
+        if constexpr (SP == 2) {
+            if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+            act_report(A.am, tmax, NT6 / 64);
+        }
     }
 }
 
@@ -1139,6 +1206,15 @@ template <int CFG> constexpr size_t conv6_lds(int SP) {
 
 template <int CFG> constexpr size_t conv6p_lds() {
     return conv6_lds<CFG>(2) + (size_t)64 * (Cfg6<CFG>::TH * Cfg6<CFG>::TW + 4) * 4;
+}
+
+// where a launch of layer L reports (slot row = the layer's index in the network, so that the rows mean the same for every batch
+// size and tile choice -- with split-K the reduce kernel reports for the layer)
+static ActMax conv6_act_slot(qmri_ctx* ctx, bool reports, const ConvLayer& L) {
+    NetPlan& net = ctx->net;
+    ActMax am{net.d_act_slots, net.d_act_count, -1};
+    if (reports && net.act_on && net.d_act_slots && L.index >= 0 && L.index < net.act_cap) am.layer = L.index;
+    return am;
 }
 
 static std::atomic<int> g_launch_counter{0};     // diagnostic: running number of k_conv6 launches (all configurations, all contexts)
@@ -1162,6 +1238,7 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.vec4 = (in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
               (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp))) ? 1 : 0;
     A.range_flag = ctx->net.d_range_flag;
+    A.am = conv6_act_slot(ctx, SP == 2 && !partial, L);             // (split-K partial sums are reported by k_conv6_reduce)
     static const int wt_stores = getenv("QMRI_CONV_WT") ? atoi(getenv("QMRI_CONV_WT")) : 1;
     A.wt = wt_stores;
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
@@ -1209,6 +1286,7 @@ int launch6p_t(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, cons
     A.ntiles = A.n_ct * A.tiles_h * A.tiles_w * B;
     A.relu_out = relu_out; A.vec4 = 1; A.wt = 1;
     A.range_flag = ctx->net.d_range_flag;
+    A.am = conv6_act_slot(ctx, true, L);
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
     A.stamps = (unsigned long long*)ctx->net.d_stamps; A.launch_idx = g_launch_counter.fetch_add(1, std::memory_order_relaxed);
@@ -1273,22 +1351,51 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
 __global__ __launch_bounds__(256) void k_conv6_reduce(const float* __restrict__ part, int ksplit, long out_ks, float* __restrict__ out,
                                                         const float* __restrict__ add1, const float* __restrict__ add2, long add1_bs,
                                                         long add2_bs, long out_bs, int Cout, int H, int W, int hp, int plane, int relu,
-                                                        long total, unsigned* range_flag) {
+                                                        long total, unsigned* range_flag, ActMax am) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int h = (int)(i % H);
-    long r = i / H;
-    const int w = (int)(r % W); r /= W;
-    const int c = (int)(r % Cout);
-    const long b = r / Cout;
-    const long o = (long)c * plane + (long)(w + 1) * hp + (h + 1);
     float v = 0.f;
-    for (int k = 0; k < ksplit; ++k) v += part[(long)k * out_ks + b * out_bs + o];
-    if (add1) v += add1[b * add1_bs + o];
-    if (add2) v += add2[b * add2_bs + o];
-    if (relu) v = fmaxf(v, 0.f);
-    out[b * out_bs + o] = v;
-    if (range_flag && !(fabsf(v) <= F16_RANGE)) *range_flag = 1u;
+    if (i < total) {                                                // (no early return: act_report shuffles across the whole wave)
+        const int h = (int)(i % H);
+        long r = i / H;
+        const int w = (int)(r % W); r /= W;
+        const int c = (int)(r % Cout);
+        const long b = r / Cout;
+        const long o = (long)c * plane + (long)(w + 1) * hp + (h + 1);
+        for (int k = 0; k < ksplit; ++k) v += part[(long)k * out_ks + b * out_bs + o];
+        if (add1) v += add1[b * add1_bs + o];
+        if (add2) v += add2[b * add2_bs + o];
+        if (relu) v = fmaxf(v, 0.f);
+        out[b * out_bs + o] = v;
+        if (range_flag && !(fabsf(v) <= F16_RANGE)) atomicOr(range_flag, 1u);
+    }
+    act_report(am, fabsf(v), 4);
+}
+
+// end of a forward pass (f16 scheme): per layer, the largest |output| over the slots its kernels reported.  record != 0 (the set-up
+// probe): store it as the layer's calibrated magnitude; else raise bit 1 of the range flag if the layer collapsed (see ACT_LOW).
+// The counts are cleared for the next pass.
+__global__ __launch_bounds__(256) void k_act_check(const float* __restrict__ slots, int* __restrict__ count, float* __restrict__ ref,
+                                                     int record, unsigned* range_flag) {
+    __shared__ float red[4];
+    const int layer = blockIdx.x, n = count[layer];
+    const float* row = slots + (size_t)layer * ACT_MAXSLOT;
+    float m = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 256 * 8) {                       // eight independent loads in flight per thread: one memory latency
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = i0 + threadIdx.x + 256 * q; v[q] = row[(i < n) ? i : 0]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, (i0 + (int)threadIdx.x + 256 * q < n) ? v[q] : 0.f);
+    }
+    m = __builtin_bit_cast(float, wave_max_bits(m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && n > 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (record) ref[layer] = m;
+        else if (m > 0.f && m < ACT_LOW && m < ref[layer] * ACT_DROP) atomicOr(range_flag, 2u);
+        count[layer] = 0;
+    }
 }
 
 inline uint16_t host_bf16(float x) {                               // round to nearest even, as v_cvt_pk_bf16_f32
@@ -1300,6 +1407,44 @@ inline uint16_t host_bf16(float x) {                               // round to n
 inline float host_bf16_to_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
 }  // namespace
+
+// f16 scheme: allocate the |output| slots and the calibrated magnitudes (once per network); reduce the slots after the last layer
+int conv6_act_begin(qmri_ctx* ctx, int nlayers) {
+    NetPlan& net = ctx->net;
+    net.act_on = false;
+    if (net.sp6 != 2) return QMRI_OK;
+    if (!net.d_act_slots) {
+        net.act_cap = nlayers;
+        QMRI_HIP(ctx, hipMalloc((void**)&net.d_act_slots, (size_t)net.act_cap * ACT_MAXSLOT * sizeof(float)));
+        QMRI_HIP(ctx, hipMalloc((void**)&net.d_act_count, (size_t)net.act_cap * sizeof(int)));
+        QMRI_HIP(ctx, hipMalloc((void**)&net.d_act_ref, (size_t)net.act_cap * sizeof(float)));
+        QMRI_HIP(ctx, hipMemsetAsync(net.d_act_count, 0, (size_t)net.act_cap * sizeof(int), ctx->stream));
+        QMRI_HIP(ctx, hipMemsetAsync(net.d_act_ref, 0, (size_t)net.act_cap * sizeof(float), ctx->stream));   // (0: nothing calibrated, nothing trips)
+    }
+    net.act_on = true;
+    return QMRI_OK;
+}
+int conv6_act_end(qmri_ctx* ctx) {
+    NetPlan& net = ctx->net;
+    if (!net.act_on) return QMRI_OK;
+    net.act_on = false;
+    static const bool verbose = getenv("QMRI_ACT_VERBOSE") != nullptr;
+    if (verbose) {                                                  // diagnostic: the per-layer maxima of this forward pass
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int> cnt(net.act_cap);
+        QMRI_HIP(ctx, hipMemcpy(cnt.data(), net.d_act_count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        fprintf(stderr, "libqmri: largest |output| per layer%s:", net.act_record ? " (calibration probe)" : "");
+        for (int l = 0; l < net.act_cap; ++l) {
+            std::vector<float> v(std::max(cnt[l], 1), 0.f);
+            QMRI_HIP(ctx, hipMemcpy(v.data(), net.d_act_slots + (size_t)l * ACT_MAXSLOT, (size_t)cnt[l] * sizeof(float), hipMemcpyDeviceToHost));
+            fprintf(stderr, " %.3g", *std::max_element(v.begin(), v.end()));
+        }
+        fprintf(stderr, "\n");
+    }
+    k_act_check<<<dim3(net.act_cap), dim3(256), 0, ctx->stream>>>(net.d_act_slots, net.d_act_count, net.d_act_ref, net.act_record ? 1 : 0, net.d_range_flag);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
 
 bool conv6_enabled() {
     static const bool on = !(getenv("QMRI_CONV_F32") && atoi(getenv("QMRI_CONV_F32")) > 0);
@@ -1432,6 +1577,7 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
     A.nsteps = L.nchunk6; A.nsteps_real = L.nsteps6s; A.n_ct = L.n_ct6;
     A.range_flag = ctx->net.d_range_flag;
+    A.am = conv6_act_slot(ctx, L.sp6 == 2, L);
     static const int wt_stores = getenv("QMRI_CONV_WT") ? atoi(getenv("QMRI_CONV_WT")) : 1;
     A.wt = wt_stores;
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
@@ -1483,7 +1629,8 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             k_conv6_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(
                 net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.base1(), add1 ? add1->base1() : nullptr, add2 ? add2->base1() : nullptr,
                 add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(),
-                L.Cout, in.H, in.W, out.hp, (int)out.plane(), relu_out, total, (L.sp6 == 2) ? ctx->net.d_range_flag : nullptr);
+                L.Cout, in.H, in.W, out.hp, (int)out.plane(), relu_out, total, (L.sp6 == 2) ? ctx->net.d_range_flag : nullptr,
+                conv6_act_slot(ctx, L.sp6 == 2, L));
             QMRI_HIP(ctx, hipGetLastError());
             return QMRI_OK;
         }

@@ -135,6 +135,7 @@ struct ConvLayer {
     float w6_descale = 1.f;  // f16 scheme: 2^-k of the power-of-two the packed weights carry (conv6_kernels.hip)
     int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks (2x2 layers: K steps), 64-row output tiles of wp6
     int nsteps6s = 0;             // 2x2 layers: K steps that carry weights (nchunk6 is padded to a multiple of 3)
+    int index = -1;               // position in NetPlan::layers (row of the |output| report, conv6_kernels.hip ACT_LOW)
 };
 
 // activation tensor in HBM: [B][Cal][W+2][hp] fp32, h fastest, permanent zero halo, channels >= C are zero.
@@ -168,6 +169,11 @@ struct NetPlan {
     unsigned* d_range_flag = nullptr;   // f16 scheme: raised by a conv kernel whose output leaves the f16-splittable range
     unsigned* h_range_flag = nullptr;   // pinned host copy, refreshed after every forward of the ADMM loop (checked at the loop's next sync point)
     int fallbacks = 0;                  // times a run-time guard moved the network from the f16 to the bf16 scheme since qmri_set_denoiser
+    float* d_act_slots = nullptr;       // f16 scheme: largest |output| per (reporting launch, wave) of the current forward pass (conv6_kernels.hip, ACT_LOW)
+    int* d_act_count = nullptr;         // ... valid slots per reporting launch
+    float* d_act_ref = nullptr;         // ... the magnitude of every layer under the set-up probe (calibrated reference)
+    int act_cap = 0;                    // rows of the three arrays (= layers)
+    bool act_on = false, act_record = false;   // a reporting forward pass is under way; it is the calibration probe
     int sp6 = 2;                     // scheme the layers are packed for
     std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
@@ -284,6 +290,8 @@ int conv_cin_pad(ConvKind kind, int Cin);
 int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop);   // profile level 2: next event pair of the forward (else nullptrs)
 int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv = false, long count = -1);   // count >= 0: only the first `count` pairs are accumulated   // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3 (tv: ms_tv_iter / n_tv_iter)
 bool conv6_enabled();
+int conv6_act_begin(qmri_ctx* ctx, int nlayers);           // f16 scheme: start / finish the per-layer |output| report of a forward pass
+int conv6_act_end(qmri_ctx* ctx);
 int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (QMRI_CONV_SCHEME=bf16x6)
 bool conv6_weights_fit_f16(const float* w, size_t n);
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);

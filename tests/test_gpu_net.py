@@ -238,3 +238,37 @@ def test_denoiser_errors(engine_mod, synth):
     with pytest.raises(engine_mod.QmriError):
         e.set_denoiser(np.zeros(synth.unetres_nparams(), np.float32), 36, 36)   # not divisible by 8
     e.close()
+
+
+def test_low_magnitude_mid_layer_trips_the_guard_and_stays_fp32_accurate(engine_mod, oracle, synth):
+    """The low side of the f16 split: a layer output that is tiny as a whole (here a millionth of what the probe saw, because the layer reads
+    one input channel that is tiny in THIS image -- the calibration probe at qmri_set_denoiser, a uniform random input, does not see
+    it) would be carried with an absolute instead of a relative error and amplified by the next layer.  Every kernel of the f16
+    scheme reports its tensor's largest |output|; k_act_check raises the guard after the forward pass, the call is repeated on the
+    bf16 scheme and the result matches the fp32 oracle to 1e-5.  qmri_denoiser_scheme shows the switch."""
+    H = W = 32
+    width, nb = 32, 4
+    w0 = np.zeros((width, 10, 3, 3), np.float32)
+    for c in range(10):
+        w0[c, c, 1, 1] = 1.0                                        # layer 0: copies the 10 input channels
+    w1 = np.zeros((width, width, 3, 3), np.float32)
+    rng = np.random.default_rng(4)
+    w1[:, 0] = (0.002 * (0.5 + rng.random((width, 3, 3)))).astype(np.float32)   # layer 1: reads channel 0 only (positive weights: no ReLU loss)
+    w2 = (rng.random((width, width, 3, 3)) * 1e4).astype(np.float32)  # layer 2: brings the tensor back up (probe: ~3e4, inside the f16 range)
+    w3 = ((rng.random((10, width, 3, 3)) - 0.3) * 0.01).astype(np.float32)
+    w = np.concatenate([a.ravel() for a in (w0, w1, w2, w3)])
+    x = synth.uniform01(21, H * W * 10).reshape(H, W, 10).copy()
+    x_small = x.copy()
+    x_small[:, :, 0] *= 1e-6                                        # channel 0 tiny in this image; the image's maximum stays ~1
+    net = oracle.Net(w, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, H, W, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1)
+    assert e.denoiser_scheme() == (2, 0)                            # the probe input is ordinary: f16 x 3 products
+    y = e.denoise(x)                                                # ordinary image: stays on the f16 scheme
+    assert rel_err(y, net.denoise(x)) < 1e-5 and e.denoiser_scheme() == (2, 0)
+    ys, yo = e.denoise(x_small), net.denoise(x_small)
+    err = rel_err(ys, yo)
+    print(f"tiny mid-layer tensor: |y| {np.abs(yo).max():.3g}, rel_err {err:.2e}, scheme {e.denoiser_scheme()}")
+    assert np.abs(yo).max() > 1e-4 and err < 1e-5
+    assert e.denoiser_scheme() == (3, 1)                            # the low-magnitude guard moved the network to bf16 x 6, once
+    e.close()
