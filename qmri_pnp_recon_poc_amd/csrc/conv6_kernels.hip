@@ -45,6 +45,16 @@ constexpr int CK = 16;           // input channels per chunk = K of one MFMA
 constexpr int ast6(int SP) { return 3 * 2 * SP * 64; }   // uint4 per step of A: 3 taps x 2 cout tiles x SP splits x 64 lanes
 constexpr float LO_SCALE = 2048.f;    // f16 scheme: the low piece is stored as (x - hi) * 2^11, so it is normal whenever x is
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share one, MI355X_MICROARCH.md), each with its own L2.  Tiles
+// that are neighbours in memory -- the cout tiles of one pixel tile read the same activations, vertically adjacent pixel tiles share
+// their halo rows' 128-byte lines -- are consecutive in tile order, so the default order puts them on eight different L2s: measured
+// 28.3 MB fetched per 224 x 224 layer for 16.3 MB of input (rocprofv3 FETCH_SIZE).  The remap gives every XCD one contiguous range
+// of tiles (bijective for any n; placement only ever changes speed).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, idx = id >> 3;
+    return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 struct ActMax { float* slots; int* count; int layer; };   // where a launch reports its largest |output| (see ACT_LOW); layer < 0: it does not
 
 struct Conv6Args {
@@ -55,6 +65,7 @@ struct Conv6Args {
     int nchunk, n_ct, tiles_h, tiles_w, relu_out;
     int vec4;                     // epilogue may use aligned float4 accesses (H % 4 == 0 and line-aligned tensors)
     int wt;                       // write-through (sc1) output stores, see store4()
+    int xcd;                      // XCD-aware tile order, see xcd_remap()
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int ntiles;                   // k_conv6p: tiles of the launch (n_ct * tiles_h * tiles_w * B)
@@ -263,7 +274,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     float* ot = (SP == 3) ? (float*)Bbuf : (float*)smem;
     static_assert(SP == 3 ? (64 * PP * 4 <= 2 * 3 * 2 * NPX * 16) : (64 * PP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "output tile must fit the operand buffers");
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
     const int th = bid % A.tiles_h; bid /= A.tiles_h;
     const int tw = bid % A.tiles_w; bid /= A.tiles_w;
@@ -605,6 +616,7 @@ struct Tile6 { int ct, oh0, ow0, b; };
 
 template <int CFG> __device__ __forceinline__ Tile6 tile6(const Conv6Args& A, int t) {
     Tile6 r;
+    if (A.xcd) t = xcd_remap(t, A.ntiles);                          // (a workgroup's tiles t, t + gridDim.x, ... share t % 8: gridDim.x % 8 == 0 or gridDim.x == ntiles)
     r.ct = t % A.n_ct; t /= A.n_ct;
     const int th = t % A.tiles_h; t /= A.tiles_h;
     const int tw = t % A.tiles_w;
@@ -1241,6 +1253,8 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.am = conv6_act_slot(ctx, SP == 2 && !partial, L);             // (split-K partial sums are reported by k_conv6_reduce)
     static const int wt_stores = getenv("QMRI_CONV_WT") ? atoi(getenv("QMRI_CONV_WT")) : 1;
     A.wt = wt_stores;
+    static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
+    A.xcd = xcd_order;
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.stamps = (unsigned long long*)ctx->net.d_stamps;
     static const int stamp_launch = getenv("QMRI_CONV_STAMP_LAUNCH") ? atoi(getenv("QMRI_CONV_STAMP_LAUNCH")) : -1;
@@ -1285,6 +1299,8 @@ int launch6p_t(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, cons
     A.tiles_h = (in.H + C::TH - 1) / C::TH; A.tiles_w = (in.W + C::TW - 1) / C::TW;
     A.ntiles = A.n_ct * A.tiles_h * A.tiles_w * B;
     A.relu_out = relu_out; A.vec4 = 1; A.wt = 1;
+    static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
+    A.xcd = xcd_order;
     A.range_flag = ctx->net.d_range_flag;
     A.am = conv6_act_slot(ctx, true, L);
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of the dominant kernel (k_conv6 at the 224 x 224 x 64 level) from two SEPARATE rocprofv3 --pmc passes
+(FETCH_SIZE in one, WRITE_SIZE in the other -- they do not fit one pass, MI355X_MICROARCH.md section rocprofv3 PMC slots), corrected as
+that guide's HBM section prescribes, written to profiles/conv_traffic.json (which bench.py reports as roofline.traffic).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_net.py 1 3
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_net.py 1 3
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [profiles/rNN_pmc_conv_traffic.txt]
+
+Corrections.  FETCH_SIZE / WRITE_SIZE are in KB (x 1024).  On gfx950 FETCH_SIZE counts a 16-byte-per-lane coalesced read at exactly half
+its bytes; WRITE_SIZE is exact for 16-byte-per-lane stores.  In k_conv6 the residual operand (global_load_dwordx4) and the weight
+copies (buffer_load_dwordx4) are 16 B per lane, the activation requests are 4 B per lane (a width the guide leaves uncalibrated: taken
+as counted).  The residual share is MEASURED, not assumed: the launches of one forward pass alternate between layers without and with
+a residual operand, the two populations separate cleanly in FETCH_SIZE, and their difference is the residual read as counted (half
+its bytes), so   corrected FETCH(residual layer) = FETCH(plain layer) + 2 x (FETCH(residual layer) - FETCH(plain layer)).
+The weights (147 KB per layer, read through L2 once per XCD) are below the resolution of this and left as counted."""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALG = {"input_with_halo": 196 * 64 * 18 * 18 * 4, "residual": 64 * 224 * 224 * 4, "output": 64 * 224 * 224 * 4, "weights_f16_pairs": 64 * 64 * 9 * 4}
+
+
+def rows(d, counter):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])))
+    return sorted(out)
+
+
+def main():
+    dfetch, dwrite = sys.argv[1], sys.argv[2]
+    sel = lambda rs: [v for (_, n, g, v) in rs if "k_conv6<0, 2" in n and g == 196 * 512]
+    f, w = sel(rows(dfetch, "FETCH_SIZE")), sel(rows(dwrite, "WRITE_SIZE"))
+    if not f or not w:
+        raise SystemExit("no k_conv6<0, 2> launches with 196 workgroups found in the counter files")
+    f.sort()
+    # populations (separated by > 15 % gaps): the head layer (10 input channels), plain layers (input + weights), residual layers
+    # (+ the residual operand), the level's last layer (+ residual + skip).  plain = the most populous, residual = the next larger one
+    clusters = [[f[0]]]
+    for v in f[1:]:
+        if v > 1.15 * clusters[-1][-1]: clusters.append([v])
+        else: clusters[-1].append(v)
+    ip = max(range(len(clusters)), key=lambda i: len(clusters[i]))
+    if ip + 1 >= len(clusters):
+        raise SystemExit("could not separate plain and residual launches: " + str([(len(c), c[0]) for c in clusters]))
+    plain, res = clusters[ip], clusters[ip + 1]
+    med = lambda a: sorted(a)[len(a) // 2]
+    fp, fr, wm = med(plain) * 1024, med(res) * 1024, med(w) * 1024
+    res_counted = fr - fp
+    corr_plain, corr_res = fp, fp + 2 * res_counted
+    n_p, n_r = len(plain), len(res)
+    mean_corr = (n_p * (corr_plain + wm) + n_r * (corr_res + wm)) / (n_p + n_r)
+    mean_raw = (n_p * (fp + wm) + n_r * (fr + wm)) / (n_p + n_r)
+    alg_plain = ALG["input_with_halo"] + ALG["output"] + ALG["weights_f16_pairs"]
+    alg_res = alg_plain + ALG["residual"]
+    out = {"kernel": "k_conv6<0, 2> (224 x 224 x 64 level, 196 workgroups)", "launches": {"plain": n_p, "residual": n_r},
+           "raw": {"fetch_plain_bytes": int(fp), "fetch_residual_bytes": int(fr), "write_bytes": int(wm)},
+           "corrected": {"fetch_plain_bytes": int(corr_plain), "fetch_residual_bytes": int(corr_res), "write_bytes": int(wm),
+                         "residual_read_as_counted": int(res_counted), "residual_read_true": ALG["residual"]},
+           "algorithmic": {"plain_layer_bytes": alg_plain, "residual_layer_bytes": alg_res, **ALG},
+           "ratio_corrected_over_algorithmic": {"plain": round((corr_plain + wm) / alg_plain, 3), "residual": round((corr_res + wm) / alg_res, 3)},
+           "raw_bytes_per_launch_per_slice": int(mean_raw), "corrected_bytes_per_launch_per_slice": int(mean_corr),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/prof_net.py 1 3; tools/pmc_traffic.py; "
+                     "FETCH x2 on the 16-B-per-lane residual reads (measured share), 4-B-per-lane activation reads as counted"}
+    with open(os.path.join(ROOT, "profiles", "conv_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    txt = json.dumps(out, indent=1)
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as fh:
+            fh.write(txt + "\n")
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()
