@@ -77,6 +77,11 @@ int qmri_operator_m(const qmri_ctx* ctx, int* m_out);
 int qmri_forward(qmri_ctx* ctx, const void* x, int x_is_complex, void* y);
 /* x = F.adjoint(y): y m complex -> x N*M*s complex. */
 int qmri_adjoint(qmri_ctx* ctx, const void* y, void* x);
+/* The same two maps for MATLAB `single` arrays (interleaved complex floats at the boundary; x real if !x_is_complex).  The arithmetic
+ * stays complex double as in the reference's F (fft2 of a single array would be single in MATLAB: these entry points are at least as
+ * accurate); results are rounded to single once, on the way out. */
+int qmri_forward_f32(qmri_ctx* ctx, const float* x, int x_is_complex, float* y);
+int qmri_adjoint_f32(qmri_ctx* ctx, const float* y, float* x);
 /* device-resident variants, `batch` slices stored back to back */
 int qmri_forward_dev(qmri_ctx* ctx, const void* d_x, void* d_y, int batch);
 int qmri_adjoint_dev(qmri_ctx* ctx, const void* d_y, void* d_x, int batch);
@@ -185,6 +190,10 @@ int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap,
  * qmap: Npix x 3 doubles column-major (T1, T2, PD, in the units of dict.lut); X_out: Npix x s singles column-major;
  * idx_out (nullable): the 1-based nearest entry.  Uses the dictionary of qmri_set_dictionary (Q >= 2). */
 int qmri_synthesize_tsmi(qmri_ctx* ctx, const double* qmap, int Npix, float* X_out, int32_t* idx_out);
+/* mode 'complex' of the same script (main_synthesize_tsmis.m:27,100-103): X = real(dict.D(I,:)) .* dict.normD(I) .* qm(:,3) with a complex
+ * PD, no abs and no sign alignment, stored as cat(3, real(X), imag(X)).  qmap: Npix x 3 (T1, T2, real(PD)); pd_imag: Npix or NULL
+ * (imaginary part of PD); X_out: Npix x 2s singles column-major (the s real channels, then the s imaginary ones). */
+int qmri_synthesize_tsmi_complex(qmri_ctx* ctx, const double* qmap, const double* pd_imag, int Npix, float* X_out, int32_t* idx_out);
 
 /* ---- slice batches over several GPUs of one node (slices are independent; no collective) ------------ */
 typedef struct {

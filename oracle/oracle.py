@@ -88,6 +88,7 @@ def lib():
         L.orc_norm_tv.argtypes = [dp, C.c_int, C.c_int]
         L.orc_prox_tv.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp]
         L.orc_synthesize_tsmi.argtypes = [dp, C.c_int, fp, fp, fp, C.c_int, C.c_int, fp, ip]
+        L.orc_synthesize_tsmi_complex.argtypes = [dp, dp, C.c_int, fp, fp, fp, C.c_int, C.c_int, fp, ip]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(usable_cpus())
@@ -326,19 +327,27 @@ def fista_lrtv(op: Operator, y, K=4e-5, iters=200, step=None, tol=1e-4, backtrac
     return x, {"iters": it, "obj": np.array(objs), "prox_iters": np.array(pits, np.int32), "step": step, "halvings": halv}
 
 
-def synthesize_tsmi(qmap, D, normD, lut):
-    """main_synthesize_tsmis.m:82-100 (mode 'real'): qmap [..., 3] (T1, T2, PD) -> (X [..., s] float32, idx 1-based int32)."""
-    qmap = np.asarray(qmap, dtype=np.float64)
+def synthesize_tsmi(qmap, D, normD, lut, mode="real"):
+    """main_synthesize_tsmis.m:82-103: qmap [..., 3] (T1, T2, PD) -> (X float32, idx 1-based int32).  mode 'real': X [..., s];
+    mode 'complex' (PD may be complex): X [..., 2s] = real parts of the s channels, then the imaginary parts."""
+    qmap = np.asarray(qmap)
+    if mode == "real" and np.iscomplexobj(qmap):
+        qmap = np.concatenate([qmap[..., :2].real, np.abs(qmap[..., 2:3])], axis=-1)
     shp = qmap.shape[:-1]
-    q = np.asfortranarray(qmap.reshape(-1, 3, order="F"))
+    pim = np.ascontiguousarray(qmap[..., 2].imag.reshape(-1, order="F"), dtype=np.float64) if np.iscomplexobj(qmap) else None
+    q = np.asfortranarray(np.asarray(qmap.real, dtype=np.float64).reshape(-1, 3, order="F"))
     D = np.asfortranarray(D, dtype=np.float32)
     lut = np.asfortranarray(lut, dtype=np.float32)
     nd = np.ascontiguousarray(normD, dtype=np.float32).ravel()
     K, s = D.shape
-    X = np.empty((q.shape[0], s), np.float32, order="F")
+    nch = s if mode == "real" else 2 * s
+    X = np.empty((q.shape[0], nch), np.float32, order="F")
     idx = np.empty(q.shape[0], np.int32)
-    lib().orc_synthesize_tsmi(_dp(q), q.shape[0], _fp(D), _fp(nd), _fp(lut), K, s, _fp(X), _ip(idx))
-    return X.reshape(shp + (s,), order="F"), idx.reshape(shp, order="F")
+    if mode == "real":
+        lib().orc_synthesize_tsmi(_dp(q), q.shape[0], _fp(D), _fp(nd), _fp(lut), K, s, _fp(X), _ip(idx))
+    else:
+        lib().orc_synthesize_tsmi_complex(_dp(q), _dp(pim), q.shape[0], _fp(D), _fp(nd), _fp(lut), K, s, _fp(X), _ip(idx))
+    return X.reshape(shp + (nch,), order="F"), idx.reshape(shp, order="F")
 
 
 def dict_match(X, D, normD, lut, block_size=1e9, want_mt=True, want_dm=True, want_xfit=False):

@@ -112,3 +112,27 @@ void orc_synthesize_tsmi(const double* qmap, int Npix, const float* D, const flo
         for (int c = 0; c < s; ++c) X[(size_t)c * Npix + p] = D[(size_t)K * c + bi] * nd * pd * sg;
     }
 }
+
+/* mode 'complex' of main_synthesize_tsmis.m:100-103: X = (real(D(I,:)) .* normD(I)) .* qm(:,3), PD complex, no abs, no sign alignment;
+ * stored as cat(3, real(X), imag(X)): X is Npix x 2s.  pd_imag may be NULL (real PD: the imaginary channels are zero). */
+void orc_synthesize_tsmi_complex(const double* qmap, const double* pd_imag, int Npix, const float* D, const float* normD, const float* lut,
+                                 int K, int s, float* X, int32_t* idx) {
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < Npix; ++p) {
+        const double q1 = qmap[p], q2 = qmap[(size_t)Npix + p];
+        double best = INFINITY;
+        int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const double d1 = q1 - (double)lut[k], d2 = q2 - (double)lut[(size_t)K + k];
+            const double d = d1 * d1 + d2 * d2;
+            if (d < best) { best = d; bi = k; }
+        }
+        if (idx) idx[p] = bi + 1;
+        const float nd = normD[bi], pr = (float)qmap[(size_t)2 * Npix + p], pi = pd_imag ? (float)pd_imag[p] : 0.f;
+        for (int c = 0; c < s; ++c) {
+            const float base = D[(size_t)K * c + bi] * nd;
+            X[(size_t)c * Npix + p] = base * pr;
+            X[(size_t)(s + c) * Npix + p] = base * pi;
+        }
+    }
+}

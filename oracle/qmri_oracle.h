@@ -116,6 +116,10 @@ int orc_prox_tv(const double* b, int R, int C, double gamma, double tol, int max
 void orc_synthesize_tsmi(const double* qmap, int Npix, const float* D, const float* normD, const float* lut, int K, int s,
                          float* X, int32_t* idx);
 
+/* mode 'complex' (:100-103): PD complex (pd_imag nullable), X: Npix x 2s (real channels, then imaginary channels). */
+void orc_synthesize_tsmi_complex(const double* qmap, const double* pd_imag, int Npix, const float* D, const float* normD, const float* lut,
+                                 int K, int s, float* X, int32_t* idx);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

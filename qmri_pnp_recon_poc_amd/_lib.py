@@ -18,11 +18,11 @@ CSRC = os.path.join(_PKG, "csrc")
 SYMBOLS = [
     "qmri_abi_version", "qmri_create", "qmri_destroy", "qmri_last_error", "qmri_set_stream", "qmri_synchronize",
     "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
-    "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
+    "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_onnx_read_unetres",
-    "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi",
+    "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi", "qmri_synthesize_tsmi_complex",
 ]
 
 
@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
     L.qmri_operator_m.argtypes = [vp, C.POINTER(i)]
     L.qmri_forward.argtypes = [vp, vp, i, vp]
     L.qmri_adjoint.argtypes = [vp, vp, vp]
+    L.qmri_forward_f32.argtypes = [vp, fp, i, fp]
+    L.qmri_adjoint_f32.argtypes = [vp, fp, fp]
     L.qmri_forward_dev.argtypes = [vp, vp, vp, i]
     L.qmri_adjoint_dev.argtypes = [vp, vp, vp, i]
     L.qmri_xupdate.argtypes = [vp, vp, vp, C.c_double, C.c_double, i, i, vp, ip, ip]
@@ -119,6 +121,7 @@ def lib() -> C.CDLL:
     L.qmri_prox_tv.argtypes = [vp, dp, i, i, C.c_double, C.c_double, i, dp, ip, dp]
     L.qmri_norm_tv.argtypes = [vp, dp, i, i, dp]
     L.qmri_synthesize_tsmi.argtypes = [vp, dp, i, fp, ip]
+    L.qmri_synthesize_tsmi_complex.argtypes = [vp, dp, dp, i, fp, ip]
     L.qmri_set_dictionary.argtypes = [vp, i, i, i, fp, fp, fp]
     L.qmri_dict_match.argtypes = [vp, vp, i, fp, fp, fp, ip]
     L.qmri_dict_match_dev.argtypes = [vp, vp, i, vp, vp, vp, vp]

@@ -446,6 +446,29 @@ extern "C" int qmri_adjoint(qmri_ctx* ctx, const void* y, void* x) {
     return QMRI_OK;
 }
 
+// single-precision boundary (MATLAB `single` arrays): widened on the host, computed in double, rounded once on the way out
+extern "C" int qmri_forward_f32(qmri_ctx* ctx, const float* x, int x_is_complex, float* y) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, x && y, "x / y must not be NULL");
+    const OpHost& o = ctx->op;
+    const size_t n = (size_t)o.N * o.M * o.s * (x_is_complex ? 2 : 1);
+    std::vector<double> xd(x, x + n), yd((size_t)2 * o.m);
+    QMRI_TRY(qmri_forward(ctx, xd.data(), x_is_complex, yd.data()));
+    for (size_t i = 0; i < yd.size(); ++i) y[i] = (float)yd[i];
+    return QMRI_OK;
+}
+
+extern "C" int qmri_adjoint_f32(qmri_ctx* ctx, const float* y, float* x) {
+    REQUIRE_OP(ctx);
+    QMRI_CHECK_ARG(ctx, x && y, "x / y must not be NULL");
+    const OpHost& o = ctx->op;
+    const size_t n2 = (size_t)2 * o.N * o.M * o.s;
+    std::vector<double> yd(y, y + (size_t)2 * o.m), xd(n2);
+    QMRI_TRY(qmri_adjoint(ctx, yd.data(), xd.data()));
+    for (size_t i = 0; i < n2; ++i) x[i] = (float)xd[i];
+    return QMRI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // x-update drivers
 // ---------------------------------------------------------------------------------------------------

@@ -1016,7 +1016,7 @@ struct Conv6sArgs {
     int nsteps_real;                      // carry zero weights and repeat the last step's activations
     unsigned* range_flag;                 // as in Conv6Args
     float descale_hi, descale_lo;
-    int wt;                               // as in Conv6Args
+    int wt, xcd;                          // as in Conv6Args
     ActMax am;                            // as in Conv6Args
 };
 
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
     float* ot = (SP == 3) ? (float*)Bbuf : (float*)smem;            // (SP == 2: aliases A too; the last stores into A precede the loop's last barrier)
     static_assert(SP == 3 ? (OROWS * PPs * 4 <= 2 * BSTEP * 4) : (OROWS * PPs * 4 <= 2 * ASTS * 16 + 2 * BSTEP * 4), "output tile must fit the operand buffers");
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;   // (the cout tiles of a pixel tile read the same activations: one L2)
     const int ct = bid % A.n_ct; bid /= A.n_ct;
     const int th = bid % A.tiles_h; bid /= A.tiles_h;
     const int tw = bid % A.tiles_w;
@@ -1596,6 +1596,8 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     A.am = conv6_act_slot(ctx, L.sp6 == 2, L);
     static const int wt_stores = getenv("QMRI_CONV_WT") ? atoi(getenv("QMRI_CONV_WT")) : 1;
     A.wt = wt_stores;
+    static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
+    A.xcd = xcd_order;
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.tiles_h = (A.GH + STH - 1) / STH; A.tiles_w = (A.GW + STW - 1) / STW;
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;

@@ -79,9 +79,36 @@ __global__ __launch_bounds__(256) void k_synth_tsmi(const double* __restrict__ q
     for (int c = 0; c < s; ++c) X[(size_t)c * Npix + p] = atom(c) * nd * pd * sg;
 }
 
+// mode 'complex' (main_synthesize_tsmis.m:100-103): X = (D .* normD) .* PD with PD complex, no abs and no sign alignment;
+// the output stacks the real parts of the s channels and then their imaginary parts (cat(3, real(X), imag(X)): 2s channels)
+__global__ __launch_bounds__(256) void k_synth_tsmi_complex(const double* __restrict__ qmap, const double* __restrict__ pd_imag, int Npix,
+                                                             const int32_t* __restrict__ idx, const float* __restrict__ pack,
+                                                             const float* __restrict__ normD, int s, float* __restrict__ X) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Npix) return;
+    const int a = idx[p] - 1;
+    const int npair = (s + 1) / 2, t = a >> 5;
+    const float nd = normD[a], pr = (float)qmap[(size_t)2 * Npix + p], pi = pd_imag ? (float)pd_imag[p] : 0.f;
+    for (int c = 0; c < s; ++c) {
+        const float base = pack[((size_t)t * npair + (c >> 1)) * 64 + (a & 31) + 32 * (c & 1)] * nd;
+        X[(size_t)c * Npix + p] = base * pr;
+        X[(size_t)(s + c) * Npix + p] = base * pi;
+    }
+}
+
 }  // namespace
 
+static int synthesize_impl(qmri_ctx* ctx, const double* qmap, const double* pd_imag, int complex_mode, int Npix, float* X_out, int32_t* idx_out);
+
 extern "C" int qmri_synthesize_tsmi(qmri_ctx* ctx, const double* qmap, int Npix, float* X_out, int32_t* idx_out) {
+    return synthesize_impl(ctx, qmap, nullptr, 0, Npix, X_out, idx_out);
+}
+
+extern "C" int qmri_synthesize_tsmi_complex(qmri_ctx* ctx, const double* qmap, const double* pd_imag, int Npix, float* X_out, int32_t* idx_out) {
+    return synthesize_impl(ctx, qmap, pd_imag, 1, Npix, X_out, idx_out);
+}
+
+static int synthesize_impl(qmri_ctx* ctx, const double* qmap, const double* pd_imag, int complex_mode, int Npix, float* X_out, int32_t* idx_out) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
     DictHost& d = ctx->dict;
@@ -89,7 +116,8 @@ extern "C" int qmri_synthesize_tsmi(qmri_ctx* ctx, const double* qmap, int Npix,
     QMRI_CHECK_ARG(ctx, qmap && X_out && Npix > 0, "qmri_synthesize_tsmi: qmap / X_out NULL or Npix <= 0");
     if (d.Q < 2) { qmri_set_error(ctx, "the look-up table needs T1 and T2 columns (Q >= 2)"); return QMRI_ERR_UNSUPPORTED; }
     double* d_q = nullptr; float* d_X = nullptr; int32_t* d_i = nullptr;
-    double* d_pd = nullptr; int32_t* d_pi = nullptr;
+    double* d_pd = nullptr; int32_t* d_pi = nullptr; double* d_im = nullptr;
+    const int nch = complex_mode ? 2 * d.s : d.s;                   // output channels
     const int nbx = (Npix + NNT * NN_PPT - 1) / (NNT * NN_PPT);
     int nslice = std::max(1, std::min(NN_KSPLIT_TARGET / std::max(nbx, 1), (d.K + NN_TILE - 1) / NN_TILE));
     const int kslice = (((d.K + nslice - 1) / nslice) + NN_TILE - 1) / NN_TILE * NN_TILE;     // whole tiles per slice
@@ -97,15 +125,18 @@ extern "C" int qmri_synthesize_tsmi(qmri_ctx* ctx, const double* qmap, int Npix,
     int st = QMRI_OK;
     auto fail = [&](const char* what) { qmri_set_error(ctx, "qmri_synthesize_tsmi: %s", what); st = QMRI_ERR_HIP; };
     do {
-        if (hipMalloc((void**)&d_q, (size_t)3 * Npix * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_X, (size_t)d.s * Npix * sizeof(float)) != hipSuccess ||
+        if (hipMalloc((void**)&d_q, (size_t)3 * Npix * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_X, (size_t)nch * Npix * sizeof(float)) != hipSuccess ||
+            (pd_imag && hipMalloc((void**)&d_im, (size_t)Npix * sizeof(double)) != hipSuccess) ||
             hipMalloc((void**)&d_i, (size_t)Npix * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&d_pd, (size_t)nslice * Npix * sizeof(double)) != hipSuccess ||
             hipMalloc((void**)&d_pi, (size_t)nslice * Npix * sizeof(int32_t)) != hipSuccess) { fail("hipMalloc"); st = QMRI_ERR_NOMEM; break; }
         if (hipMemcpyAsync(d_q, qmap, (size_t)3 * Npix * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
+        if (pd_imag && hipMemcpyAsync(d_im, pd_imag, (size_t)Npix * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
         k_nn_lut<<<dim3(nbx, nslice), dim3(NNT), 0, ctx->stream>>>(d_q, Npix, d.d_lut, d.K, kslice, d_pd, d_pi);
         k_nn_combine<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_pd, d_pi, Npix, nslice, d_i);
-        k_synth_tsmi<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, Npix, d_i, d.d_pack, d.d_normD, d.s, d_X);
+        if (complex_mode) k_synth_tsmi_complex<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, d_im, Npix, d_i, d.d_pack, d.d_normD, d.s, d_X);
+        else k_synth_tsmi<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, Npix, d_i, d.d_pack, d.d_normD, d.s, d_X);
         if (hipGetLastError() != hipSuccess) { fail("kernel launch"); break; }
-        if (hipMemcpyAsync(X_out, d_X, (size_t)d.s * Npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        if (hipMemcpyAsync(X_out, d_X, (size_t)nch * Npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (idx_out && hipMemcpyAsync(idx_out, d_i, (size_t)Npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { fail("synchronize"); break; }
     } while (0);
@@ -114,5 +145,6 @@ extern "C" int qmri_synthesize_tsmi(qmri_ctx* ctx, const double* qmap, int Npix,
     if (d_i) (void)hipFree(d_i);
     if (d_pd) (void)hipFree(d_pd);
     if (d_pi) (void)hipFree(d_pi);
+    if (d_im) (void)hipFree(d_im);
     return st;
 }

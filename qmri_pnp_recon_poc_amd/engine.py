@@ -138,10 +138,18 @@ class Engine:
         self.N, self.M, self.s, self.T, self.m = int(N), int(M), int(s), int(T), int(fp[-1])
 
     def forward(self, x):
-        """y = F.forward(x)  (main_recon_tsmis_FFT.m:228).  x: [N,M,s] real or complex."""
+        """y = F.forward(x)  (main_recon_tsmis_FFT.m:228).  x: [N,M,s] real or complex; single-precision input (float32 /
+        complex64, a MATLAB `single` array) goes through the _f32 entry point and comes back as complex64."""
         x = np.asarray(x)
         if x.shape != (self.N, self.M, self.s):
             raise ValueError(f"x must be {self.N}x{self.M}x{self.s}")
+        if x.dtype in (np.float32, np.complex64):
+            cx = np.iscomplexobj(x)
+            xb = np.ascontiguousarray(x.ravel(order="F"))
+            y = np.empty(self.m, np.complex64)
+            fp = C.POINTER(C.c_float)
+            self._check(self.L.qmri_forward_f32(self.h, xb.view(np.float32).ctypes.data_as(fp), int(cx), y.view(np.float32).ctypes.data_as(fp)))
+            return y
         y = np.empty(self.m, np.complex128)
         if np.iscomplexobj(x):
             xb = _cbuf(x)
@@ -152,7 +160,15 @@ class Engine:
         return y
 
     def adjoint(self, y):
-        """x = F.adjoint(y)  (main_recon_tsmis_FFT.m:229)."""
+        """x = F.adjoint(y)  (main_recon_tsmis_FFT.m:229); complex64 in -> complex64 out (the _f32 entry point)."""
+        if np.asarray(y).dtype == np.complex64:
+            y32 = np.ascontiguousarray(np.asarray(y).ravel(order="F"))
+            if y32.size != self.m:
+                raise ValueError(f"y must have {self.m} elements")
+            x = np.empty(self.N * self.M * self.s, np.complex64)
+            fp = C.POINTER(C.c_float)
+            self._check(self.L.qmri_adjoint_f32(self.h, y32.view(np.float32).ctypes.data_as(fp), x.view(np.float32).ctypes.data_as(fp)))
+            return x.reshape((self.N, self.M, self.s), order="F")
         yb = _cbuf(y)
         if yb.size != self.m:
             raise ValueError(f"y must have {self.m} elements")
@@ -233,22 +249,34 @@ class Engine:
         self._check(self.L.qmri_set_dictionary(self.h, K, s, Q, Df.ctypes.data_as(f), nd.ctypes.data_as(f), lf.ctypes.data_as(f)))
         self.dict_shape = (K, s, Q)
 
-    def synthesize_tsmi(self, qmap):
-        """TSMI of a quantitative map (main_synthesize_tsmis.m:82-100, mode 'real'): qmap [..., 3] (T1, T2, PD) ->
-        (X [..., s] float32, idx [...] 1-based nearest dictionary entry).  Needs set_dictionary."""
-        qmap = np.asarray(qmap, dtype=np.float64)
+    def synthesize_tsmi(self, qmap, mode="real"):
+        """TSMI of a quantitative map (main_synthesize_tsmis.m:82-103): qmap [..., 3] (T1, T2, PD) ->
+        (X, idx [...] 1-based nearest dictionary entry).  mode 'real' (:91-98): X [..., s] float32, |PD| and the sign of channel 1
+        folded in; mode 'complex' (:100-103): PD may be complex, X [..., 2s] = the real parts of the s channels, then the imaginary
+        ones.  Needs set_dictionary."""
+        if mode not in ("real", "complex"):
+            raise ValueError("mode must be 'real' or 'complex'")
+        qmap = np.asarray(qmap)
         if qmap.shape[-1] != 3:
             raise ValueError("qmap must have T1, T2, PD along its last dimension")
         if getattr(self, "dict_shape", None) is None:
             raise ValueError("dictionary not set")
+        if mode == "real" and np.iscomplexobj(qmap):
+            qmap = np.concatenate([qmap[..., :2].real, np.abs(qmap[..., 2:3])], axis=-1)     # abs(qm(:,3)), :92
         shp = qmap.shape[:-1]
-        q = np.ascontiguousarray(qmap.reshape(-1, 3, order="F").ravel(order="F"))
+        pd_im = np.ascontiguousarray(qmap[..., 2].imag.reshape(-1, order="F"), dtype=np.float64) if np.iscomplexobj(qmap) else None
+        q = np.ascontiguousarray(np.asarray(qmap.real, dtype=np.float64).reshape(-1, 3, order="F").ravel(order="F"))
         npix, s = q.size // 3, self.dict_shape[1]
-        X = np.empty(npix * s, np.float32)
+        nch = s if mode == "real" else 2 * s
+        X = np.empty(npix * nch, np.float32)
         idx = np.empty(npix, np.int32)
-        self._check(self.L.qmri_synthesize_tsmi(self.h, q.ctypes.data_as(C.POINTER(C.c_double)), npix, X.ctypes.data_as(C.POINTER(C.c_float)),
-                                                idx.ctypes.data_as(C.POINTER(C.c_int32))))
-        return X.reshape(shp + (s,), order="F"), idx.reshape(shp, order="F")
+        dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        if mode == "real":
+            self._check(self.L.qmri_synthesize_tsmi(self.h, q.ctypes.data_as(dp), npix, X.ctypes.data_as(fp), idx.ctypes.data_as(ip)))
+        else:
+            self._check(self.L.qmri_synthesize_tsmi_complex(self.h, q.ctypes.data_as(dp), pd_im.ctypes.data_as(dp) if pd_im is not None else None,
+                                                            npix, X.ctypes.data_as(fp), idx.ctypes.data_as(ip)))
+        return X.reshape(shp + (nch,), order="F"), idx.reshape(shp, order="F")
 
     # -- LRTV option ---------------------------------------------------------------------------------
     def lrtv(self, y, K=4e-5, iters=200, step=None, tol=1e-4, backtrack=True, prox_tol=None, prox_maxit=None):

@@ -176,16 +176,18 @@ def metrics(qmap, qmap0, foreground_mask, X=None, X0=None):
     return out
 
 
-def synthesize_tsmis(qmap, dictionary, device=0):
-    """main_synthesize_tsmis.m:76-100 (mode 'real') for one volume: qmap slices x 3 x N x M (the file layout, :180) ->
-    X slices x N x M x s single, first SVD channel non-negative.  Runs on the GPU (exhaustive nearest-entry search)."""
+def synthesize_tsmis(qmap, dictionary, device=0, mode="real"):
+    """main_synthesize_tsmis.m:76-103 for one volume: qmap slices x 3 x N x M (the file layout, :180) -> X slices x N x M x C single.
+    mode 'real' (:27,91-98): C = s, |PD| folded in, first SVD channel non-negative; mode 'complex' (:100-103): PD may be complex,
+    C = 2s (real parts of the s channels, then the imaginary parts).  Runs on the GPU (exhaustive nearest-entry search)."""
     from . import reference_api as R
-    q = np.asarray(qmap, dtype=np.float64)
+    q = np.asarray(qmap)
+    q = q.astype(np.complex128 if np.iscomplexobj(q) else np.float64)
     if q.ndim != 4 or q.shape[1] != 3:
         raise ValueError("qmap must be slices x 3 x N x M")
     eng = R._engine(device)
     eng.set_dictionary(dictionary["D"], dictionary["normD"], dictionary["lut"])
-    return np.stack([eng.synthesize_tsmi(np.transpose(q[i], (1, 2, 0)))[0] for i in range(q.shape[0])])
+    return np.stack([eng.synthesize_tsmi(np.transpose(q[i], (1, 2, 0)), mode=mode)[0] for i in range(q.shape[0])])
 
 
 def training_volume(X_slices, channels_to_save=None):

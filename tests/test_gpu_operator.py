@@ -39,6 +39,20 @@ def test_forward_adjoint_vs_oracle(eng, case224):
     assert abs(lhs - rhs) / abs(lhs) < 1e-12
 
 
+def test_single_precision_boundary(eng, case224):
+    """qmri_forward_f32 / qmri_adjoint_f32 (MATLAB `single` arrays at the boundary): computed in double, rounded once."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((224, 224, 10)) + 1j * rng.standard_normal((224, 224, 10))).astype(np.complex64)
+    y = (rng.standard_normal(eng.m) + 1j * rng.standard_normal(eng.m)).astype(np.complex64)
+    op = case224["op"]
+    yg, xg = eng.forward(x), eng.adjoint(y)
+    assert yg.dtype == np.complex64 and xg.dtype == np.complex64
+    assert np.array_equal(yg, op.forward(x.astype(np.complex128)).astype(np.complex64)) or rel_err(yg, op.forward(x.astype(np.complex128))) < 1e-7
+    assert rel_err(xg, op.adjoint(y.astype(np.complex128))) < 1e-7            # one rounding to single
+    xr = case224["X0"].astype(np.float32)                                      # real single input (F.forward(single(X0)))
+    assert rel_err(eng.forward(xr), op.forward(xr.astype(np.float64))) < 1e-7
+
+
 def test_epi_operator_vs_oracle(engine_mod, oracle, case224):
     fp, k = oracle.epi_mask(224, 224, 1 / 65, 200)
     V = case224["dic"]["V"]

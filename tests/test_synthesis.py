@@ -71,3 +71,49 @@ def test_gpu_synthesis_roundtrip_through_the_match(engine_mod, oracle, synth):
             assert np.array_equal(m["dm"][fg], idx[fg])                         # the match finds the atom the synthesis used
     finally:
         R.release()
+
+
+def test_oracle_complex_mode_vs_numpy(oracle, synth):
+    """mode 'complex' (main_synthesize_tsmis.m:27,100-103): X = real(D(I,:)) .* normD(I) .* qm(:,3) with a complex PD, no abs, no sign
+    alignment, stored as cat(3, real(X), imag(X)) -- 20 channels for s = 10."""
+    dic = synth.make_dictionary(T=24, n_t1=24, n_t2=16, s=10)
+    q = _maps(synth, dic).astype(np.complex128)
+    rng = np.random.default_rng(2)
+    q[:, :, 2] = q[:, :, 2] * np.exp(1j * rng.uniform(-3, 3, q.shape[:2]))       # complex proton density
+    X, idx = oracle.synthesize_tsmi(q, dic["D"], dic["normD"], dic["lut"], mode="complex")
+    assert X.shape == (40, 40, 20) and X.dtype == np.float32
+    _, idx_r = oracle.synthesize_tsmi(q.real, dic["D"], dic["normD"], dic["lut"])
+    assert np.array_equal(idx, idx_r)                                            # the search only sees T1, T2
+    I = idx.ravel(order="F") - 1
+    base = np.asarray(dic["D"], np.float32)[I] * np.asarray(dic["normD"], np.float32).ravel()[I, None]
+    pd = q[:, :, 2].reshape(-1, order="F")
+    want = np.concatenate([base * pd.real.astype(np.float32)[:, None], base * pd.imag.astype(np.float32)[:, None]], axis=1)
+    assert np.array_equal(X.reshape(-1, 20, order="F"), want)
+    Xr, _ = oracle.synthesize_tsmi(q.real, dic["D"], dic["normD"], dic["lut"], mode="complex")     # real PD: imaginary channels are zero
+    assert np.all(Xr[:, :, 10:] == 0) and np.array_equal(Xr[:, :, :10], (base * pd.real.astype(np.float32)[:, None]).reshape(40, 40, 10, order="F"))
+
+
+@pytest.mark.gpu
+def test_gpu_complex_mode_vs_oracle(engine_mod, oracle, synth):
+    from qmri_pnp_recon_poc_amd import harness as H, reference_api as R
+    dic = synth.make_dictionary(T=24, n_t1=48, n_t2=40, s=10)
+    e = engine_mod.Engine(0)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    q = _maps(synth, dic, N=64, seed=3).astype(np.complex128)
+    q[:, :, 2] = q[:, :, 2] * np.exp(1j * np.linspace(-2, 2, 64))[None, :]
+    Xg, ig = e.synthesize_tsmi(q, mode="complex")
+    Xo, io = oracle.synthesize_tsmi(q, dic["D"], dic["normD"], dic["lut"], mode="complex")
+    assert Xg.shape == (64, 64, 20) and np.array_equal(ig, io) and np.array_equal(Xg, Xo)        # bit-exact
+    Xg2, _ = e.synthesize_tsmi(q.real, mode="complex")                                         # real PD through the complex mode
+    assert np.all(Xg2[:, :, 10:] == 0)
+    Xr, _ = e.synthesize_tsmi(q, mode="real")                                                  # complex maps through the real mode: |PD| (:92)
+    Xro, _ = oracle.synthesize_tsmi(q, dic["D"], dic["normD"], dic["lut"], mode="real")
+    assert np.array_equal(Xr, Xro) and np.all(Xr[:, :, 0] >= 0)
+    with pytest.raises(ValueError):
+        e.synthesize_tsmi(q, mode="imaginary")
+    e.close()
+    try:
+        X = H.synthesize_tsmis(np.transpose(q[None], (0, 3, 1, 2)), dic, mode="complex")        # volume layout: slices x 3 x N x M
+        assert X.shape == (1, 64, 64, 20) and np.array_equal(X[0], Xo)
+    finally:
+        R.release()
