@@ -15,8 +15,9 @@
 // max(abs(ip)) compares single-precision MAGNITUDES: two atoms whose |ip|^2 differ in the last bits but whose
 // sqrtf rounds to the same single tie, and the first index wins (:92).  The loop keeps that semantics without a
 // square root per candidate: beside the best magnitude it holds `thr`, the largest |ip|^2 whose correctly rounded
-// square root is still that magnitude; a candidate beats the incumbent iff its |ip|^2 exceeds thr.  The square
-// root (and the 1-4 neighbours of thr) are evaluated only when the incumbent changes.
+// square root is still that magnitude; a candidate beats the incumbent iff its |ip|^2 exceeds thr (checked once per
+// 32-atom tile on the tile's maximum).  The square root and the bounds of its pre-image are evaluated only when the
+// incumbent changes.
 //
 // Work split: one workgroup (4 waves) per 32-pixel tile; wave w takes atom tiles w, w+4, ...; the four
 // (max, argmax) candidates per pixel are merged through LDS preferring the lower index on ties.
@@ -28,26 +29,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NT = 256;
 constexpr int MAXPAIR = 8;      // s <= 16
 
-// largest float whose correctly rounded square root is still s = sqrtf(m2)  (two or three floats share one root).
+// The floats whose correctly rounded square root is s: lo .. hi (two or three consecutive floats share one root).
 // sqrtf() is the correctly rounded square root under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt (the __fsqrt_rn
 // intrinsic is NOT: without OCML_BASIC_ROUNDED_OPERATIONS it is the 1-ulp native instruction) -- bit-identical to glibc's sqrtf.
-// x rounds to s iff sqrt(x) < s + ulp(s)/2 =: mid (a tie is impossible: mid has 25 significant bits, mid^2 an odd 50th one, and x
-// only 24), i.e. iff x < mid^2, which is exact in double precision: the answer is the largest float below mid^2.
-__device__ __forceinline__ float sqrt_preimage_top(float m2, float s) {
+// x rounds to s iff (prev(s) + s)/2 < sqrt(x) < (s + next(s))/2 (a tie is impossible: a midpoint has 25 significant bits, its square
+// an odd 50th one, x only 24), i.e. iff mid_lo^2 < x < mid_hi^2 with both squares exact in double precision.
+__device__ __forceinline__ void sqrt_preimage(float s, float m2, float& lo, float& hi) {
     if (!(s >= 1e-30f && s <= 1e30f)) {                                 // zero, tiny, infinite or NaN: walk (never in practice)
-        float t = m2;
-        for (int it = 0; it < 4; ++it) {
-            const float n = __uint_as_float(__float_as_uint(t) + 1u);  // next float up (t >= 0)
-            if (sqrtf(n) == s) t = n; else break;
-        }
-        return t;
+        lo = hi = m2;
+        for (int it = 0; it < 4; ++it) { const float n = __uint_as_float(__float_as_uint(hi) + 1u); if (sqrtf(n) == s) hi = n; else break; }
+        for (int it = 0; it < 4 && lo > 0.f; ++it) { const float n = __uint_as_float(__float_as_uint(lo) - 1u); if (sqrtf(n) == s) lo = n; else break; }
+        return;
     }
-    const float half_ulp = __uint_as_float((__float_as_uint(s) & 0x7F800000u) - (24u << 23));   // 2^(e-24) for s = 1.f x 2^e
-    const double mid = (double)s + (double)half_ulp;
-    const double b = mid * mid;                                         // exact
-    float t = (float)b;                                                 // nearest float; step down if it did not land below b
-    if ((double)t >= b) t = __uint_as_float(__float_as_uint(t) - 1u);
-    return t;
+    const double sd = (double)s;
+    const double mid_hi = 0.5 * (sd + (double)__uint_as_float(__float_as_uint(s) + 1u));
+    const double mid_lo = 0.5 * (sd + (double)__uint_as_float(__float_as_uint(s) - 1u));
+    const double bh = mid_hi * mid_hi, bl = mid_lo * mid_lo;            // exact
+    hi = (float)bh;                                                     // nearest float; step down if it did not land below bh
+    if ((double)hi >= bh) hi = __uint_as_float(__float_as_uint(hi) - 1u);
+    lo = (float)bl;                                                     // ... step up if it did not land above bl
+    if ((double)lo <= bl) lo = __uint_as_float(__float_as_uint(lo) + 1u);
 }
 
 // D packed as MFMA A-fragments: pack[tile][pair q][lane] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s)
@@ -92,11 +93,17 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
         tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
                      fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
         if (tmax > thr) {          // some atom of this tile beats the incumbent (rare once the scan has passed the neighbourhood of the match)
+            // the new magnitude is sqrtf of the tile's largest |ip|^2; MATLAB's max keeps the FIRST atom with that magnitude, i.e. the
+            // lowest row of the tile whose |ip|^2 lies in the root's pre-image [lo, hi]: one square root per update, not per candidate
+            float lo, hi;
+            best = sqrtf(tmax);
+            sqrt_preimage(best, tmax, lo, hi);
+            thr = hi;
+            int rsel = 15;                                                  // (the tile's maximum itself is >= lo: some row qualifies)
+            cre = are[15]; cim = aim[15];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {                                  // ascending atom index: the first of equal magnitudes stays
-                const int atom = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D row of the 32x32 MFMA tile
-                if (m2[r] > thr) { best = sqrtf(m2[r]); thr = sqrt_preimage_top(m2[r], best); bidx = atom; cre = are[r]; cim = aim[r]; }
-            }
+            for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; cre = are[r]; cim = aim[r]; }     // (ascending rows = ascending atoms)
+            bidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;          // C/D row of the 32x32 MFMA tile
         }
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
