@@ -259,6 +259,13 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     }
     QMRI_TRY(alloc_tensor(ctx, p.in32, desc->in_nc, conv_cin_pad(CONV_3X3, desc->in_nc), H, W, B));
     QMRI_TRY(alloc_tensor(ctx, p.out32, desc->out_nc, desc->out_nc, H, W, B));
+    // BLOCKED interior tensors (PTensor::blk): every layer on the conv6 kernels, every interior channel count a multiple of 8
+    p.blk_ok = conv6_enabled();
+    for (const ConvLayer& L : p.layers) if (!L.wp6) p.blk_ok = false;
+    if (desc->arch == QMRI_ARCH_UNETRES) { for (int l = 0; l < 4; ++l) if (desc->nc[l] % 8) p.blk_ok = false; }
+    else if (nb > 1 && desc->nc[0] % 8) p.blk_ok = false;
+    for (int l = 0; l < 4; ++l) if ((p.x[l].p && p.x[l].Cal % 8) || (p.a[l].p && p.a[l].Cal % 8) || (p.t[l].p && p.t[l].Cal % 8)) p.blk_ok = false;
+    p.interior_fmt = -1;
     QMRI_TRY(dev_alloc(ctx, &p.d_counter, (size_t)1));
     QMRI_HIP(ctx, hipMemset(p.d_counter, 0, sizeof(unsigned)));
     if (getenv("QMRI_CONV_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_stamps, 4096 * 11 * sizeof(unsigned long long))); }
@@ -292,6 +299,22 @@ static int net_forward_layers(qmri_ctx* ctx, int B);
 
 // network forward on the context's padded tensors: in32 -> out32
 static int net_forward_padded(qmri_ctx* ctx, int B) {
+    {
+        // Interior tensors (everything between the head's input and the tail's output) are BLOCKED when every layer runs on the
+        // matrix-core kernels (PTensor::blk), planar otherwise (the f32-MFMA kernels of the calibration pass, QMRI_CONV_F32, odd
+        // channel counts).  The two formats put the zero halo at different addresses: a change of format re-zeroes the tensors.
+        NetPlan& p = ctx->net;
+        const bool blk = p.blk_ok && !p.force_f32 && conv6_enabled();
+        if (p.interior_fmt != -1 && p.interior_fmt != (blk ? 1 : 0)) {
+            PTensor* ts[12];
+            int nt = 0;
+            for (int l = 0; l < 4; ++l) { ts[nt++] = &p.x[l]; ts[nt++] = &p.a[l]; ts[nt++] = &p.t[l]; }
+            for (int i = 0; i < nt; ++i)
+                if (ts[i]->p) QMRI_HIP(ctx, hipMemsetAsync(ts[i]->p, 0, ((size_t)p.maxB * ts[i]->batch_stride() + 8192) * sizeof(float), ctx->stream));
+        }
+        p.interior_fmt = blk ? 1 : 0;
+        for (int l = 0; l < 4; ++l) { p.x[l].blk = blk; p.a[l].blk = blk; p.t[l].blk = blk; }
+    }
     const bool report = !ctx->net.force_f32;                        // (the calibration's f32 pass reports nothing)
     if (report) QMRI_TRY(conv6_act_begin(ctx, (int)ctx->net.layers.size()));
     QMRI_TRY(net_forward_layers(ctx, B));

@@ -66,6 +66,7 @@ struct Conv6Args {
     int vec4;                     // epilogue may use aligned float4 accesses (H % 4 == 0 and line-aligned tensors)
     int wt;                       // write-through (sc1) output stores, see store4()
     int xcd;                      // XCD-aware tile order, see xcd_remap()
+    int in_blk, out_blk;          // the input / the output (and with it the residual operands) is a BLOCKED tensor [c/8][w][h][8] (see BRegs)
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int ntiles;                   // k_conv6p: tiles of the launch (n_ct * tiles_h * tiles_w * B)
@@ -142,24 +143,38 @@ __device__ __forceinline__ unsigned usgpr(unsigned v) {
 }
 __device__ __forceinline__ void bload4(u32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bload4f(f32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
+__device__ __forceinline__ void bload4f_o16(f32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
+__device__ __forceinline__ void bstore4_o16(f32x4 x, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:16 sc1\n\ts_nop 1" ::"v"(x), "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bload1(float& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bstore4(f32x4 x, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(x), "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void gload4r(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 __device__ __forceinline__ void gload1(float& dst, unsigned off, const void* base) { asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
-template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], float (&b)[1][8]) {
+// One loader item of the B operand = 8 input channels of one pixel.  PLANAR tensors ([c][w][h], h fastest): eight 4-byte requests, one
+// per channel plane.  BLOCKED tensors ([c/8][w][h][8], the interior format of the matrix-core schemes): the eight
+// channels are 32 contiguous bytes, two 16-byte requests -- a vector-memory instruction costs a loader wave 25-60 cycles of issue
+// whatever its width, and the loader waves' issue time bounds the loop (tools/conv6p_stamps.py).
+template <bool INB> struct BRegs;
+template <> struct BRegs<false> { float v[8]; __device__ __forceinline__ float get(int j) const { return v[j]; } };
+template <> struct BRegs<true> { f32x4 q[2]; __device__ __forceinline__ float get(int j) const { return q[j >> 2][j & 3]; } };
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], BRegs<false>& b) {
     asm volatile("s_waitcnt vmcnt(%13)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
-                   "+v"(b[0][4]), "+v"(b[0][5]), "+v"(b[0][6]), "+v"(b[0][7])
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]),
+                   "+v"(b.v[4]), "+v"(b.v[5]), "+v"(b.v[6]), "+v"(b.v[7])
                  : "n"(N)
                  : "memory");
 }
-
-template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], float (&b)[1][8]) {
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], BRegs<false>& b) {
     asm volatile("s_waitcnt vmcnt(%11)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
-                   "+v"(b[0][4]), "+v"(b[0][5]), "+v"(b[0][6]), "+v"(b[0][7])
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]),
+                   "+v"(b.v[4]), "+v"(b.v[5]), "+v"(b.v[6]), "+v"(b.v[7])
                  : "n"(N)
                  : "memory");
+}
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], BRegs<true>& b) {
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b.q[0]), "+v"(b.q[1]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], BRegs<true>& b) {
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b.q[0]), "+v"(b.q[1]) : "n"(N) : "memory");
 }
 
 // Output stores.  A plain store leaves its line dirty in the XCD's L2, and the end-of-kernel release then writes all of them back
@@ -250,7 +265,7 @@ __device__ __forceinline__ void act_report(const ActMax& am, float tmax, int wav
 // (Measured and removed: streaming the residual operand into an LDS tile during the last 8 steps of the loop, so that the epilogue
 //  finds it on chip.  The loop is bound by the loader waves (tools/conv6p_stamps.py), so what the epilogue saved the loop lost:
 //  634.9 vs 634.9 ADMM it/s, residual layers 21.3 us either way against 17.8 us for layers without a residual operand.)
-template <int CFG, int SP, bool STAMP>
+template <int CFG, int SP, bool STAMP, bool INB>
 __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int AST = ast6(SP);
     typedef Cfg6<CFG> C;
@@ -263,8 +278,9 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int NBI = 2 * NLP;                                    // loader items of one chunk of B: (k-half, pixel)
     constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);          // ... per loader thread and step (a chunk is spread over its 3 steps)
     constexpr int NAQ = (AST + NLD6 - 1) / NLD6;                    // uint4 of A per loader thread and step
-    static_assert(((SP == 3 && NAQ == 5) || (SP == 2 && NAQ == 3)) && NBQ == 1, "gwait() is written for 5 + 8 / 3 + 8 loads per step");
-    constexpr int NLOAD = NAQ + 8 * NBQ;                            // vector-memory loads a loader thread issues per step
+    static_assert(((SP == 3 && NAQ == 5) || (SP == 2 && NAQ == 3)) && NBQ == 1, "gwait() is written for 5 / 3 loads of A and one item of B per step");
+    constexpr int NBL = INB ? 2 : 8;                                // requests per item of B (BRegs)
+    constexpr int NLOAD = NAQ + NBL;                                // vector-memory loads a loader thread issues per step
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
     constexpr int PXT = TH * TW, PP = PXT + 4;                      // output tile in LDS: [64 cout][PP], aliases the B buffers
@@ -293,8 +309,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         constexpr unsigned ASTB = AST * 16;                         // bytes of A per step
         const unsigned plane4 = (unsigned)A.in_plane * 4u, chunkB = CK * plane4;
         const unsigned wbase = (unsigned)(((size_t)ct * A.nchunk_all + (size_t)ks * A.nchunk) * 3 * ASTB);   // steps of a cout tile are contiguous
-        const unsigned ibase = (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0) * 4);   // halo origin = padded (oh0, ow0)
-        unsigned aoff[NAQ], boff[3][8], ldsB[3];                   // loop-invariant byte offsets of this thread's requests / LDS stores
+        // halo origin = padded (oh0, ow0); a chunk (16 channels = two blocks of 8) is CK planes further in either format
+        const unsigned ibase = INB ? (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane) * 4 + ((size_t)ow0 * A.in_hp + oh0) * 32)
+                                   : (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0) * 4);
+        unsigned aoff[NAQ], boff[3][INB ? 1 : 8], ldsB[3];         // loop-invariant byte offsets of this thread's requests / LDS stores
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
 #pragma unroll
@@ -303,13 +321,17 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             if (item >= NBI) item = 0;
             const int h2 = item / NLP, px = item - h2 * NLP;
             const int dw = px / IH, dh = px - dw * IH;
-            const unsigned b0 = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
+            if constexpr (INB) {
+                boff[part][0] = (unsigned)((((size_t)h2) * A.in_plane + dw * A.in_hp + dh) * 32);   // the 8 channels are contiguous
+            } else {
+                const unsigned b0 = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) boff[part][j] = b0 + (unsigned)j * plane4;   // the 8 channels differ by a plane
+                for (int j = 0; j < 8; ++j) boff[part][j] = b0 + (unsigned)j * plane4;   // the 8 channels differ by a plane
+            }
             ldsB[part] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
         }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
-        float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
+        BRegs<INB> rb0, rb1, rb2;
         // Schedule.  Barrier g precedes compute step g.  Abuf[(g+1)&1] is free once step g-1 is over, i.e. after barrier g:
         // iteration g (between barriers g and g+1) stores A(g+1).  Bbuf[(c+1)&1] is free once chunk c-1 is over, i.e. after
         // barrier 3c: iterations 3c, 3c+1, 3c+2 store the three parts of B(c+1).  What an iteration stores was requested
@@ -328,22 +350,23 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
             const unsigned so_ = ibase + (unsigned)(((c_) < A.nchunk) ? (c_) : A.nchunk - 1) * chunkB;           \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_[0][j], boff[part_][j], srdI, so_);          \
+            if constexpr (INB) { bload4f(rb_.q[0], boff[part_][0], srdI, so_); bload4f_o16(rb_.q[1], boff[part_][0], srdI, so_); } \
+            else { _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_.v[j], boff[part_][j], srdI, so_); }  \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
         {                                                                                                        \
             unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_];              \
             uint4 s0, s1, s2;                                                                                    \
             if constexpr (SP == 3) {                                                                             \
-                split_pair(rb_[0][0], rb_[0][1], s0.x, s1.x, s2.x);                                              \
-                split_pair(rb_[0][2], rb_[0][3], s0.y, s1.y, s2.y);                                              \
-                split_pair(rb_[0][4], rb_[0][5], s0.z, s1.z, s2.z);                                              \
-                split_pair(rb_[0][6], rb_[0][7], s0.w, s1.w, s2.w);                                              \
+                split_pair(rb_.get(0), rb_.get(1), s0.x, s1.x, s2.x);                                            \
+                split_pair(rb_.get(2), rb_.get(3), s0.y, s1.y, s2.y);                                            \
+                split_pair(rb_.get(4), rb_.get(5), s0.z, s1.z, s2.z);                                            \
+                split_pair(rb_.get(6), rb_.get(7), s0.w, s1.w, s2.w);                                            \
             } else {                                                                                             \
-                split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x);                                                  \
-                split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y);                                                  \
-                split_pair_h(rb_[0][4], rb_[0][5], s0.z, s1.z);                                                  \
-                split_pair_h(rb_[0][6], rb_[0][7], s0.w, s1.w);                                                  \
+                split_pair_h(rb_.get(0), rb_.get(1), s0.x, s1.x);                                                \
+                split_pair_h(rb_.get(2), rb_.get(3), s0.y, s1.y);                                                \
+                split_pair_h(rb_.get(4), rb_.get(5), s0.z, s1.z);                                                \
+                split_pair_h(rb_.get(6), rb_.get(7), s0.w, s1.w);                                                \
             }                                                                                                    \
             *(uint4*)bd = s0;                    /* split planes are 2*NPX entries apart */                       \
             *(uint4*)(bd + 2 * NPX * 16) = s1;                                                                   \
@@ -511,7 +534,52 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         const bool has1 = A.add1 != nullptr, has2 = A.add2 != nullptr;
         bool bad = false;
         float tmax = 0.f;
-        if (A.vec4) {
+        if (A.out_blk) {
+            // BLOCKED output (and residual operands): the 8 channels of a block at one pixel are 32 contiguous bytes.  A thread takes
+            // HALF of such an item (4 channels, 16 bytes), lane pairs take the two halves of one pixel and consecutive pairs consecutive
+            // pixels (h fastest): a wave's store / residual request covers whole 512-byte runs (a lane storing both halves would
+            // write every line in two half-filled pieces -- measured 2 us slower per 224 x 224 layer), and the LDS reads of a 32-lane
+            // group fall on 32 different banks (4 channels further = 16 banks further, PP = 4 mod 32).
+            constexpr int NHI = 16 * PXT, HQ = NHI / NT6;           // half-items of the tile; per thread
+            static_assert(NHI % NT6 == 0 && PP % 32 == 4, "epilogue");
+            unsigned off[HQ];                                       // float offset of the half-item inside one image, ~0u = outside
+            f32x4 r1[HQ], r2[HQ];
+#pragma unroll
+            for (int k = 0; k < HQ; ++k) {
+                const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
+                const int g = e / PXT, px = e - g * PXT, w = px / TH, h = px - w * TH;
+                const int cb = ct * 8 + g, oh = oh0 + h, ow = ow0 + w;
+                const bool ok = cb * 8 < A.Cout && oh < A.H && ow < A.W;
+                off[k] = ok ? (unsigned)(((size_t)cb * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) * 8 + 4 * half) : ~0u;
+                r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
+            }
+            if (has1) {
+#pragma unroll
+                for (int k = 0; k < HQ; ++k) r1[k] = *(const f32x4*)(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 8u));
+            }
+            if (has2) {
+#pragma unroll
+                for (int k = 0; k < HQ; ++k) r2[k] = *(const f32x4*)(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 8u));
+            }
+            lds_barrier6();                                         // the output tile is complete
+#pragma unroll
+            for (int k = 0; k < HQ; ++k) {
+                const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
+                const int g = e / PXT, px = e - g * PXT;
+                const float* op = ot + (g * 8 + 4 * half) * PP + px;
+                f32x4 x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = op[j * PP];
+                x = (x + r1[k]) + r2[k];
+                if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+                if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
+                if constexpr (SP == 2) {
+                    const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+                    bad |= !(gm <= F16_RANGE);                      // (also NaN)
+                    if (off[k] != ~0u) tmax = fmaxf(tmax, gm);
+                }
+            }
+        } else if (A.vec4) {
             constexpr int NG = 64 * PXT / 4, GQ = NG / NT6;         // float4 groups of the tile; per thread
             static_assert(NG % NT6 == 0 && TH % 4 == 0, "epilogue");
             unsigned off[GQ];                                       // element offset inside one image (fits 32 bits), ~0u = outside
@@ -589,7 +657,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     if constexpr (STAMP) { if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64(); }
 }
 
-template <int CFG, int SP, bool STAMP = false> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP, STAMP>(A); }
+template <int CFG, int SP, bool INB, bool STAMP = false> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP, STAMP, INB>(A); }
 
 // =====================================================================================================================
 // k_conv6p : persistent, software-pipelined form of k_conv6 (f16 x 3 scheme) for launches with several tiles per CU -- slice
@@ -649,15 +717,14 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
     constexpr int NBI = 2 * NLP;
     constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);
     constexpr int NAQ = (AST + NLD6 - 1) / NLD6;
-    static_assert(NAQ == 3 && NBQ == 1, "gwait() is written for 3 + 8 loads per step");
-    constexpr int NLOAD = NAQ + 8 * NBQ;
+    static_assert(NAQ == 3 && NBQ == 1, "gwait() is written for 3 + 2 loads per step");
+    constexpr int NLOAD = NAQ + 2;                                  // (BLOCKED tensors throughout: conv6_launch checks)
     constexpr int PXT = TH * TW, PP = PXT + 4;
-    constexpr int GPC = PXT / 4;                                    // float4 groups per output channel of the tile
-    constexpr int NG = 64 * GPC;                                    // ... of the tile
-    constexpr int EPS = 8;                                          // steps of the next tile that carry the epilogue
-    constexpr int GQL = NG / NLD6, GPS = GQL / EPS;                 // groups per loader thread: per tile, per step
-    constexpr int COSTEP = NLD6 / GPC;                              // consecutive groups of a thread are this many channels apart
-    static_assert(GQL * NLD6 == NG && GPS * EPS == GQL && COSTEP * GPC == NLD6 && TH % 4 == 0, "epilogue split");
+    // epilogue: half-items (4 channels of a block at one pixel, 16 bytes; lane pairs = the two halves of a pixel, see k_conv6), 16 * PXT
+    // per tile; a loader thread handles two per step: the same half at two pixels 128 apart (256-pixel tile) or in two blocks
+    constexpr int NGS = NLD6 / PXT;                                 // channel blocks covered by the loader threads in one step
+    constexpr int EPS = 8 / NGS;                                    // steps of the next tile that carry the epilogue = items per loader thread
+    static_assert(NGS * PXT == NLD6 && EPS * NGS == 8 && EPS >= 4, "epilogue split");
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
     uint4* Bbuf = Abuf + NABUF * AST;                               // [2][SP][2 k-halves][NPX]
@@ -679,9 +746,9 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         const u32x4 srdW = make_srd(A.wp), srdI = make_srd(A.in), srdO = make_srd(A.out);
         const u32x4 srdR1 = make_srd(NRES > 0 ? (const void*)A.add1 : (const void*)A.out), srdR2 = make_srd(NRES > 1 ? (const void*)A.add2 : (const void*)A.out);
         constexpr unsigned ASTB = AST * 16;                         // bytes of A per step
-        const unsigned plane4 = (unsigned)A.in_plane * 4u, oplane4 = (unsigned)A.out_plane * 4u;
+        const unsigned plane4 = (unsigned)A.in_plane * 4u, oplane32 = (unsigned)A.out_plane * 32u;   // (bytes of a plane / of a block's plane)
         const unsigned chunkB = CK * plane4;                        // bytes between chunks of the input
-        unsigned aoff[NAQ], boff[3][8];                             // per-lane byte offsets of this thread's requests
+        unsigned aoff[NAQ], boff[3];                                // per-lane byte offsets of this thread's requests
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);      // (AST == NAQ * NLD6)
         static_assert(AST == NAQ * NLD6, "A requests");
@@ -692,28 +759,33 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             if (item >= NBI) item = 0;
             const int h2 = item / NLP, px = item - h2 * NLP;
             const int dw = px / IH, dh = px - dw * IH;
-            const unsigned b0 = (unsigned)(((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) boff[part][j] = b0 + (unsigned)j * plane4;
+            boff[part] = (unsigned)(((size_t)h2 * A.in_plane + dw * A.in_hp + dh) * 32);
             ldsB[part] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
         }
         unsigned char* const ldsA = (unsigned char*)Abuf + lt * 16;                    // + buffer * ASTB + q * NLD6 * 16 (immediates)
         unsigned char* const ldsBb = (unsigned char*)Bbuf;
-        // this thread's share of a tile's epilogue: GQL float4 groups at a fixed (w, h), channels eco0 + COSTEP * k
-        const int erem = lt % GPC, eco0 = lt / GPC;
-        const int ew = erem / (TH / 4), eh = 4 * (erem - ew * (TH / 4));
-        const unsigned evoff = (unsigned)(((size_t)eco0 * A.out_plane + (size_t)(ew + 1) * A.out_hp + (eh + 1)) * 4);   // + scalar (tile, slice)
-        const unsigned char* const otp = (const unsigned char*)(ot + eco0 * PP + 4 * erem);        // + k * COSTEP * PP * 4
+        // this thread's share of a tile's epilogue: half ehalf of pixels epx[q] in channel blocks egs[q] + NGS * j (j = step), q = 0, 1
+        const int ehalf = lt & 1;
+        int ew[2], eh[2];
+        unsigned evoff[2];                                          // + scalar (tile, slice)
+        const float* otp[2];                                        // + j * NGS * 8 * PP, channel c: + c * PP
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = (lt >> 1) + (NLD6 / 2) * q, epx = idx % PXT, egs = idx / PXT;
+            ew[q] = epx / TH; eh[q] = epx - ew[q] * TH;
+            evoff[q] = (unsigned)(((size_t)egs * A.out_plane + (size_t)(ew[q] + 1) * A.out_hp + (eh[q] + 1)) * 32 + 16 * ehalf);
+            otp[q] = ot + (egs * 8 + 4 * ehalf) * PP + epx;
+        }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
-        float rb0[NBQ][8], rb1[NBQ][8], rb2[NBQ][8];
-        f32x4 rr0[GPS][NRES > 0 ? NRES : 1], rr1[GPS][NRES > 0 ? NRES : 1], rr2[GPS][NRES > 0 ? NRES : 1];   // residual operands, same rotation
+        BRegs<true> rb0, rb1, rb2;
+        f32x4 rr0[NRES > 0 ? NRES : 1][2], rr1[NRES > 0 ? NRES : 1][2], rr2[NRES > 0 ? NRES : 1][2];   // residual operands [operand][q], same rotation
         // scalar byte offsets of a tile inside the weights / the input / the output (and residual) tensors
         struct TOff { unsigned w, i, o, r1, r2; int oh0, ow0; };
         auto toff = [&](const Tile6& t) __attribute__((always_inline)) {
             TOff r;
             r.w = (unsigned)t.ct * (unsigned)A.nchunk_all * 3u * ASTB;
-            r.i = (unsigned)(((size_t)t.b * A.in_bs + (size_t)t.ow0 * A.in_hp + t.oh0) * 4);
-            const unsigned px = (unsigned)(((size_t)t.ct * 64 * A.out_plane + (size_t)t.ow0 * A.out_hp + t.oh0) * 4);
+            r.i = (unsigned)((size_t)t.b * A.in_bs * 4 + ((size_t)t.ow0 * A.in_hp + t.oh0) * 32);
+            const unsigned px = (unsigned)(((size_t)t.ct * 8 * A.out_plane + (size_t)t.ow0 * A.out_hp + t.oh0) * 32);
             r.o = (unsigned)((size_t)t.b * A.out_bs * 4) + px;
             r.r1 = (unsigned)((size_t)t.b * A.add1_bs * 4) + px;
             r.r2 = (unsigned)((size_t)t.b * A.add2_bs * 4) + px;
@@ -738,42 +810,45 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         {                                                                                                        \
             const int cc_ = (c_);                                                                                \
             const unsigned so_ = (cc_ < A.nchunk) ? cur.i + (unsigned)cc_ * chunkB : nx.i + (unsigned)(cc_ - A.nchunk) * chunkB; \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_[0][j], boff[part_][j], srdI, so_);          \
+            bload4f(rb_.q[0], boff[part_], srdI, so_); bload4f_o16(rb_.q[1], boff[part_], srdI, so_);            \
         }
 #define PSTORE_B(c_, part_, rb_)                                                                                 \
         {                                                                                                        \
             unsigned char* bd = ldsBb + ((c_) & 1) * (SP * 2 * NPX * 16) + ldsB[part_];                          \
             uint4 s0, s1;                                                                                        \
-            split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x);                                                      \
-            split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y);                                                      \
-            split_pair_h(rb_[0][4], rb_[0][5], s0.z, s1.z);                                                      \
-            split_pair_h(rb_[0][6], rb_[0][7], s0.w, s1.w);                                                      \
+            split_pair_h(rb_.q[0][0], rb_.q[0][1], s0.x, s1.x);                                                  \
+            split_pair_h(rb_.q[0][2], rb_.q[0][3], s0.y, s1.y);                                                  \
+            split_pair_h(rb_.q[1][0], rb_.q[1][1], s0.z, s1.z);                                                  \
+            split_pair_h(rb_.q[1][2], rb_.q[1][3], s0.w, s1.w);                                                  \
             if ((part_) * (NBQ * NLD6) + lt < NBI) { *(uint4*)bd = s0; *(uint4*)(bd + 2 * NPX * 16) = s1; }      \
         }
-        // residual operands of epilogue slice j_ (groups GPS*j_ ...) of tile t_: requested into set rr_.  Issued in EVERY step (a
+        // residual operands of epilogue slice j_ (channel blocks egs + NGS*j_) of tile t_: requested into set rr_.  Issued in EVERY step (a
         // step that has nothing to prefetch repeats slice 0 of the current tile): one unconditional instruction sequence, so the
         // destination registers of in-flight loads are never merged across branches (no copies of in-flight registers)
 #define PREQ_RES(t_, j_, rr_)                                                                                    \
         if constexpr (NRES > 0) {                                                                                \
-            const bool okhw_ = (t_).oh0 + eh < A.H && (t_).ow0 + ew < A.W;                                       \
-            const unsigned vo_ = okhw_ ? evoff : 0u;                                                             \
-            _Pragma("unroll") for (int q = 0; q < GPS; ++q) {                                                    \
-                const unsigned ko_ = (unsigned)((j_) * GPS + q) * COSTEP * oplane4;                              \
-                bload4f(rr_[q][0], vo_, srdR1, usgpr((t_).r1 + ko_));                                            \
-                if constexpr (NRES > 1) bload4f(rr_[q][1], vo_, srdR2, usgpr((t_).r2 + ko_));                    \
+            const unsigned ko_ = (unsigned)((j_) * NGS) * oplane32;                                              \
+            const unsigned so1_ = usgpr((t_).r1 + ko_), so2_ = (NRES > 1) ? usgpr((t_).r2 + ko_) : 0u;           \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+                const bool okhw_ = (t_).oh0 + eh[q] < A.H && (t_).ow0 + ew[q] < A.W;                             \
+                const unsigned vo_ = okhw_ ? evoff[q] : 0u;                                                      \
+                bload4f(rr_[0][q], vo_, srdR1, so1_);                                                            \
+                if constexpr (NRES > 1) bload4f(rr_[1][q], vo_, srdR2, so2_);                                    \
             }                                                                                                    \
         }
         // epilogue slice j_ of tile t_ (its accumulators are in `ot`): LDS tile + residual operands (set rr_), ReLU, guard, store
 #define PEPI(t_, j_, rr_)                                                                                        \
         {                                                                                                        \
-            const bool okhw_ = (t_).oh0 + eh < A.H && (t_).ow0 + ew < A.W;                                       \
-            _Pragma("unroll") for (int q = 0; q < GPS; ++q) {                                                    \
-                const int k_ = (j_) * GPS + q;                                                                   \
-                f32x4 x = *(const f32x4*)(otp + k_ * (COSTEP * PP * 4));                                         \
-                if constexpr (NRES > 0) x = x + rr_[q][0];                                                       \
-                if constexpr (NRES > 1) x = x + rr_[q][1];                                                       \
+            const unsigned so_ = usgpr((t_).o + (unsigned)((j_) * NGS) * oplane32);                              \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+                const bool okhw_ = (t_).oh0 + eh[q] < A.H && (t_).ow0 + ew[q] < A.W;                             \
+                const float* op_ = otp[q] + (j_) * (NGS * 8 * PP);                                               \
+                f32x4 x;                                                                                         \
+                _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) x[c_] = op_[c_ * PP];                           \
+                if constexpr (NRES > 0) x = x + rr_[0][q];                                                       \
+                if constexpr (NRES > 1) x = x + rr_[1][q];                                                       \
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); } \
-                if (okhw_) bstore4(x, evoff, srdO, usgpr((t_).o + (unsigned)k_ * COSTEP * oplane4));             \
+                if (okhw_) bstore4(x, evoff[q], srdO, so_);                                                      \
                 {                                                                                                \
                     const float gm_ = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));   \
                     bad |= !(gm_ <= F16_RANGE);                                                                  \
@@ -816,8 +891,8 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             }                                                                                                    \
             __builtin_amdgcn_s_setprio(0);                                                                       \
             P_STAMP(2, sidx);                                                                                    \
-            gwait<2 * NLOAD>(rs_a, rs_b);                                                                        \
-            if constexpr (NRES > 0) { _Pragma("unroll") for (int q = 0; q < GPS; ++q) { asm volatile("" : "+v"(rs_r[q][0])); if constexpr (NRES > 1) asm volatile("" : "+v"(rs_r[q][1])); } } \
+            gwait<2 * (NLOAD + 2 * NRES)>(rs_a, rs_b);   /* exactly the requests issued since set rs: two iterations' operands and residuals */ \
+            if constexpr (NRES > 0) { asm volatile("" : "+v"(rs_r[0][0]), "+v"(rs_r[0][1])); if constexpr (NRES > 1) asm volatile("" : "+v"(rs_r[1][0]), "+v"(rs_r[1][1])); } \
             P_STAMP(3, sidx);                                                                                    \
             PSTORE_A(((k_) + 2) % 3, rs_a) PSTORE_B(c0 + 1, part_, rs_b)   /* step g+k_+2 lives in A buffer (g+k_+2) % 3, g % 3 == 0 */ \
             P_STAMP(4, sidx);                                                                                    \
@@ -852,7 +927,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         gwait<0>(ra0, rb0); gwait<0>(ra1, rb1); gwait<0>(ra2, rb2);   // (requests past the end are still in flight)
         if constexpr (NRES > 0) {
 #pragma unroll
-            for (int q = 0; q < GPS; ++q) { asm volatile("" : "+v"(rr0[q][0]), "+v"(rr1[q][0]), "+v"(rr2[q][0])); if constexpr (NRES > 1) asm volatile("" : "+v"(rr0[q][1]), "+v"(rr1[q][1]), "+v"(rr2[q][1])); }
+            for (int q = 0; q < NRES; ++q) asm volatile("" : "+v"(rr0[q][0]), "+v"(rr0[q][1]), "+v"(rr1[q][0]), "+v"(rr1[q][1]), "+v"(rr2[q][0]), "+v"(rr2[q][1]));
         }
         if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
 #undef PITER
@@ -948,37 +1023,41 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         last = tile6<CFG>(A, tile - tstride);
     }
 
-    // ---- the workgroup's last tile: all eight waves, as in k_conv6 (`ot` is complete: the loop's last barrier follows its stores)
+    // ---- the workgroup's last tile: all eight waves, as in k_conv6's BLOCKED epilogue (`ot` is complete: the loop's last barrier
+    // follows its stores)
     {
         const int ct = last.ct, oh0 = last.oh0, ow0 = last.ow0, b = last.b;
-        const bool has1 = NRES > 0, has2 = NRES > 1;
         bool bad = false;
-        constexpr int GQ = NG / NT6;
-        static_assert(NG % NT6 == 0, "epilogue");
-        unsigned off[GQ];
-        f32x4 r1[GQ], r2[GQ];
+        constexpr int NHI = 16 * PXT, HQ = NHI / NT6;
+        static_assert(NHI % NT6 == 0 && PP % 32 == 4, "epilogue");
+        unsigned off[HQ];
+        f32x4 r1[HQ], r2[HQ];
 #pragma unroll
-        for (int k = 0; k < GQ; ++k) {
-            const int e = k * NT6 + tid;
-            const int co = e / GPC, rem = e - co * GPC, w = rem / (TH / 4), h = 4 * (rem - w * (TH / 4));
-            const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
-            const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
-            off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
+        for (int k = 0; k < HQ; ++k) {
+            const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
+            const int g = e / PXT, px = e - g * PXT, w = px / TH, h = px - w * TH;
+            const int cb = ct * 8 + g, oh = oh0 + h, ow = ow0 + w;
+            const bool ok = cb * 8 < A.Cout && oh < A.H && ow < A.W;
+            off[k] = ok ? (unsigned)(((size_t)cb * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) * 8 + 4 * half) : ~0u;
             r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
         }
-        if (has1) {
+        if constexpr (NRES > 0) {
 #pragma unroll
-            for (int k = 0; k < GQ; ++k) r1[k] = *(const f32x4*)(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 1u));
+            for (int k = 0; k < HQ; ++k) r1[k] = *(const f32x4*)(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 8u));
         }
-        if (has2) {
+        if constexpr (NRES > 1) {
 #pragma unroll
-            for (int k = 0; k < GQ; ++k) r2[k] = *(const f32x4*)(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 1u));
+            for (int k = 0; k < HQ; ++k) r2[k] = *(const f32x4*)(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 8u));
         }
 #pragma unroll
-        for (int k = 0; k < GQ; ++k) {
-            const int e = k * NT6 + tid;
-            const int co = e / GPC, rem = e - co * GPC;
-            f32x4 x = (*(const f32x4*)(ot + co * PP + 4 * rem) + r1[k]) + r2[k];
+        for (int k = 0; k < HQ; ++k) {
+            const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
+            const int g = e / PXT, px = e - g * PXT;
+            const float* op = ot + (g * 8 + 4 * half) * PP + px;
+            f32x4 x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = op[j * PP];
+            x = (x + r1[k]) + r2[k];
             if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
             if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
             const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
@@ -1028,7 +1107,7 @@ template <int N> __device__ __forceinline__ void gwait_s(u32x4 (&a)[2], f32x4 (&
 }
 __device__ __forceinline__ void gload4f(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
 
-template <int KIND, int SP>       // 0 = DOWN, 1 = UP; SP as in k_conv6
+template <int KIND, int SP, bool BLK>   // 0 = DOWN, 1 = UP; SP as in k_conv6; BLK: input and output are BLOCKED tensors (BRegs)
 __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
     constexpr int ASTS = asts6(SP);
     constexpr int NAS = ASTS / NLD6;                                // uint4 of A per loader thread and step
@@ -1059,19 +1138,33 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         unsigned aoff[NAS];
 #pragma unroll
         for (int q = 0; q < NAS; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);
-        // this thread's activations: 2 channels (pair cp of an 8-channel half) x 4 consecutive h
+        // PLANAR: this thread's activations are 2 channels (pair cp of an 8-channel half) x 4 consecutive h.
+        // BLOCKED: one item = the 8 channels of (k-half h2, plane pl) at one pixel of the tile, 32 contiguous bytes; consecutive
+        //          lanes take consecutive h of the input (DOWN: 16 = 8 output rows x kh; UP: 8), i.e. contiguous runs of 512 / 256 bytes
         const int cp = lt & 3, rest = lt >> 2;
         int h2, pl, hg, wq;                                         // k-half, plane (UP: channel slice), h group, column
         if (KIND == 0) { h2 = rest & 1; hg = (rest >> 1) & 3; wq = rest >> 3; pl = 0; }
         else { pl = rest & 1; h2 = (rest >> 1) & 1; hg = (rest >> 2) & 1; wq = rest >> 3; }
-        // byte offset of (channel 0 of the pair, first h) relative to the step's base pointer; second channel = + plane
+        int bh = 0, bpx = 0;                                        // BLOCKED: input h inside the tile; LDS pixel index of the item
+        if constexpr (BLK) {
+            if (KIND == 0) { bh = lt & 15; h2 = (lt >> 4) & 1; wq = lt >> 5; pl = bh & 1; bpx = wq * STH + (bh >> 1); }
+            else { bh = lt & 7; wq = (lt >> 3) & 7; h2 = (lt >> 6) & 1; pl = lt >> 7; bpx = wq * STH + bh; }
+        }
+        // byte offset of this thread's first request relative to the step's base pointer (PLANAR: channel 0 of the pair, first h; the
+        // second channel = + plane.  BLOCKED: the item; its second half = + 16)
         unsigned boff;
-        if (KIND == 0) boff = (unsigned)((((size_t)(h2 * 8 + cp * 2)) * A.in_plane + (size_t)(2 * wq) * A.in_hp + 4 * hg) * 4);
-        else boff = (unsigned)((((size_t)(pl * 16 + h2 * 8 + cp * 2)) * A.in_plane + (size_t)wq * A.in_hp + 4 * hg) * 4);
-        const unsigned boff2 = boff + (unsigned)A.in_plane * 4u;
-        // halo-free tile origin: padded coordinates = logical + 1
+        if constexpr (BLK) {
+            if (KIND == 0) boff = (unsigned)((((size_t)h2) * A.in_plane + (size_t)(2 * wq) * A.in_hp + bh) * 32);
+            else boff = (unsigned)((((size_t)(pl * 2 + h2)) * A.in_plane + (size_t)wq * A.in_hp + bh) * 32);
+        } else {
+            if (KIND == 0) boff = (unsigned)((((size_t)(h2 * 8 + cp * 2)) * A.in_plane + (size_t)(2 * wq) * A.in_hp + 4 * hg) * 4);
+            else boff = (unsigned)((((size_t)(pl * 16 + h2 * 8 + cp * 2)) * A.in_plane + (size_t)wq * A.in_hp + 4 * hg) * 4);
+        }
+        const unsigned boff2 = BLK ? boff + 16u : boff + (unsigned)A.in_plane * 4u;
+        // halo-free tile origin: padded coordinates = logical + 1  (BLOCKED: a pixel is 8 floats)
+        constexpr int EPX = BLK ? 8 : 1;
         const float* isrc = A.in + (size_t)b * A.in_bs + ((KIND == 0) ? ((size_t)(2 * gw0 + 1) * A.in_hp + 2 * gh0 + 1)
-                                                                      : ((size_t)(gw0 + 1) * A.in_hp + gh0 + 1));
+                                                                      : ((size_t)(gw0 + 1) * A.in_hp + gh0 + 1)) * EPX;
         __builtin_amdgcn_s_setprio(2);
         u32x4 ra0[NAS], ra1[NAS], ra2[NAS];
         f32x4 rb0[2], rb1[2], rb2[2];
@@ -1080,7 +1173,7 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
             const int ga = ((g_) < nsteps) ? (g_) : nsteps - 1, gg = (ga < A.nsteps_real) ? ga : A.nsteps_real - 1;   \
             const uint4* ws = uniform_ptr(wsrc + (size_t)ga * ASTS);                                             \
             _Pragma("unroll") for (int q = 0; q < NAS; ++q) gload4(ra_[q], aoff[q], ws);                         \
-            const float* bs_ = (KIND == 0) ? uniform_ptr(isrc + (size_t)(gg >> 1) * CK * A.in_plane + (size_t)(gg & 1) * A.in_hp) \
+            const float* bs_ = (KIND == 0) ? uniform_ptr(isrc + (size_t)(gg >> 1) * CK * A.in_plane + (size_t)(gg & 1) * A.in_hp * EPX) \
                                            : uniform_ptr(isrc + (size_t)gg * 32 * A.in_plane);                   \
             gload4f(rb_[0], boff, bs_); gload4f(rb_[1], boff2, bs_);                                             \
         }
@@ -1089,6 +1182,19 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
             uint4* ad = Abuf + ((g_) & 1) * ASTS;                                                                \
             _Pragma("unroll") for (int q = 0; q < NAS; ++q) ad[lt + NLD6 * q] = __builtin_bit_cast(uint4, ra_[q]); \
             unsigned* bd = Bbuf + ((g_) & 1) * BSTEP;                                                            \
+            if constexpr (BLK) {                                                                                 \
+                uint4 s0, s1, s2;                                                                                \
+                if constexpr (SP == 3) {                                                                         \
+                    split_pair(rb_[0][0], rb_[0][1], s0.x, s1.x, s2.x); split_pair(rb_[0][2], rb_[0][3], s0.y, s1.y, s2.y); \
+                    split_pair(rb_[1][0], rb_[1][1], s0.z, s1.z, s2.z); split_pair(rb_[1][2], rb_[1][3], s0.w, s1.w, s2.w); \
+                } else {                                                                                         \
+                    split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x); split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y); \
+                    split_pair_h(rb_[1][0], rb_[1][1], s0.z, s1.z); split_pair_h(rb_[1][2], rb_[1][3], s0.w, s1.w); \
+                }                                                                                                \
+                uint4* be = (uint4*)bd + (h2 * 2 + pl) * SNPX + bpx;                                             \
+                be[0] = s0; be[2 * 2 * SNPX] = s1;                                                               \
+                if constexpr (SP == 3) be[2 * 2 * 2 * SNPX] = s2;                                                \
+            } else                                                                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
                 unsigned p0, p1, p2 = 0;                                                                         \
                 if constexpr (SP == 3) split_pair(rb_[0][j], rb_[1][j], p0, p1, p2);                             \
@@ -1176,8 +1282,45 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         }
     }
     lds_barrier6();
-    // ---- all eight waves: aligned float4 rows of the output tile
-    {
+    // ---- all eight waves.  BLOCKED: two half-items (4 channels of a block at one output pixel, 16 bytes) per thread; lane pairs take
+    // the two halves of one pixel, so a wave stores contiguous runs (see k_conv6)
+    if constexpr (BLK) {
+        static_assert((OROWS / 8) * OPX == NT6 && PPs % 32 == 4, "epilogue");
+        bool bad = false;
+        float tmax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
+            const int g = e / OPX, px = e - g * OPX;
+            const float* op = ot + (g * 8 + 4 * half) * PPs + px;
+            f32x4 x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = op[j * PPs];
+            const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            if constexpr (SP == 2) bad |= !(gm <= F16_RANGE);
+            int cb, oh, ow;                                         // output channel block; output coordinates
+            bool ok;
+            if (KIND == 0) {
+                const int w = px / STH, h = px - w * STH;
+                cb = ct * 8 + g; oh = gh0 + h; ow = gw0 + w;
+                ok = cb * 8 < A.Cout && oh < A.GH && ow < A.GW;
+            } else {
+                const int iw = px / (2 * STH), hh = px - iw * (2 * STH);   // hh = 2*ih + kh
+                const int kw = ct & 1, ih = gh0 + (hh >> 1), iwg = gw0 + iw;
+                cb = (ct >> 1) * 4 + g; oh = 2 * gh0 + hh; ow = 2 * iwg + kw;
+                ok = cb * 8 < A.Cout && ih < A.GH && iwg < A.GW;
+            }
+            if (ok) {
+                tmax = fmaxf(tmax, gm);
+                store4(A.out + (size_t)b * A.out_bs + ((size_t)cb * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) * 8 + 4 * half, x, A.wt);
+            }
+        }
+        if constexpr (SP == 2) {
+            if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+            act_report(A.am, tmax, NT6 / 64);
+        }
+    } else {
+        // PLANAR: aligned float4 rows of the output tile
         constexpr int NG = OROWS * OPX / 4, GQ = NG / NT6;
         static_assert(NG % NT6 == 0, "epilogue");
         bool bad = false;
@@ -1236,8 +1379,13 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
             const PTensor* add2, int relu_out, int ksplit = 1, float* partial = nullptr, long out_ks = 0) {
     typedef Cfg6<CFG> C;
     Conv6Args A;
-    A.in = in.base1(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.base1();
-    A.add1 = add1 ? add1->base1() : nullptr; A.add2 = add2 ? add2->base1() : nullptr;
+    A.in = in.fbase(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.fbase();
+    A.add1 = add1 ? add1->fbase() : nullptr; A.add2 = add2 ? add2->fbase() : nullptr;
+    A.in_blk = in.blk ? 1 : 0; A.out_blk = (out.blk && !partial) ? 1 : 0;       // (split-K partial sums are planar scratch)
+    if ((add1 && add1->blk != out.blk) || (add2 && add2->blk != out.blk) || (out.blk && L.Cout % 8 != 0)) {
+        qmri_set_error(ctx, "conv layer %d: residual operands and output must share one tensor format (blocked needs Cout %% 8 == 0)", L.index);
+        return QMRI_ERR_STATE;
+    }
     A.Cout = L.Cout; A.W = in.W; A.H = in.H;
     A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
@@ -1262,7 +1410,8 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.detail = (stamp_launch < 0 || A.launch_idx == stamp_launch) ? 1 : 0;
     const size_t lds = conv6_lds<CFG>(SP);
     if (!ctx->conv6_attr[CFG][SP - 2]) {
-        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->conv6_attr[CFG][SP - 2] = true;
     }
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
@@ -1270,14 +1419,24 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));                  // (profile level 2 only)
     if constexpr (SP == 2 && CFG < 2) {
         if (A.stamps) {                                             // QMRI_CONV_STAMPS: the diagnostic instantiation (tools/conv6_stamps.py)
-            QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_conv6<CFG, SP, true><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+            if (in.blk) {
+                QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k_conv6<CFG, SP, true, true><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+            } else {
+                QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k_conv6<CFG, SP, false, true><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+            }
             QMRI_HIP(ctx, hipGetLastError());
             return QMRI_OK;
         }
     }
-    if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP>), dim3(grid), dim3(NT6), (std::uint32_t)lds, ctx->stream, e0, e1, 0, A);
-    else k_conv6<CFG, SP><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+    if (in.blk) {
+        if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP, true>), dim3(grid), dim3(NT6), (std::uint32_t)lds, ctx->stream, e0, e1, 0, A);
+        else k_conv6<CFG, SP, true><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+    } else {
+        if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP, false>), dim3(grid), dim3(NT6), (std::uint32_t)lds, ctx->stream, e0, e1, 0, A);
+        else k_conv6<CFG, SP, false><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+    }
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -1288,8 +1447,9 @@ int launch6p_t(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, cons
                int relu_out) {
     typedef Cfg6<CFG> C;
     Conv6Args A{};
-    A.in = in.base1(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.base1();
-    A.add1 = add1 ? add1->base1() : nullptr; A.add2 = add2 ? add2->base1() : nullptr;
+    A.in = in.fbase(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.fbase();   // (BLOCKED tensors: launch6p checks)
+    A.add1 = add1 ? add1->fbase() : nullptr; A.add2 = add2 ? add2->fbase() : nullptr;
+    A.in_blk = 1; A.out_blk = 1;
     A.Cout = L.Cout; A.W = in.W; A.H = in.H;
     A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
@@ -1333,9 +1493,10 @@ int launch6p(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const 
     *done = false;
     static const int persist = getenv("QMRI_CONV_PERSIST") ? atoi(getenv("QMRI_CONV_PERSIST")) : 1;
     if (!persist || L.sp6 != 2 || L.Cout % 64 != 0 || L.nchunk6 < 4 || L.nchunk6 % 2 != 0 || (add2 && !add1)) return QMRI_OK;
-    const bool vec4 = in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
-                      (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp));
-    if (!vec4) return QMRI_OK;
+    if (!in.blk || !out.blk || (add1 && !add1->blk) || (add2 && !add2->blk)) return QMRI_OK;      // k_conv6p is written for BLOCKED tensors
+    const bool same = (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp && add1->plane() == out.plane())) &&
+                      (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp && add2->plane() == out.plane()));
+    if (!same) return QMRI_OK;
     if (!ctx->conv_ncu) {
         hipDeviceProp_t prop;
         QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -1400,6 +1561,44 @@ __global__ __launch_bounds__(256) void k_conv6_reduce(const float* __restrict__ 
             gm = fabsf(v);
             if (range_flag && !(gm <= F16_RANGE)) atomicOr(range_flag, 1u);
         }
+    }
+    act_report(am, gm, 4);
+}
+
+// The same for BLOCKED output / residual tensors (the partial sums are planar scratch): one half-item (4 channels of a block at one
+// pixel, 16 bytes) per thread, lane pairs = the two halves of a pixel, h fastest -- the partial reads are coalesced per channel, the
+// stores contiguous.  Same order of additions as above.
+__global__ __launch_bounds__(256) void k_conv6_reduce_blk(const float* __restrict__ part, int ksplit, long out_ks, float* __restrict__ out,
+                                                            const float* __restrict__ add1, const float* __restrict__ add2, long add1_bs,
+                                                            long add2_bs, long out_bs, int Cout, int H, int W, int hp, int plane, int relu,
+                                                            long total_half_items, unsigned* range_flag, ActMax am) {
+    const long i2 = (long)blockIdx.x * 256 + threadIdx.x;
+    float gm = 0.f;
+    if (i2 < total_half_items) {
+        const int half = (int)(i2 & 1);
+        const long i = i2 >> 1;
+        const int h = (int)(i % H);
+        long r = i / H;
+        const int w = (int)(r % W); r /= W;
+        const int nblk = Cout / 8;
+        const int g = (int)(r % nblk);
+        const long b = r / nblk;
+        const long px = (long)(w + 1) * hp + (h + 1);
+        const float* pp = part + b * out_bs + (long)(8 * g + 4 * half) * plane + px;
+        f32x4 x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = pp[(long)j * plane];
+        for (int k = 1; k < ksplit; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] += pp[(long)k * out_ks + (long)j * plane];
+        }
+        const long bo = ((long)g * plane + px) * 8 + 4 * half;
+        if (add1) x = x + *(const f32x4*)(add1 + b * add1_bs + bo);
+        if (add2) x = x + *(const f32x4*)(add2 + b * add2_bs + bo);
+        if (relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        store4(out + b * out_bs + bo, x, 1);
+        gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+        if (range_flag && !(gm <= F16_RANGE)) atomicOr(range_flag, 1u);
     }
     act_report(am, gm, 4);
 }
@@ -1595,6 +1794,12 @@ void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packe
 // returns false if the layer/tensors do not meet the kernel's alignment assumptions (the f32 kernel then runs)
 bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out) {
     if (!L.wp6 || (L.kind != CONV_DOWN && L.kind != CONV_UP)) return false;
+    if (in.blk != out.blk) return false;
+    if (in.blk) {                                                   // BLOCKED: 32-byte items, no alignment along h
+        if (L.Cout % 8) return false;
+        if (L.kind == CONV_DOWN) return in.H % 2 == 0 && in.W % 2 == 0 && in.Cal >= (L.nsteps6s / 2) * CK;
+        return in.Cal >= L.nsteps6s * 32;
+    }
     if (in.h0 % 4 || in.hp % 4 || out.h0 % 4 || out.hp % 4) return false;
     if (L.kind == CONV_DOWN) return in.H % 2 == 0 && in.W % 2 == 0 && (in.H / 2) % 4 == 0 && in.Cal >= (L.nsteps6s / 2) * CK;
     return in.H % 2 == 0 && in.Cal >= L.nsteps6s * 32;
@@ -1603,7 +1808,11 @@ bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out) {
 int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out) {
     const bool up = (L.kind == CONV_UP);
     Conv6sArgs A;
-    A.in = in.base1(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.base1();
+    if (in.blk != out.blk || (out.blk && L.Cout % 8 != 0)) {
+        qmri_set_error(ctx, "conv layer %d: input and output of a 2x2 layer must share one tensor format", L.index);
+        return QMRI_ERR_STATE;
+    }
+    A.in = in.fbase(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.fbase();
     A.Cout = L.Cout;
     A.GH = up ? in.H : in.H / 2; A.GW = up ? in.W : in.W / 2;
     A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
@@ -1618,13 +1827,14 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     A.descale_hi = L.w6_descale; A.descale_lo = L.w6_descale * (1.f / LO_SCALE);
     A.tiles_h = (A.GH + STH - 1) / STH; A.tiles_w = (A.GW + STW - 1) / STW;
     const int grid = A.n_ct * A.tiles_h * A.tiles_w * B;
-    if (L.sp6 == 2) {
-        if (up) k_conv6s<1, 2><<<dim3(grid), dim3(NT6), conv6s_lds(2), ctx->stream>>>(A);
-        else k_conv6s<0, 2><<<dim3(grid), dim3(NT6), conv6s_lds(2), ctx->stream>>>(A);
-    } else {
-        if (up) k_conv6s<1, 3><<<dim3(grid), dim3(NT6), conv6s_lds(3), ctx->stream>>>(A);
-        else k_conv6s<0, 3><<<dim3(grid), dim3(NT6), conv6s_lds(3), ctx->stream>>>(A);
+#define LAUNCH6S(KIND_, SP_)                                                                                     \
+    {                                                                                                            \
+        if (in.blk) k_conv6s<KIND_, SP_, true><<<dim3(grid), dim3(NT6), conv6s_lds(SP_), ctx->stream>>>(A);      \
+        else k_conv6s<KIND_, SP_, false><<<dim3(grid), dim3(NT6), conv6s_lds(SP_), ctx->stream>>>(A);            \
     }
+    if (L.sp6 == 2) { if (up) LAUNCH6S(1, 2) else LAUNCH6S(0, 2) }
+    else { if (up) LAUNCH6S(1, 3) else LAUNCH6S(0, 3) }
+#undef LAUNCH6S
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -1663,11 +1873,22 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             const long total = (long)B * L.Cout * in.H * in.W;
             const bool vec = in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
                              (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp));
-#define REDUCE_ARGS net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.base1(), add1 ? add1->base1() : nullptr, add2 ? add2->base1() : nullptr,        \
+            if ((add1 && add1->blk != out.blk) || (add2 && add2->blk != out.blk) || (out.blk && L.Cout % 8 != 0)) {
+                qmri_set_error(ctx, "conv layer %d: residual operands and output must share one tensor format", L.index);
+                return QMRI_ERR_STATE;
+            }
+#define REDUCE_ARGS net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.fbase(), add1 ? add1->fbase() : nullptr, add2 ? add2->fbase() : nullptr,        \
                 add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(),                \
                 L.Cout, in.H, in.W, out.hp, (int)out.plane(), relu_out, total, (L.sp6 == 2) ? ctx->net.d_range_flag : nullptr,                      \
                 conv6_act_slot(ctx, L.sp6 == 2, L)
-            if (vec) k_conv6_reduce<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, ctx->stream>>>(REDUCE_ARGS);
+            if (out.blk) {
+                const long total_items = total / 4;             // half-items
+                k_conv6_reduce_blk<<<dim3((unsigned)((total_items + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+                    net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.fbase(), add1 ? add1->fbase() : nullptr, add2 ? add2->fbase() : nullptr,
+                    add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(), L.Cout, in.H,
+                    in.W, out.hp, (int)out.plane(), relu_out, total_items, (L.sp6 == 2) ? ctx->net.d_range_flag : nullptr,
+                    conv6_act_slot(ctx, L.sp6 == 2, L));
+            } else if (vec) k_conv6_reduce<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, ctx->stream>>>(REDUCE_ARGS);
             else k_conv6_reduce<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(REDUCE_ARGS);
 #undef REDUCE_ARGS
             QMRI_HIP(ctx, hipGetLastError());

@@ -496,6 +496,10 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         if (L.kind == CONV_3X3 || L.kind == CONV_3X3N) return conv6_launch(ctx, L, B, in, out, add1, add2, relu_out);
         if (!add1 && !add2 && !relu_out && conv6s_usable(L, in, out)) return conv6s_launch(ctx, L, B, in, out);
     }
+    if (in.blk || out.blk || (add1 && add1->blk) || (add2 && add2->blk)) {      // (the f32-MFMA kernels below read planar tensors only)
+        qmri_set_error(ctx, "conv layer %d: no matrix-core kernel for a blocked tensor", L.index);
+        return QMRI_ERR_STATE;
+    }
     switch (L.kind) {
         case CONV_3X3: return launch_kind<CONV_3X3>(ctx, L, B, in, out, add1, add2, relu_out);
         case CONV_3X3N: return launch_kind<CONV_3X3N>(ctx, L, B, in, out, add1, add2, relu_out);

@@ -146,7 +146,12 @@ struct PTensor {
     float* p = nullptr;
     int C = 0, Cal = 0, H = 0, W = 0;
     int hp = 0, h0 = 1;
+    // BLOCKED: element (c, w, h) of the padded image lives at ((c/8 * plane + w * hp + h) * 8 + c%8 instead of c * plane + w * hp + h -- the
+    // interior format of the matrix-core conv kernels (conv6_kernels.hip: 8 channels of a pixel = 32 contiguous bytes = two 16-byte
+    // requests).  Same allocation either way (Cal % 8 == 0); a property of the current forward pass, set by net_forward_padded.
+    bool blk = false;
     float* base1() const { return p + (h0 - 1); }
+    float* fbase() const { return p + (size_t)(h0 - 1) * (blk ? 8 : 1); }      // halo origin of row 0 in the tensor's current format
     size_t plane() const { return (size_t)hp * (W + 2); }
     size_t batch_stride() const { return (size_t)Cal * plane(); }
 };
@@ -175,6 +180,8 @@ struct NetPlan {
     int act_cap = 0;                    // rows of the three arrays (= layers)
     bool act_on = false, act_record = false;   // a reporting forward pass is under way; it is the calibration probe
     int sp6 = 2;                     // scheme the layers are packed for
+    bool blk_ok = false;             // the network's interior tensors may be BLOCKED (PTensor::blk): every layer runs on the conv6 kernels, channels % 8 == 0
+    int interior_fmt = -1;           // format the interior tensors were last written in (-1: untouched zeros, 0 planar, 1 blocked): a change re-zeroes them (halo)
     std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
