@@ -155,7 +155,8 @@ __device__ __forceinline__ void gload1(float& dst, unsigned off, const void* bas
 // whatever its width, and the loader waves' issue time bounds the loop (tools/conv6p_stamps.py).
 template <bool INB> struct BRegs;
 template <> struct BRegs<false> { float v[8]; __device__ __forceinline__ float get(int j) const { return v[j]; } };
-template <> struct BRegs<true> { f32x4 q[2]; __device__ __forceinline__ float get(int j) const { return q[j >> 2][j & 3]; } };
+template <> struct BRegs<true> { f32x4 q[2]; };   // two HALF-items (4 channels, 16 bytes) of different pixels: lane pairs take the two halves
+                                                   // of one pixel, so a wave's request covers contiguous runs (as the epilogue's stores do)
 template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], BRegs<false>& b) {
     asm volatile("s_waitcnt vmcnt(%13)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]),
@@ -312,23 +313,32 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         // halo origin = padded (oh0, ow0); a chunk (16 channels = two blocks of 8) is CK planes further in either format
         const unsigned ibase = INB ? (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane) * 4 + ((size_t)ow0 * A.in_hp + oh0) * 32)
                                    : (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0) * 4);
-        unsigned aoff[NAQ], boff[3][INB ? 1 : 8], ldsB[3];         // loop-invariant byte offsets of this thread's requests / LDS stores
+        unsigned aoff[NAQ], boff[3][INB ? 2 : 8], ldsB[3][INB ? 2 : 1];   // loop-invariant byte offsets of this thread's requests / LDS stores
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
-            int item = part * (NBQ * NLD6) + lt;
-            if (item >= NBI) item = 0;
-            const int h2 = item / NLP, px = item - h2 * NLP;
-            const int dw = px / IH, dh = px - dw * IH;
             if constexpr (INB) {
-                boff[part][0] = (unsigned)((((size_t)h2) * A.in_plane + dw * A.in_hp + dh) * 32);   // the 8 channels are contiguous
+                // half-items: half (lt & 1) of items part * 256 + (lt >> 1) and + 128
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    int item = part * (NBQ * NLD6) + (lt >> 1) + (NLD6 / 2) * q;
+                    if (item >= NBI) item = 0;
+                    const int h2 = item / NLP, px = item - h2 * NLP;
+                    const int dw = px / IH, dh = px - dw * IH;
+                    boff[part][q] = (unsigned)((((size_t)h2) * A.in_plane + dw * A.in_hp + dh) * 32 + 16 * (lt & 1));
+                    ldsB[part][q] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + 8 * (lt & 1));
+                }
             } else {
+                int item = part * (NBQ * NLD6) + lt;
+                if (item >= NBI) item = 0;
+                const int h2 = item / NLP, px = item - h2 * NLP;
+                const int dw = px / IH, dh = px - dw * IH;
                 const unsigned b0 = (unsigned)((((size_t)(h2 * 8)) * A.in_plane + dw * A.in_hp + dh) * 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) boff[part][j] = b0 + (unsigned)j * plane4;   // the 8 channels differ by a plane
+                ldsB[part][0] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
             }
-            ldsB[part] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
         }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
         BRegs<INB> rb0, rb1, rb2;
@@ -350,12 +360,27 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
             const unsigned so_ = ibase + (unsigned)(((c_) < A.nchunk) ? (c_) : A.nchunk - 1) * chunkB;           \
-            if constexpr (INB) { bload4f(rb_.q[0], boff[part_][0], srdI, so_); bload4f_o16(rb_.q[1], boff[part_][0], srdI, so_); } \
+            if constexpr (INB) { bload4f(rb_.q[0], boff[part_][0], srdI, so_); bload4f(rb_.q[1], boff[part_][1], srdI, so_); } \
             else { _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_.v[j], boff[part_][j], srdI, so_); }  \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
-        {                                                                                                        \
-            unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_];              \
+        if constexpr (INB) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+                unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_][q];       \
+                uint2 s0, s1, s2;                /* 4 channels = 8 bytes of a 16-byte entry */                    \
+                if constexpr (SP == 3) {                                                                         \
+                    split_pair(rb_.q[q][0], rb_.q[q][1], s0.x, s1.x, s2.x);                                      \
+                    split_pair(rb_.q[q][2], rb_.q[q][3], s0.y, s1.y, s2.y);                                      \
+                } else {                                                                                         \
+                    split_pair_h(rb_.q[q][0], rb_.q[q][1], s0.x, s1.x);                                          \
+                    split_pair_h(rb_.q[q][2], rb_.q[q][3], s0.y, s1.y);                                          \
+                }                                                                                                \
+                *(uint2*)bd = s0;                /* split planes are 2*NPX entries apart */                       \
+                *(uint2*)(bd + 2 * NPX * 16) = s1;                                                               \
+                if constexpr (SP == 3) *(uint2*)(bd + 4 * NPX * 16) = s2;                                        \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_][0];           \
             uint4 s0, s1, s2;                                                                                    \
             if constexpr (SP == 3) {                                                                             \
                 split_pair(rb_.get(0), rb_.get(1), s0.x, s1.x, s2.x);                                            \
@@ -748,20 +773,22 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         constexpr unsigned ASTB = AST * 16;                         // bytes of A per step
         const unsigned plane4 = (unsigned)A.in_plane * 4u, oplane32 = (unsigned)A.out_plane * 32u;   // (bytes of a plane / of a block's plane)
         const unsigned chunkB = CK * plane4;                        // bytes between chunks of the input
-        unsigned aoff[NAQ], boff[3];                                // per-lane byte offsets of this thread's requests
+        unsigned aoff[NAQ], boff[3][2];                             // per-lane byte offsets of this thread's requests
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);      // (AST == NAQ * NLD6)
         static_assert(AST == NAQ * NLD6, "A requests");
-        unsigned ldsB[3];                                           // LDS byte offset (inside one B buffer) of the item each part stores
+        unsigned ldsB[3][2];                                        // LDS byte offset (inside one B buffer) of the half-items each part stores
 #pragma unroll
-        for (int part = 0; part < 3; ++part) {
-            int item = part * (NBQ * NLD6) + lt;
-            if (item >= NBI) item = 0;
-            const int h2 = item / NLP, px = item - h2 * NLP;
-            const int dw = px / IH, dh = px - dw * IH;
-            boff[part] = (unsigned)(((size_t)h2 * A.in_plane + dw * A.in_hp + dh) * 32);
-            ldsB[part] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16);
-        }
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                           // half (lt & 1) of items part * 256 + (lt >> 1) and + 128, as in k_conv6
+                int item = part * (NBQ * NLD6) + (lt >> 1) + (NLD6 / 2) * q;
+                if (item >= NBI) item = 0;                          // (the last part is not full: surplus threads repeat item 0 -- same bytes, as in k_conv6)
+                const int h2 = item / NLP, px = item - h2 * NLP;
+                const int dw = px / IH, dh = px - dw * IH;
+                boff[part][q] = (unsigned)(((size_t)h2 * A.in_plane + dw * A.in_hp + dh) * 32 + 16 * (lt & 1));
+                ldsB[part][q] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + 8 * (lt & 1));
+            }
         unsigned char* const ldsA = (unsigned char*)Abuf + lt * 16;                    // + buffer * ASTB + q * NLD6 * 16 (immediates)
         unsigned char* const ldsBb = (unsigned char*)Bbuf;
         // this thread's share of a tile's epilogue: half ehalf of pixels epx[q] in channel blocks egs[q] + NGS * j (j = step), q = 0, 1
@@ -810,17 +837,17 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         {                                                                                                        \
             const int cc_ = (c_);                                                                                \
             const unsigned so_ = (cc_ < A.nchunk) ? cur.i + (unsigned)cc_ * chunkB : nx.i + (unsigned)(cc_ - A.nchunk) * chunkB; \
-            bload4f(rb_.q[0], boff[part_], srdI, so_); bload4f_o16(rb_.q[1], boff[part_], srdI, so_);            \
+            bload4f(rb_.q[0], boff[part_][0], srdI, so_); bload4f(rb_.q[1], boff[part_][1], srdI, so_);          \
         }
 #define PSTORE_B(c_, part_, rb_)                                                                                 \
         {                                                                                                        \
-            unsigned char* bd = ldsBb + ((c_) & 1) * (SP * 2 * NPX * 16) + ldsB[part_];                          \
-            uint4 s0, s1;                                                                                        \
-            split_pair_h(rb_.q[0][0], rb_.q[0][1], s0.x, s1.x);                                                  \
-            split_pair_h(rb_.q[0][2], rb_.q[0][3], s0.y, s1.y);                                                  \
-            split_pair_h(rb_.q[1][0], rb_.q[1][1], s0.z, s1.z);                                                  \
-            split_pair_h(rb_.q[1][2], rb_.q[1][3], s0.w, s1.w);                                                  \
-            if ((part_) * (NBQ * NLD6) + lt < NBI) { *(uint4*)bd = s0; *(uint4*)(bd + 2 * NPX * 16) = s1; }      \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+                unsigned char* bd = ldsBb + ((c_) & 1) * (SP * 2 * NPX * 16) + ldsB[part_][q];                   \
+                uint2 s0, s1;                                                                                    \
+                split_pair_h(rb_.q[q][0], rb_.q[q][1], s0.x, s1.x);                                              \
+                split_pair_h(rb_.q[q][2], rb_.q[q][3], s0.y, s1.y);                                              \
+                *(uint2*)bd = s0; *(uint2*)(bd + 2 * NPX * 16) = s1;                                             \
+            }                                                                                                    \
         }
         // residual operands of epilogue slice j_ (channel blocks egs + NGS*j_) of tile t_: requested into set rr_.  Issued in EVERY step (a
         // step that has nothing to prefetch repeats slice 0 of the current tile): one unconditional instruction sequence, so the
@@ -1145,22 +1172,31 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
         int h2, pl, hg, wq;                                         // k-half, plane (UP: channel slice), h group, column
         if (KIND == 0) { h2 = rest & 1; hg = (rest >> 1) & 3; wq = rest >> 3; pl = 0; }
         else { pl = rest & 1; h2 = (rest >> 1) & 1; hg = (rest >> 2) & 1; wq = rest >> 3; }
-        int bh = 0, bpx = 0;                                        // BLOCKED: input h inside the tile; LDS pixel index of the item
+        // byte offsets of this thread's two requests relative to the step's base pointer.  PLANAR: channel 0 of the pair, first h; the
+        // second channel = + plane.  BLOCKED: half (lt & 1) of items (lt >> 1) and (lt >> 1) + 128 (lane pairs = the halves of a pixel)
+        unsigned boff, boff2;
+        int bent[2] = {0, 0};                                       // BLOCKED: LDS entry (uint4 index inside one split plane of a step) of each item
         if constexpr (BLK) {
-            if (KIND == 0) { bh = lt & 15; h2 = (lt >> 4) & 1; wq = lt >> 5; pl = bh & 1; bpx = wq * STH + (bh >> 1); }
-            else { bh = lt & 7; wq = (lt >> 3) & 7; h2 = (lt >> 6) & 1; pl = lt >> 7; bpx = wq * STH + bh; }
-        }
-        // byte offset of this thread's first request relative to the step's base pointer (PLANAR: channel 0 of the pair, first h; the
-        // second channel = + plane.  BLOCKED: the item; its second half = + 16)
-        unsigned boff;
-        if constexpr (BLK) {
-            if (KIND == 0) boff = (unsigned)((((size_t)h2) * A.in_plane + (size_t)(2 * wq) * A.in_hp + bh) * 32);
-            else boff = (unsigned)((((size_t)(pl * 2 + h2)) * A.in_plane + (size_t)wq * A.in_hp + bh) * 32);
+            unsigned bo[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int it = (lt >> 1) + (NLD6 / 2) * q;
+                if (KIND == 0) {
+                    const int bh = it & 15, ih2 = (it >> 4) & 1, iwq = it >> 5;      // input h inside the tile (= 2 * output row + kh), k-half, column
+                    bo[q] = (unsigned)((((size_t)ih2) * A.in_plane + (size_t)(2 * iwq) * A.in_hp + bh) * 32);
+                    bent[q] = (ih2 * 2 + (bh & 1)) * SNPX + iwq * STH + (bh >> 1);
+                } else {
+                    const int bh = it & 7, iwq = (it >> 3) & 7, ih2 = (it >> 6) & 1, ipl = it >> 7;
+                    bo[q] = (unsigned)((((size_t)(ipl * 2 + ih2)) * A.in_plane + (size_t)iwq * A.in_hp + bh) * 32);
+                    bent[q] = (ih2 * 2 + ipl) * SNPX + iwq * STH + bh;
+                }
+            }
+            boff = bo[0] + 16u * (lt & 1); boff2 = bo[1] + 16u * (lt & 1);
         } else {
             if (KIND == 0) boff = (unsigned)((((size_t)(h2 * 8 + cp * 2)) * A.in_plane + (size_t)(2 * wq) * A.in_hp + 4 * hg) * 4);
             else boff = (unsigned)((((size_t)(pl * 16 + h2 * 8 + cp * 2)) * A.in_plane + (size_t)wq * A.in_hp + 4 * hg) * 4);
+            boff2 = boff + (unsigned)A.in_plane * 4u;
         }
-        const unsigned boff2 = BLK ? boff + 16u : boff + (unsigned)A.in_plane * 4u;
         // halo-free tile origin: padded coordinates = logical + 1  (BLOCKED: a pixel is 8 floats)
         constexpr int EPX = BLK ? 8 : 1;
         const float* isrc = A.in + (size_t)b * A.in_bs + ((KIND == 0) ? ((size_t)(2 * gw0 + 1) * A.in_hp + 2 * gh0 + 1)
@@ -1183,17 +1219,14 @@ __global__ __launch_bounds__(NT6) void k_conv6s(const Conv6sArgs A) {
             _Pragma("unroll") for (int q = 0; q < NAS; ++q) ad[lt + NLD6 * q] = __builtin_bit_cast(uint4, ra_[q]); \
             unsigned* bd = Bbuf + ((g_) & 1) * BSTEP;                                                            \
             if constexpr (BLK) {                                                                                 \
-                uint4 s0, s1, s2;                                                                                \
-                if constexpr (SP == 3) {                                                                         \
-                    split_pair(rb_[0][0], rb_[0][1], s0.x, s1.x, s2.x); split_pair(rb_[0][2], rb_[0][3], s0.y, s1.y, s2.y); \
-                    split_pair(rb_[1][0], rb_[1][1], s0.z, s1.z, s2.z); split_pair(rb_[1][2], rb_[1][3], s0.w, s1.w, s2.w); \
-                } else {                                                                                         \
-                    split_pair_h(rb_[0][0], rb_[0][1], s0.x, s1.x); split_pair_h(rb_[0][2], rb_[0][3], s0.y, s1.y); \
-                    split_pair_h(rb_[1][0], rb_[1][1], s0.z, s1.z); split_pair_h(rb_[1][2], rb_[1][3], s0.w, s1.w); \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                  \
+                    uint2 s0, s1, s2;                                                                            \
+                    if constexpr (SP == 3) { split_pair(rb_[q][0], rb_[q][1], s0.x, s1.x, s2.x); split_pair(rb_[q][2], rb_[q][3], s0.y, s1.y, s2.y); } \
+                    else { split_pair_h(rb_[q][0], rb_[q][1], s0.x, s1.x); split_pair_h(rb_[q][2], rb_[q][3], s0.y, s1.y); } \
+                    uint2* be = (uint2*)((uint4*)bd + bent[q]) + (lt & 1);                                       \
+                    be[0] = s0; be[2 * (2 * 2 * SNPX)] = s1;                                                     \
+                    if constexpr (SP == 3) be[2 * (2 * 2 * 2 * SNPX)] = s2;                                      \
                 }                                                                                                \
-                uint4* be = (uint4*)bd + (h2 * 2 + pl) * SNPX + bpx;                                             \
-                be[0] = s0; be[2 * 2 * SNPX] = s1;                                                               \
-                if constexpr (SP == 3) be[2 * 2 * 2 * SNPX] = s2;                                                \
             } else                                                                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
                 unsigned p0, p1, p2 = 0;                                                                         \
