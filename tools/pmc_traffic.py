@@ -8,12 +8,12 @@ that guide's HBM section prescribes, written to profiles/conv_traffic.json (whic
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [profiles/rNN_pmc_conv_traffic.txt]
 
 Corrections.  FETCH_SIZE / WRITE_SIZE are in KB (x 1024).  On gfx950 FETCH_SIZE counts a 16-byte-per-lane coalesced read at exactly half
-its bytes; WRITE_SIZE is exact for 16-byte-per-lane stores.  In k_conv6 the residual operand (global_load_dwordx4) and the weight
-copies (buffer_load_dwordx4) are 16 B per lane, the activation requests are 4 B per lane (a width the guide leaves uncalibrated: taken
-as counted).  The residual share is MEASURED, not assumed: the launches of one forward pass alternate between layers without and with
-a residual operand, the two populations separate cleanly in FETCH_SIZE, and their difference is the residual read as counted (half
-its bytes), so   corrected FETCH(residual layer) = FETCH(plain layer) + 2 x (FETCH(residual layer) - FETCH(plain layer)).
-The weights (147 KB per layer, read through L2 once per XCD) are below the resolution of this and left as counted."""
+its bytes; WRITE_SIZE is exact for 16-byte-per-lane stores.  With BLOCKED interior tensors (k_conv6<.., true, ..>: DESIGN.md section 4)
+every request of the kernel -- weights, activations, residual operands -- is 16 B per lane, so the whole of FETCH_SIZE is doubled.
+The residual share still checks the factor: the launches of one forward pass alternate between layers without and with a residual
+operand, the two populations separate cleanly, and their difference as counted must be half of the 12 845 056 bytes a residual
+operand has (it is: 6.43 MB).  (Planar tensors, the layout before: activation requests were 4 B per lane, a width the guide leaves
+uncalibrated, taken as counted, and only the residual share was doubled -- profiles/r02_d_pmc_conv_traffic.txt.)"""
 import csv
 import glob
 import json
@@ -53,7 +53,8 @@ def main():
     med = lambda a: sorted(a)[len(a) // 2]
     fp, fr, wm = med(plain) * 1024, med(res) * 1024, med(w) * 1024
     res_counted = fr - fp
-    corr_plain, corr_res = fp, fp + 2 * res_counted
+    blocked = any("k_conv6<0, 2, true" in n for (_, n, g, v) in rows(dfetch, "FETCH_SIZE") if g == 196 * 512)
+    corr_plain, corr_res = (2 * fp, 2 * fr) if blocked else (fp, fp + 2 * res_counted)
     n_p, n_r = len(plain), len(res)
     mean_corr = (n_p * (corr_plain + wm) + n_r * (corr_res + wm)) / (n_p + n_r)
     mean_raw = (n_p * (fp + wm) + n_r * (fr + wm)) / (n_p + n_r)
@@ -66,8 +67,10 @@ def main():
            "algorithmic": {"plain_layer_bytes": alg_plain, "residual_layer_bytes": alg_res, **ALG},
            "ratio_corrected_over_algorithmic": {"plain": round((corr_plain + wm) / alg_plain, 3), "residual": round((corr_res + wm) / alg_res, 3)},
            "raw_bytes_per_launch_per_slice": int(mean_raw), "corrected_bytes_per_launch_per_slice": int(mean_corr),
+           "tensor_format": "blocked [c/8][w][h][8]" if blocked else "planar [c][w][h]",
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/prof_net.py 1 3; tools/pmc_traffic.py; "
-                     "FETCH x2 on the 16-B-per-lane residual reads (measured share), 4-B-per-lane activation reads as counted"}
+                     + ("FETCH x2 (every request of the kernel is 16 B per lane; the residual share as counted = half its bytes confirms the factor)"
+                        if blocked else "FETCH x2 on the 16-B-per-lane residual reads (measured share), 4-B-per-lane activation reads as counted")}
     with open(os.path.join(ROOT, "profiles", "conv_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     txt = json.dumps(out, indent=1)
