@@ -606,6 +606,7 @@ void qmri_free_dict(qmri_ctx* ctx) {
     if (d.d_pack) (void)hipFree(d.d_pack);
     if (d.d_normD) (void)hipFree(d.d_normD);
     if (d.d_lut) (void)hipFree(d.d_lut);
+    if (d.d_part) (void)hipFree(d.d_part);
     d = DictHost();
 }
 

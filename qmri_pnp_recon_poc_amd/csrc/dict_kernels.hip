@@ -19,13 +19,19 @@
 // 32-atom tile on the tile's maximum).  The square root and the bounds of its pre-image are evaluated only when the
 // incumbent changes.
 //
-// Work split: one workgroup (4 waves) per 32-pixel tile; wave w takes atom tiles w, w+4, ...; the four
-// (max, argmax) candidates per pixel are merged through LDS preferring the lower index on ties.
+// Work split: a workgroup (4 waves) takes one 32-pixel tile and one of P contiguous parts of the atom tiles; wave w takes the part's
+// tiles w, w+4, ...; the four (max, argmax) candidates per pixel are merged through LDS preferring the lower index on ties.  P > 1
+// when the pixel tiles alone do not fill the device evenly: a workgroup walks ALL its atoms (1.1 ms at K = 98 304), so 1568 pixel
+// tiles on 1280 resident workgroups took two rounds, the second at 22 % occupancy -- the matrix pipe idled 40 % of the launch.  The
+// parts' candidates go to a scratch array and k_dict_merge picks per pixel: larger magnitude, then lower index -- the same rule,
+// so max(abs(ip)) with the first index winning ties (mrf_dtm_cpu.m:92) whatever the split.
+#include <algorithm>
 #include "qmri_internal.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NT = 256;
 constexpr int MAXPAIR = 8;      // s <= 16
 
@@ -54,9 +60,10 @@ __device__ __forceinline__ void sqrt_preimage(float s, float m2, float& lo, floa
 // D packed as MFMA A-fragments: pack[tile][pair q][lane] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s)
 template <int NPAIR>
 __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X, int Npix, int s, const float* __restrict__ pack,
-                                                    int ntiles, int K, const float* __restrict__ normD,
+                                                    int ntiles_all, int K, const float* __restrict__ normD,
                                                     const float* __restrict__ lut, int Q, float* __restrict__ qmap,
-                                                    float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm) {
+                                                    float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm,
+                                                    float4* __restrict__ part) {
     __shared__ float s_best[4][32];
     __shared__ int s_idx[4][32];
     __shared__ float s_re[4][32];
@@ -76,20 +83,41 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
     }
     float best = -1.0f, thr = -1.0f, cre = 0.f, cim = 0.f;      // best = abs(ip) of the incumbent, thr: see the header
     int bidx = 0;
-    for (int t = wave; t < ntiles; t += 4) {
-        const float* ap = pack + ((size_t)t * NPAIR) * 64 + lane;
-        float a[NPAIR];
+    // this workgroup's part of the atom tiles: [tbeg, ntiles)
+    const int tper = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int tbeg = (int)blockIdx.y * tper, ntiles = min(ntiles_all, tbeg + tper);
+    // The atom fragments of tile t + 4 are requested before the products of tile t (register double buffer): the loop used to
+    // request a tile's fragments and wait for them at once, one L2 latency per tile hidden only by occupancy.
+    float a[NPAIR], an[NPAIR];
+    {
+        const float* ap = pack + ((size_t)((tbeg + wave < ntiles) ? tbeg + wave : 0) * NPAIR) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) a[q] = ap[q * 64];
+    }
+    for (int t = tbeg + wave; t < ntiles; t += 4) {
+        {
+            const int tn = (t + 4 < ntiles) ? t + 4 : t;           // (clamped: the last tile is requested twice)
+            const float* ap = pack + ((size_t)tn * NPAIR) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) an[q] = ap[q * 64];
+        }
         f32x16 are = {0}, aim = {0};
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
             are = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bre[q], are, 0, 0, 0);
             aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bim[q], aim, 0, 0, 0);
         }
+        // |ip|^2 = fma(im, im, re * re), two rows per packed instruction (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations as the
+        // scalar forms, so the bits the oracle computes).  The file is compiled with -amdgpu-mfma-vgpr-form (Makefile): the products
+        // land in VGPRs and the epilogue reads them in place -- with AGPR accumulators 32 of its 80 vector instructions per tile
+        // were v_accvgpr_read, and the epilogue's issue slots, not the matrix pipe, set the pace (10 MFMAs per 32 x 32 outputs).
         float m2[16], tmax;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m2[r] = __builtin_fmaf(aim[r], aim[r], are[r] * are[r]);
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 re = {are[r], are[r + 1]}, im = {aim[r], aim[r + 1]};
+            const f32x2 v = __builtin_elementwise_fma(im, im, re * re);
+            m2[r] = v[0]; m2[r + 1] = v[1];
+        }
         tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
                      fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
         if (tmax > thr) {          // some atom of this tile beats the incumbent (rare once the scan has passed the neighbourhood of the match)
@@ -105,6 +133,8 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; cre = are[r]; cim = aim[r]; }     // (ascending rows = ascending atoms)
             bidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;          // C/D row of the 32x32 MFMA tile
         }
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) a[q] = an[q];
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
     {
@@ -123,6 +153,10 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; cre = s_re[w][tid]; cim = s_im[w][tid]; }
         }
         if (bidx >= K) bidx = 0;       // cannot happen: padded atoms are all-zero and never beat a real one
+        if (part) {                    // atoms split over workgroups: k_dict_merge finishes the pixel
+            part[(size_t)blockIdx.y * Npix + p] = make_float4(best, __int_as_float(bidx), cre, cim);
+            return;
+        }
         const float nd = normD[bidx];
         if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
         if (mt) mt[p] = best;                                        // :150-154
@@ -135,15 +169,68 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
     }
 }
 
+// per pixel: the best candidate of the P atom parts (larger magnitude, then lower index), then the outputs as in k_dict_match
+__global__ __launch_bounds__(256) void k_dict_merge(const float4* __restrict__ part, int P, int Npix, int K, const float* __restrict__ normD,
+                                                     const float* __restrict__ lut, int Q, float* __restrict__ qmap, float* __restrict__ pd,
+                                                     float* __restrict__ mt, int32_t* __restrict__ dm) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Npix) return;
+    float4 b = part[p];
+    for (int k = 1; k < P; ++k) {
+        const float4 o = part[(size_t)k * Npix + p];
+        if (o.x > b.x || (o.x == b.x && __float_as_int(o.y) < __float_as_int(b.y))) b = o;
+    }
+    int bidx = __float_as_int(b.y);
+    if (bidx >= K || bidx < 0) bidx = 0;   // (cannot happen, as in k_dict_match)
+    const float nd = normD[bidx];
+    if (dm) dm[p] = bidx + 1;
+    if (mt) mt[p] = b.x;
+    if (pd) { pd[2 * (size_t)p] = b.z / nd; pd[2 * (size_t)p + 1] = b.w / nd; }
+    if (qmap)
+        for (int q = 0; q < Q; ++q) {
+            const float v = lut[(size_t)bidx + (size_t)K * q];
+            qmap[(size_t)p + (size_t)Npix * q] = (v != v) ? 0.f : v;
+        }
+}
+
 }  // namespace
 
 int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm) {
-    const DictHost& D = ctx->dict;
+    DictHost& D = ctx->dict;
     const int npair = (D.s + 1) / 2;
-    dim3 grid((Npix + 31) / 32), blk(NT);
+    if (npair < 1 || npair > MAXPAIR) {
+        qmri_set_error(ctx, "dictionary match supports s <= %d channels (got %d)", 2 * MAXPAIR, D.s);
+        return QMRI_ERR_UNSUPPORTED;
+    }
+    const int ptiles = (Npix + 31) / 32;
+    // atom parts: none if the pixel tiles fill the device's resident workgroups at least four times over (a ragged last round then
+    // costs little), else as many as give ~8 rounds, each part keeping >= 64 atom tiles per wave
+    if (!D.slots) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dict_match<5>, NT, 0));
+        D.slots = std::max(1, per_cu) * prop.multiProcessorCount;
+    }
+    int P = 1;
+    if (ptiles < 4 * D.slots) {
+        P = (8 * D.slots + ptiles - 1) / ptiles;
+        P = std::max(1, std::min(P, D.ntiles / (4 * 64)));
+    }
+    float4* part = nullptr;
+    if (P > 1) {
+        const size_t need = (size_t)P * Npix;
+        if (D.part_cap < need) {
+            if (D.d_part) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); QMRI_HIP(ctx, hipFree(D.d_part)); D.d_part = nullptr; D.part_cap = 0; }
+            QMRI_HIP(ctx, hipMalloc((void**)&D.d_part, need * sizeof(float4)));
+            D.part_cap = need;
+        }
+        part = D.d_part;
+    }
+    dim3 grid(ptiles, P), blk(NT);
 #define LAUNCH(NP)                                                                                                    \
     k_dict_match<NP><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q, \
-                                                    d_qmap, d_pd, d_mt, d_dm)
+                                                    d_qmap, d_pd, d_mt, d_dm, part)
     switch (npair) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -152,12 +239,13 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
         case 5: LAUNCH(5); break;
         case 6: LAUNCH(6); break;
         case 7: LAUNCH(7); break;
-        case 8: LAUNCH(8); break;
-        default:
-            qmri_set_error(ctx, "dictionary match supports s <= %d channels (got %d)", 2 * MAXPAIR, D.s);
-            return QMRI_ERR_UNSUPPORTED;
+        default: LAUNCH(8); break;
     }
 #undef LAUNCH
     QMRI_HIP(ctx, hipGetLastError());
+    if (P > 1) {
+        k_dict_merge<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(part, P, Npix, D.K, D.d_normD, D.d_lut, D.Q, d_qmap, d_pd, d_mt, d_dm);
+        QMRI_HIP(ctx, hipGetLastError());
+    }
     return QMRI_OK;
 }

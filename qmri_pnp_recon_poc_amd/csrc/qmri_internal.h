@@ -224,7 +224,8 @@ struct DictHost {
     int K = 0, s = 0, Q = 0, ntiles = 0;
     float* d_pack = nullptr;            // [ntiles][npair][64] MFMA A-fragments
     float* d_normD = nullptr; float* d_lut = nullptr;
-    float* d_best = nullptr; int32_t* d_bidx = nullptr;   // workspaces
+    float4* d_part = nullptr; size_t part_cap = 0;        // (|ip|, atom index, re, im) per (atom part, pixel) when the atoms are split over workgroups
+    int slots = 0;                                        // workgroups of k_dict_match the device holds at once (occupancy query, first launch)
 };
 
 struct qmri_ctx {
