@@ -3,7 +3,7 @@
 the script prints -- so that someone holding the reference's data files gets the script's numbers from this engine.
 Host logic in numpy/scipy; the reconstruction and the match run on the GPU through `reference_api`.
 
-  load_mat(path)                       `load(...)` of a MATLAB v5/v7 file (scipy.io); v7.3 (HDF5) needs re-saving with '-v7'
+  load_mat(path)                       `load(...)` of a MATLAB file: v5/v7 (scipy.io) or -v7.3 (HDF5; mat73.py, no HDF5 library needed)
   load_dictionary(path)                `load(dict_dir); V = real(dict.V)`                     main_recon_tsmis_FFT.m:121-130
   load_tsmi(path) / crop_tsmi(X)       `load(tsmi_dir); X0 = X((4:227),(4:227),:)`            :199-212
   load_qmaps(path, slice)              qmap(slice,:,:,:) -> N x M x 3, cropped the same way   :177-189
@@ -35,12 +35,13 @@ CROP = slice(3, 227)          # MATLAB (4:227): 230 -> 224                      
 # files
 # ------------------------------------------------------------------------------------------------------------
 def load_mat(path):
-    """dict of the variables in a MATLAB v5/v7 file; structs become objects with attribute access."""
+    """dict of the variables in a MATLAB file; structs become objects with attribute access.  v5 / v7 files go through scipy.io,
+    -v7.3 files (HDF5 containers) through the dependency-free reader in mat73.py -- same shapes, same squeezing."""
+    from . import mat73
+    if mat73.is_mat73(path):
+        return mat73.load_mat73(path, squeeze_me=True)
     import scipy.io
-    try:
-        return {k: v for k, v in scipy.io.loadmat(path, squeeze_me=True, struct_as_record=False).items() if not k.startswith("__")}
-    except NotImplementedError as e:                          # scipy: "Please use HDF reader for matlab v7.3 files"
-        raise ValueError(f"{path} is a MATLAB v7.3 (HDF5) file; re-save it with save(..., '-v7')") from e
+    return {k: v for k, v in scipy.io.loadmat(path, squeeze_me=True, struct_as_record=False).items() if not k.startswith("__")}
 
 
 def load_dictionary(path):
