@@ -54,6 +54,9 @@ def audit(lines, name):
             pending.append((i, regs(t.split()[1].rstrip(','))))
             nload += 1
             continue
+        if t.startswith('global_store') or t.startswith('buffer_store'):
+            pending.append((i, []))          # stores take a place in the in-order vmcnt queue (no destination registers)
+            continue
         if inasm and t.startswith('s_waitcnt vmcnt'):
             n = int(re.search(r'vmcnt\((\d+)\)', t).group(1))
             pending = pending[-n:] if n > 0 else []
