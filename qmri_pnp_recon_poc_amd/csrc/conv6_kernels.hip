@@ -1890,7 +1890,10 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     // once per tile (16 x 14 MB); instead keep the 256-pixel tile and split K over workgroups, then add the partial
     // outputs in slice order (deterministic) in a second, elementwise kernel.
     static const bool splitk_on = !(getenv("QMRI_CONV_SPLITK") && atoi(getenv("QMRI_CONV_SPLITK")) == 0);
-    static const int mid_cfg = getenv("QMRI_CONV_MIDCFG") ? atoi(getenv("QMRI_CONV_MIDCFG")) : 1;   // 56 x 56 level: tile config of the split-K variant (0, 1), 2 = no split
+    // 56 x 56 level: tile config of the split-K variant (0, 1), 2 = no split.  With blocked tensors the unsplit 64-pixel tiles (196
+    // workgroups x 48 steps, no reduce launch) win: 696 vs 672 ADMM it/s on one box (round 2; with planar tensors split-K = 2 on
+    // 128-pixel tiles + a reduce kernel was the faster form)
+    static const int mid_cfg = getenv("QMRI_CONV_MIDCFG") ? atoi(getenv("QMRI_CONV_MIDCFG")) : 2;
     if (splitk_on && L.nchunk6 >= 16) {
         // candidate: the 256-pixel tile (28 x 28 level) or the 128-pixel tile (56 x 56 level), K split so that about one
         // workgroup per CU results and every workgroup still walks >= 4 chunks
