@@ -1897,10 +1897,17 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     if (splitk_on && L.nchunk6 >= 16) {
         // candidate: the 256-pixel tile (28 x 28 level) or the 128-pixel tile (56 x 56 level), K split so that about one
         // workgroup per CU results and every workgroup still walks >= 4 chunks
-        const int cfg = (in.H <= 32) ? 0 : mid_cfg;
-        const long nt = (cfg == 0) ? ntiles(16, 16) : ntiles(16, 8);
+        // 28 x 28 level: tile config and largest K split.  Measured with blocked tensors on one box (ADMM it/s, two runs each):
+        // 256-pixel tiles x 8 slices (the round-1 choice) 701.6 | x 4: 695 | 128-pixel x 4: 715 | x 2: 695 | 64-pixel x 2: 717.6 | x 1: 679
+        static const int deep_cfg = getenv("QMRI_CONV_DEEPCFG") ? atoi(getenv("QMRI_CONV_DEEPCFG")) : 2;
+        static const int deep_ks = getenv("QMRI_CONV_DEEPKS") ? atoi(getenv("QMRI_CONV_DEEPKS")) : 2;
+        const bool deep = in.H <= 32;
+        const int cfg = deep ? deep_cfg : mid_cfg;
+        const long nt = (cfg == 0) ? ntiles(16, 16) : (cfg == 1) ? ntiles(16, 8) : ntiles(8, 8);
         int ksplit = 1;
-        while (cfg < 2 && ksplit * 2 * nt <= 256 && L.nchunk6 % (ksplit * 2) == 0 && L.nchunk6 / (ksplit * 2) >= 4) ksplit *= 2;
+        while ((deep || cfg < 2) && ksplit * 2 * nt <= 256 && ksplit * 2 <= (deep ? deep_ks : 8) && L.nchunk6 % (ksplit * 2) == 0 &&
+               L.nchunk6 / (ksplit * 2) >= 4)
+            ksplit *= 2;
         if (ksplit > 1 && in.H <= 64) {
             const long out_ks = (long)B * out.Cal * out.plane();
             const size_t need = (size_t)ksplit * out_ks + 8192;
@@ -1911,7 +1918,8 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
                 net.c6part_floats = need;
             }
             if (cfg == 0) QMRI_TRY(launch6<0>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
-            else QMRI_TRY(launch6<1>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            else if (cfg == 1) QMRI_TRY(launch6<1>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            else QMRI_TRY(launch6<2>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
             const long total = (long)B * L.Cout * in.H * in.W;
             const bool vec = in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
                              (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp));
