@@ -272,3 +272,43 @@ def test_low_magnitude_mid_layer_trips_the_guard_and_stays_fp32_accurate(engine_
     assert np.abs(yo).max() > 1e-4 and err < 1e-5
     assert e.denoiser_scheme() == (3, 1)                            # the low-magnitude guard moved the network to bf16 x 6, once
     e.close()
+
+
+def _unet_nparams(in_nc, out_nc, nc, nb):
+    n = nc[0] * in_nc * 9
+    for l in range(3): n += 2 * nb * nc[l] * nc[l] * 9 + nc[l + 1] * nc[l] * 4
+    n += 2 * nb * nc[3] * nc[3] * 9
+    for l in (3, 2, 1): n += nc[l] * nc[l - 1] * 4 + 2 * nb * nc[l - 1] * nc[l - 1] * 9
+    return n + out_nc * nc[0] * 9
+
+
+@pytest.mark.parametrize("nc,hw", [((12, 20, 36, 68), (32, 32)), ((16, 24, 40, 72), (40, 24)), ((8, 16, 32, 64), (24, 40))],
+                         ids=["planar_tensors_channels_not_x8", "blocked_channels_x8_not_x16", "blocked_ragged_tiles"])
+def test_unetres_tensor_formats(engine_mod, oracle, synth, nc, hw):
+    """Interior tensors are BLOCKED ([c/8][w][h][8]) when every interior channel count is a multiple of 8 and planar otherwise
+    (DESIGN.md section 4): both regimes, channel counts that are no multiple of the 16-channel chunk or of the 64-row tile, and
+    images that are no multiple of the pixel tiles, against the oracle."""
+    H, W = hw
+    nb = 1
+    n = _unet_nparams(10, 10, nc, nb)
+    w = ((synth.uniform01(21, n) - 0.5) * 0.3).astype(np.float32)
+    x = synth.uniform01(22, H * W * 10).reshape(H, W, 10)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, H, W, in_nc=10, out_nc=10, nc=nc, nb=nb, max_batch=3)
+    yo = oracle.Net(w, in_nc=10, out_nc=10, nc=nc, nb=nb).denoise(x)
+    assert rel_err(e.denoise(x), yo) < 2e-5
+    xs = np.stack([x, x[::-1].copy(), 0.5 * x], axis=3)
+    yb = e.denoise(xs)                                           # (a batch: more tiles than one launch shape)
+    assert rel_err(yb[..., 1], oracle.Net(w, in_nc=10, out_nc=10, nc=nc, nb=nb).denoise(xs[..., 1])) < 2e-5
+    e.close()
+
+
+def test_seq_conv_width_not_multiple_of_8_runs_planar(engine_mod, oracle, synth):
+    nb, width = 4, 20
+    n = width * 10 * 9 + (nb - 2) * width * width * 9 + 10 * width * 9
+    w = ((synth.uniform01(23, n) - 0.5) * 0.3).astype(np.float32)
+    x = synth.uniform01(24, 36 * 28 * 10).reshape(36, 28, 10)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 36, 28, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1)
+    assert rel_err(e.denoise(x), oracle.Net(w, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1).denoise(x)) < 1e-5
+    e.close()
