@@ -547,8 +547,8 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
         tm.start();
-        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.d_vv,
-                                            o.d_z, o.ls.pz, o.ls.nblk_z));
+        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u,
+                                            nullptr /* v itself is never read again: z = v - u goes to the next x-update */, o.d_z, o.ls.pz, o.ls.nblk_z));
         tm.stop(ctx->prof.ms_elementwise);
         ctx->prof.admm_iters += 1;
     }

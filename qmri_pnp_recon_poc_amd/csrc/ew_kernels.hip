@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, int plane, in
         uv.x = uv.x + xv.x - vv;
         uv.y = uv.y + xv.y - 0.0;
         u[(size_t)b * n + i] = uv;
-        v[(size_t)b * n + i] = make_double2(vv, 0.0);
+        if (v) v[(size_t)b * n + i] = make_double2(vv, 0.0);      // (the ADMM loop passes no v: nothing reads it after the first iteration's z)
         const double2 zz = make_double2(vv - uv.x, 0.0 - uv.y);
         z[(size_t)b * n + i] = zz;
         acc += zz.x * zz.x + zz.y * zz.y;
