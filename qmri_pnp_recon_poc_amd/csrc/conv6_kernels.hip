@@ -171,6 +171,14 @@ template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], BRegs<fals
                  : "n"(N)
                  : "memory");
 }
+// the small tiles (128 / 64 pixels) need only ONE half-item per loader thread and step
+struct BRegs1 { f32x4 q[1]; };
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], BRegs1& b) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b.q[0]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], BRegs1& b) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b.q[0]) : "n"(N) : "memory");
+}
 template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], BRegs<true>& b) {
     asm volatile("s_waitcnt vmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b.q[0]), "+v"(b.q[1]) : "n"(N) : "memory");
 }
@@ -280,8 +288,13 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);          // ... per loader thread and step (a chunk is spread over its 3 steps)
     constexpr int NAQ = (AST + NLD6 - 1) / NLD6;                    // uint4 of A per loader thread and step
     static_assert(((SP == 3 && NAQ == 5) || (SP == 2 && NAQ == 3)) && NBQ == 1, "gwait() is written for 5 / 3 loads of A and one item of B per step");
-    constexpr int NBL = INB ? 2 : 8;                                // requests per item of B (BRegs)
+    // BLOCKED: half-items (16 bytes) per loader thread and step -- 2 * NBI of them per chunk over 3 steps x 256 threads: two on the
+    // 256-pixel tile, one on the smaller ones (a request costs a loader wave ~0.05 us whether its lanes carry data or repeats)
+    constexpr int NBH = (2 * NBI + 3 * NLD6 - 1) / (3 * NLD6);
+    static_assert(NBH == 1 || NBH == 2, "half-items per step");
+    constexpr int NBL = INB ? NBH : 8;                              // requests per step of B
     constexpr int NLOAD = NAQ + NBL;                                // vector-memory loads a loader thread issues per step
+    typedef typename std::conditional<INB && NBH == 1, BRegs1, BRegs<INB>>::type BR;
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
     constexpr int PXT = TH * TW, PP = PXT + 4;                      // output tile in LDS: [64 cout][PP], aliases the B buffers
@@ -319,10 +332,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
             if constexpr (INB) {
-                // half-items: half (lt & 1) of items part * 256 + (lt >> 1) and + 128
+                // half-items part * 256 NBH + 256 q + lt: half (lt & 1) of item (part NBH + q) * 128 + (lt >> 1)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    int item = part * (NBQ * NLD6) + (lt >> 1) + (NLD6 / 2) * q;
+                for (int q = 0; q < NBH; ++q) {
+                    int item = (part * NBH + q) * (NLD6 / 2) + (lt >> 1);
                     if (item >= NBI) item = 0;
                     const int h2 = item / NLP, px = item - h2 * NLP;
                     const int dw = px / IH, dh = px - dw * IH;
@@ -341,7 +354,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             }
         }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
-        BRegs<INB> rb0, rb1, rb2;
+        BR rb0, rb1, rb2;
         // Schedule.  Barrier g precedes compute step g.  Abuf[(g+1)&1] is free once step g-1 is over, i.e. after barrier g:
         // iteration g (between barriers g and g+1) stores A(g+1).  Bbuf[(c+1)&1] is free once chunk c-1 is over, i.e. after
         // barrier 3c: iterations 3c, 3c+1, 3c+2 store the three parts of B(c+1).  What an iteration stores was requested
@@ -360,12 +373,12 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
             const unsigned so_ = ibase + (unsigned)(((c_) < A.nchunk) ? (c_) : A.nchunk - 1) * chunkB;           \
-            if constexpr (INB) { bload4f(rb_.q[0], boff[part_][0], srdI, so_); bload4f(rb_.q[1], boff[part_][1], srdI, so_); } \
+            if constexpr (INB) { _Pragma("unroll") for (int q = 0; q < NBH; ++q) bload4f(rb_.q[q], boff[part_][q], srdI, so_); } \
             else { _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_.v[j], boff[part_][j], srdI, so_); }  \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
         if constexpr (INB) {                                                                                     \
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+            _Pragma("unroll") for (int q = 0; q < NBH; ++q) {                                                    \
                 unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_][q];       \
                 uint2 s0, s1, s2;                /* 4 channels = 8 bytes of a 16-byte entry */                    \
                 if constexpr (SP == 3) {                                                                         \
@@ -404,7 +417,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         C6_STAMP(2, 0);
         {
             u32x4 pa1[NAQ], pa2[NAQ];
-            BRegs<INB> pb1, pb2;
+            BR pb1, pb2;
             LOAD_A(0, ra0) LOAD_B(0, 0, rb0)
             LOAD_A(1, pa1) LOAD_B(0, 1, pb1)
             LOAD_A(1, pa2) LOAD_B(0, 2, pb2)                        // (A again: keeps the request count per batch uniform)
