@@ -81,16 +81,21 @@ struct Conv6Args {
 // 8h x 4w (stacked in h); wave_map gives its first pixel block and first cout tile.
 template <int CFG> struct Cfg6;
 template <> struct Cfg6<0> {     // 256 px, waves side by side in w, 64 cout x 64 px each
-    static constexpr int TH = 16, TW = 16, MW = 2, NCT = 2;
+    static constexpr int TH = 16, TW = 16, MW = 2, NCT = 2, MH = 1;
     static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 0; pbw = 4 * wave; m0 = 0; }
 };
 template <> struct Cfg6<1> {     // 128 px, waves 2 x 2, 64 cout x 32 px each
-    static constexpr int TH = 16, TW = 8, MW = 2, NCT = 1;
+    static constexpr int TH = 16, TW = 8, MW = 2, NCT = 1, MH = 1;
     static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 8 * (wave & 1); pbw = 4 * (wave >> 1); m0 = 0; }
 };
 template <> struct Cfg6<2> {     // 64 px, waves = 2 cout halves x 2 pixel blocks, 32 cout x 32 px each
-    static constexpr int TH = 8, TW = 8, MW = 1, NCT = 1;
+    static constexpr int TH = 8, TW = 8, MW = 1, NCT = 1, MH = 1;
     static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 0; pbw = 4 * (wave >> 1); m0 = wave & 1; }
+};
+template <> struct Cfg6<3> {     // 128 px x 32 cout: the workgroup takes ONE 32-row half (MH = 2 workgroups per 64-row tile) of the weights --
+                                 // half the weight bytes per MFMA of the 64-pixel tile, for the deep levels where the step is bound by them
+    static constexpr int TH = 16, TW = 8, MW = 1, NCT = 1, MH = 2;
+    static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 8 * (wave & 1); pbw = 4 * (wave >> 1); m0 = 0; }
 };
 constexpr int NABUF = 3;         // LDS buffers of A (one step each): step g lives in buffer g % 3 = its kh; a step's weights are complete one
                                  // barrier before the step starts, so the MFMA waves can request its first fragments across that barrier
@@ -173,6 +178,15 @@ template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], BRegs<fals
 }
 // the small tiles (128 / 64 pixels) need only ONE half-item per loader thread and step
 struct BRegs1 { f32x4 q[1]; };
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[2], BRegs1& b) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b.q[0]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[2], BRegs<false>& b) {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.v[4]), "+v"(b.v[5]), "+v"(b.v[6]), "+v"(b.v[7])
+                 : "n"(N)
+                 : "memory");
+}
 template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[5], BRegs1& b) {
     asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b.q[0]) : "n"(N) : "memory");
 }
@@ -278,7 +292,7 @@ template <int CFG, int SP, bool STAMP, bool INB>
 __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int AST = ast6(SP);
     typedef Cfg6<CFG> C;
-    constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT;
+    constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT, MH = C::MH;
     constexpr int IH = TH + 2, IW = TW + 2;                         // input tile with halo
     constexpr int IHP = ((IH + 7) / 16) * 16 + 8;                   // its LDS row pitch, = 8 mod 16 entries: conflict-free ds_read_b128 of 8h x 4w blocks
     constexpr int NPX = IHP * (IW - 1) + IH;                        // LDS entries per (split, k-half) plane (the last row is not padded)
@@ -286,8 +300,9 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     static_assert(IHP >= IH, "row pitch");
     constexpr int NBI = 2 * NLP;                                    // loader items of one chunk of B: (k-half, pixel)
     constexpr int NBQ = (NBI + 3 * NLD6 - 1) / (3 * NLD6);          // ... per loader thread and step (a chunk is spread over its 3 steps)
-    constexpr int NAQ = (AST + NLD6 - 1) / NLD6;                    // uint4 of A per loader thread and step
-    static_assert(((SP == 3 && NAQ == 5) || (SP == 2 && NAQ == 3)) && NBQ == 1, "gwait() is written for 5 / 3 loads of A and one item of B per step");
+    constexpr int ASTH = AST / MH;                                  // uint4 of A this workgroup needs per step (its 32-row half, or all)
+    constexpr int NAQ = (ASTH + NLD6 - 1) / NLD6;                   // ... per loader thread
+    static_assert((NAQ == 5 || NAQ == 3 || NAQ == 2) && NBQ == 1, "gwait() is written for 5 / 3 / 2 loads of A and one item of B per step");
     // BLOCKED: half-items (16 bytes) per loader thread and step -- 2 * NBI of them per chunk over 3 steps x 256 threads: two on the
     // 256-pixel tile, one on the smaller ones (a request costs a loader wave ~0.05 us whether its lanes carry data or repeats)
     constexpr int NBH = (2 * NBI + 3 * NLD6 - 1) / (3 * NLD6);
@@ -305,6 +320,8 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     static_assert(SP == 3 ? (64 * PP * 4 <= 2 * 3 * 2 * NPX * 16) : (64 * PP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "output tile must fit the operand buffers");
     const int tid = threadIdx.x;
     int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int mh = (MH > 1) ? bid % MH : 0;                         // which 32-row half of the 64-row tile (MH = 2)
+    if (MH > 1) bid /= MH;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
     const int th = bid % A.tiles_h; bid /= A.tiles_h;
     const int tw = bid % A.tiles_w; bid /= A.tiles_w;
@@ -328,7 +345,12 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                                    : (unsigned)(((size_t)b * A.in_bs + (size_t)ks * A.nchunk * CK * A.in_plane + (size_t)ow0 * A.in_hp + oh0) * 4);
         unsigned aoff[NAQ], boff[3][INB ? 2 : 8], ldsB[3][INB ? 2 : 1];   // loop-invariant byte offsets of this thread's requests / LDS stores
 #pragma unroll
-        for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; aoff[q] = (unsigned)(((i < AST) ? i : 0) * 16); }
+        for (int q = 0; q < NAQ; ++q) {                             // entry index in the step's A layout ((kw 2 + m) SP + sp) 64 + lane
+            int j = lt + NLD6 * q;
+            if (j >= ASTH) j = 0;
+            if (MH > 1) { const int kw = j / (SP * 64); j += (kw + mh) * (SP * 64); }     // the entries with m == mh
+            aoff[q] = (unsigned)(j * 16);
+        }
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
             if constexpr (INB) {
@@ -368,7 +390,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #define STORE_A(buf_, ra_)     /* buf_ = step % NABUF, a compile-time constant; surplus threads repeat entry 0 (clamped request) */ \
         {                                                                                                        \
             uint4* ad = Abuf + (buf_) * AST;                                                                     \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) { const int i = lt + NLD6 * q; ad[(i < AST) ? i : 0] = __builtin_bit_cast(uint4, ra_[q]); } \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) *(uint4*)((unsigned char*)ad + aoff[q]) = __builtin_bit_cast(uint4, ra_[q]); \
         }
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
@@ -465,6 +487,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h2 = lane >> 5;
     int pbh, pbw, m0;
     C::wave_map(wave, pbh, pbw, m0);
+    m0 += mh;                                                       // (MH = 2: this workgroup's half of the 64-row tile)
     const int pxl = (pbw + (li >> 3)) * IHP + pbh + (li & 7);       // LDS entry of this lane's pixel at tap (0,0), pixel block 0
     f32x16 acc[MW][NCT];
     f32x16 accl[SP == 2 ? MW : 1][SP == 2 ? NCT : 1];              // f16 scheme: the cross terms hi*lo' + lo'*hi, 2^11 too large
@@ -593,7 +616,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
                 const int g = e / PXT, px = e - g * PXT, w = px / TH, h = px - w * TH;
                 const int cb = ct * 8 + g, oh = oh0 + h, ow = ow0 + w;
-                const bool ok = cb * 8 < A.Cout && oh < A.H && ow < A.W;
+                const bool ok = cb * 8 < A.Cout && oh < A.H && ow < A.W && (MH == 1 || (g >> 2) == mh);   // (MH = 2: only this workgroup's four blocks)
                 off[k] = ok ? (unsigned)(((size_t)cb * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) * 8 + 4 * half) : ~0u;
                 r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
             }
@@ -633,7 +656,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 const int e = k * NT6 + tid;
                 const int co = e / (PXT / 4), rem = e - co * (PXT / 4), w = rem / (TH / 4), h = 4 * (rem - w * (TH / 4));
                 const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
-                const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
+                const bool ok = cog < A.Cout && oh < A.H && ow < A.W && (MH == 1 || (co >> 5) == mh);
                 off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
                 r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
             }
@@ -669,7 +692,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 const int e = k * NT6 + tid;
                 const int co = e / PXT, rem = e - co * PXT, w = rem / TH, h = rem - w * TH;
                 const int cog = ct * 64 + co, oh = oh0 + h, ow = ow0 + w;
-                const bool ok = cog < A.Cout && oh < A.H && ow < A.W;
+                const bool ok = cog < A.Cout && oh < A.H && ow < A.W && (MH == 1 || (co >> 5) == mh);
                 off[k] = ok ? (unsigned)((size_t)cog * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) : ~0u;
                 r1[k] = 0.f; r2[k] = 0.f;
             }
@@ -1466,7 +1489,7 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->conv6_attr[CFG][SP - 2] = true;
     }
-    const int grid = A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
+    const int grid = C::MH * A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));                  // (profile level 2 only)
     if constexpr (SP == 2 && CFG < 2) {
@@ -1907,18 +1930,19 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     // workgroups x 48 steps, no reduce launch) win: 696 vs 672 ADMM it/s on one box (round 2; with planar tensors split-K = 2 on
     // 128-pixel tiles + a reduce kernel was the faster form)
     static const int mid_cfg = getenv("QMRI_CONV_MIDCFG") ? atoi(getenv("QMRI_CONV_MIDCFG")) : 2;
+    static const int deep_cfg_g = getenv("QMRI_CONV_DEEPCFG") ? atoi(getenv("QMRI_CONV_DEEPCFG")) : 2;   // (28 x 28 level, see below)
     if (splitk_on && L.nchunk6 >= 16) {
         // candidate: the 256-pixel tile (28 x 28 level) or the 128-pixel tile (56 x 56 level), K split so that about one
         // workgroup per CU results and every workgroup still walks >= 4 chunks
         // 28 x 28 level: tile config and largest K split.  Measured with blocked tensors on one box (ADMM it/s, two runs each):
         // 256-pixel tiles x 8 slices (the round-1 choice) 701.6 | x 4: 695 | 128-pixel x 4: 715 | x 2: 695 | 64-pixel x 2: 717.6 | x 1: 679
-        static const int deep_cfg = getenv("QMRI_CONV_DEEPCFG") ? atoi(getenv("QMRI_CONV_DEEPCFG")) : 2;
+        const int deep_cfg = deep_cfg_g;
         static const int deep_ks = getenv("QMRI_CONV_DEEPKS") ? atoi(getenv("QMRI_CONV_DEEPKS")) : 2;
         const bool deep = in.H <= 32;
         const int cfg = deep ? deep_cfg : mid_cfg;
-        const long nt = (cfg == 0) ? ntiles(16, 16) : (cfg == 1) ? ntiles(16, 8) : ntiles(8, 8);
+        const long nt = (cfg == 0) ? ntiles(16, 16) : (cfg == 1) ? ntiles(16, 8) : (cfg == 2) ? ntiles(8, 8) : 2 * ntiles(16, 8);
         int ksplit = 1;
-        while ((deep || cfg < 2) && ksplit * 2 * nt <= 256 && ksplit * 2 <= (deep ? deep_ks : 8) && L.nchunk6 % (ksplit * 2) == 0 &&
+        while ((deep || cfg < 2) && cfg >= 0 && ksplit * 2 * nt <= 256 && ksplit * 2 <= (deep ? deep_ks : 8) && L.nchunk6 % (ksplit * 2) == 0 &&
                L.nchunk6 / (ksplit * 2) >= 4)
             ksplit *= 2;
         if (ksplit > 1 && in.H <= 64) {
@@ -1932,7 +1956,8 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             }
             if (cfg == 0) QMRI_TRY(launch6<0>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
             else if (cfg == 1) QMRI_TRY(launch6<1>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
-            else QMRI_TRY(launch6<2>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            else if (cfg == 2) QMRI_TRY(launch6<2>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
+            else QMRI_TRY(launch6<3>(ctx, L, B, in, out, nullptr, nullptr, 0, ksplit, net.d_c6part, out_ks));
             const long total = (long)B * L.Cout * in.H * in.W;
             const bool vec = in.H % 4 == 0 && out.h0 % 4 == 0 && out.hp % 4 == 0 && (!add1 || (add1->h0 == out.h0 && add1->hp == out.hp)) &&
                              (!add2 || (add2->h0 == out.h0 && add2->hp == out.hp));
@@ -1958,5 +1983,6 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             return QMRI_OK;
         }
     }
+    if (L.nchunk6 >= 16 && L.Cout % 64 == 0 && ((in.H <= 32) ? deep_cfg_g : mid_cfg) == 3) return launch6<3>(ctx, L, B, in, out, add1, add2, relu_out);
     return launch6<2>(ctx, L, B, in, out, add1, add2, relu_out);
 }

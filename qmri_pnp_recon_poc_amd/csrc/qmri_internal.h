@@ -245,7 +245,7 @@ struct qmri_ctx {
     // without putting extra packets between dependent kernels (event records in the stream add 3-5 us per kernel)
     std::vector<hipEvent_t> chain;      // pairs: [2i] start, [2i+1] stop
     size_t chain_n = 0;                 // events handed out in the current forward
-    bool conv6_attr[3][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
+    bool conv6_attr[4][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
