@@ -1929,15 +1929,20 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     // 56 x 56 level: tile config of the split-K variant (0, 1), 2 = no split.  With blocked tensors the unsplit 64-pixel tiles (196
     // workgroups x 48 steps, no reduce launch) win: 696 vs 672 ADMM it/s on one box (round 2; with planar tensors split-K = 2 on
     // 128-pixel tiles + a reduce kernel was the faster form)
-    static const int mid_cfg = getenv("QMRI_CONV_MIDCFG") ? atoi(getenv("QMRI_CONV_MIDCFG")) : 2;
-    static const int deep_cfg_g = getenv("QMRI_CONV_DEEPCFG") ? atoi(getenv("QMRI_CONV_DEEPCFG")) : 2;   // (28 x 28 level, see below)
+    // (3 = 128 pixels x 32 output channels, two workgroups per 64-row weight tile: half the weight bytes through LDS per MFMA of the
+    //  64-pixel tile -- these levels' steps are bound by LDS traffic, 4 fragment reads per 3 MFMAs and a full weight step written per
+    //  9 MFMAs of a wave: 743 -> 756 ADMM it/s with 3 / 3 / K over 4.  Measured and not kept on the way: one barrier per chunk instead
+    //  of per step (six A buffers, whole chunks requested two ahead): 18.3 vs 18.2 us per launch, the barriers are not the bound.)
+    static const int mid_cfg = getenv("QMRI_CONV_MIDCFG") ? atoi(getenv("QMRI_CONV_MIDCFG")) : 3;
+    static const int deep_cfg_g = getenv("QMRI_CONV_DEEPCFG") ? atoi(getenv("QMRI_CONV_DEEPCFG")) : 3;   // (28 x 28 level, see below)
     if (splitk_on && L.nchunk6 >= 16) {
         // candidate: the 256-pixel tile (28 x 28 level) or the 128-pixel tile (56 x 56 level), K split so that about one
         // workgroup per CU results and every workgroup still walks >= 4 chunks
         // 28 x 28 level: tile config and largest K split.  Measured with blocked tensors on one box (ADMM it/s, two runs each):
-        // 256-pixel tiles x 8 slices (the round-1 choice) 701.6 | x 4: 695 | 128-pixel x 4: 715 | x 2: 695 | 64-pixel x 2: 717.6 | x 1: 679
+        // 256-pixel tiles x 8 slices (the round-1 choice) 701.6 | x 4: 695 | 128-pixel x 4: 715 | x 2: 695 | 64-pixel x 2: 717.6 | x 1: 679;
+        // then, on another box: 64-pixel x 2 (and 64-pixel unsplit at 56 x 56) 743 | configuration 3 at both levels, K over 2: 751.6 | over 4: 756
         const int deep_cfg = deep_cfg_g;
-        static const int deep_ks = getenv("QMRI_CONV_DEEPKS") ? atoi(getenv("QMRI_CONV_DEEPKS")) : 2;
+        static const int deep_ks = getenv("QMRI_CONV_DEEPKS") ? atoi(getenv("QMRI_CONV_DEEPKS")) : 4;
         const bool deep = in.H <= 32;
         const int cfg = deep ? deep_cfg : mid_cfg;
         const long nt = (cfg == 0) ? ntiles(16, 16) : (cfg == 1) ? ntiles(16, 8) : (cfg == 2) ? ntiles(8, 8) : 2 * ntiles(16, 8);
