@@ -11,6 +11,15 @@ constexpr int DC_MAXS = 10;      // channel lines the w-pass kernels hold in LDS
 constexpr int DC_VCAP = 2048;    // doubles of V kept in LDS by the w-pass kernels (T*s <= 2048, e.g. T = 200, s = 10)
 constexpr int DC_CH = 512;       // samples of a k-row staged in LDS at a time by the adjoint scatter
 
+// Write-through (sc1) store of one complex double.  A plain store leaves its line dirty in the XCD's L2 and the kernel boundary then
+// writes all of them back before the next (dependent) kernel starts (+ B / 6 TB/s, MI355X_MICROARCH.md price list, row "boundary");
+// a write-through store sends the bytes while other workgroups still compute.  Every kernel here hands its output to another launch.
+__device__ __forceinline__ void st_wt(double2* p, double2 v) {
+    typedef double d2v_ __attribute__((ext_vector_type(2)));
+    const d2v_ t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it stalls until every global
 // store the wave has issued is acknowledged; the kernels here never communicate through global memory inside a
 // block, so their stores are left in flight.

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(NT) void k_fwd_h(OpDev op, const double2* __restric
         const int c = l / op.M, w = l - c * op.M;
         double2* dst = tmp + (size_t)b * n + (size_t)c * N * op.M + w;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) dst[(size_t)(k1 + R1 * k2) * op.M] = out[k2];
+        for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + (size_t)(k1 + R1 * k2) * op.M, out[k2]);
     }
 }
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT) void k_fwd_w(OpDev op, LsqrDev ls, const double
         if (act2) {
             double2* dst = y_out + (size_t)b * n + ((size_t)line2 * N + kh) * M;   // y_out doubles as tmp here
 #pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) dst[k1 + R1 * k2] = out[k2];
+            for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + k1 + R1 * k2, out[k2]);
         }
         return;
     }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NT) void k_fwd_w(OpDev op, LsqrDev ls, const double
         for (int i = tid; i < s * M; i += NT) {
             const int c = i / M, w = i - c * M;
             const cd z = lds[c * P::LINE + w];
-            y_out[(size_t)b * n + ((size_t)c * N + kh) * M + w] = make_double2(z.x * sc, z.y * sc);
+            st_wt(y_out + (size_t)b * n + ((size_t)c * N + kh) * M + w, make_double2(z.x * sc, z.y * sc));
         }
         return;
     }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NT) void k_adj_w(OpDev op, const double2* __restric
     if (fft_lds<R1, R2, false>(lds, s, op.tw, out, line2, k1)) {
         double2* dst = tmp + (size_t)b * n + ((size_t)line2 * N + kh) * M;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) dst[k1 + R1 * k2] = out[k2];
+        for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + k1 + R1 * k2, out[k2]);
     }
 }
 
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NT) void k_adj_h(OpDev op, const double2* __restric
         const double sc = 1.0 / sqrt((double)N * (double)M);
         const size_t g0 = (size_t)b * n + (size_t)(l0 + line2) * N;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) dst[g0 + k1 + R1 * k2] = make_double2(out[k2].x * sc, -out[k2].y * sc);
+        for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + g0 + k1 + R1 * k2, make_double2(out[k2].x * sc, -out[k2].y * sc));
     }
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT) void k_prepare_z(LsqrDev ls, size_t n, const do
     for (size_t i = i0 + threadIdx.x; i < i1; i += NT) {
         const double2 a = v[(size_t)b * n + i], c = u[(size_t)b * n + i];
         const double2 zz = make_double2(a.x - c.x, a.y - c.y);
-        z[(size_t)b * n + i] = zz;
+        st_wt(z + (size_t)b * n + i, zz);
         acc += zz.x * zz.x + zz.y * zz.y;
     }
     const double tot = block_sum(acc, red);

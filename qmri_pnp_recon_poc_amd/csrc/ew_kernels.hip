@@ -12,6 +12,15 @@
 #include "qmri_internal.h"
 
 namespace {
+// write-through store (see dc_device.h: the output goes to another launch; nothing dirty is left for the kernel boundary)
+__device__ __forceinline__ void st_wt(double2* p, double2 v) {
+    typedef double d2v_ __attribute__((ext_vector_type(2)));
+    const d2v_ t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+}  // namespace
+
+namespace {
 
 constexpr int NT = 256;
 
@@ -122,10 +131,10 @@ __global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, int plane, in
         double2 uv = u[(size_t)b * n + i];
         uv.x = uv.x + xv.x - vv;
         uv.y = uv.y + xv.y - 0.0;
-        u[(size_t)b * n + i] = uv;
+        st_wt(u + (size_t)b * n + i, uv);
         if (v) v[(size_t)b * n + i] = make_double2(vv, 0.0);      // (the ADMM loop passes no v: nothing reads it after the first iteration's z)
         const double2 zz = make_double2(vv - uv.x, 0.0 - uv.y);
-        z[(size_t)b * n + i] = zz;
+        st_wt(z + (size_t)b * n + i, zz);
         acc += zz.x * zz.x + zz.y * zz.y;
     }
     // block total in the order of dc_kernels.hip's block_sum (shuffle tree, then the waves in order)

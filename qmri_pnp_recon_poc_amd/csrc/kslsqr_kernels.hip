@@ -467,7 +467,7 @@ __global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* 
             const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
             const double2 val = (slot[q] >= 0) ? cxv[q]
                                                : make_double2(xv[q].x + ue * (zv[q].x - xv[q].x), xv[q].y + ue * (zv[q].y - xv[q].y));
-            ks.xhat_out[g] = val;
+            st_wt(ks.xhat_out + g, val);
             lds[c * P::LINE + kw] = val;
         }
     }
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* 
     if (fft_lds<R1, R2, false>(lds, s, op.tw, out, line2, k1)) {
         double2* dst = tmp + (size_t)b * n + ((size_t)line2 * N + kh) * M;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) dst[k1 + R1 * k2] = out[k2];
+        for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + k1 + R1 * k2, out[k2]);
     }
 }
 
