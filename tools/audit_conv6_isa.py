@@ -50,6 +50,10 @@ def audit(lines, name):
         if t.startswith(';;#ASMEND'): inasm = False; continue
         if not t or t.startswith(';') or t.startswith('.'): continue
         if 'scratch_' in t: scratch += 1
+        if t.startswith('global_load_lds'):
+            pending.append((i, []))          # LDS-DMA: a place in the in-order vmcnt queue, no destination registers
+            nload += 1
+            continue
         if inasm and (t.startswith('global_load') or t.startswith('buffer_load')):
             pending.append((i, regs(t.split()[1].rstrip(','))))
             nload += 1
