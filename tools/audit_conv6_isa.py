@@ -44,19 +44,45 @@ def audit(lines, name):
     inasm = False
     pending = []          # list of (line, [regs]) in issue order
     bad = nload = scratch = 0
+    labels = {}
     for i, l in enumerate(lines):
+        m = re.match(r'^(\.LBB\w+):', l)
+        if m: labels[m.group(1)] = i
+    # a backward branch = a loop: its body is walked a second time with the requests still in flight at the branch (a destination that
+    # the NEXT iteration's arithmetic reuses is invisible to a single linear pass -- the prefetch loop of k_conv6 had exactly that)
+    order = []
+    seen_back = set()
+    i = 0
+    while i < len(lines):
+        order.append(i)
+        t = lines[i].strip()
+        m = re.match(r's_cbranch_execnz (\.LBB\w+)', t)        # (per-lane loops over elements: `s_andn2 exec ...; s_cbranch_execnz`)
+        # (small loops only: the big software-pipelined loops are rotated and branchy -- a linear second walk is not their control flow;
+        #  their rotation of register sets is checked by the first pass through the unrolled body)
+        if m and m.group(1) in labels and 0 < i - labels[m.group(1)] <= 120 and i not in seen_back:
+            seen_back.add(i)
+            body = lines[labels[m.group(1)]:i]
+            # ... and only loops that request without ever waiting inside (a body with its own counted waits is a pipelined loop, see above)
+            if any(('global_load' in b or 'buffer_load' in b) for b in body) and not any('s_waitcnt vmcnt' in b for b in body):
+                order += list(range(labels[m.group(1)], i))
+        i += 1
+    counted = set()
+    for i in order:
+        l = lines[i]
         t = l.strip()
         if t.startswith(';;#ASMSTART'): inasm = True; continue
         if t.startswith(';;#ASMEND'): inasm = False; continue
         if not t or t.startswith(';') or t.startswith('.'): continue
-        if 'scratch_' in t: scratch += 1
+        first = i not in counted
+        counted.add(i)
+        if 'scratch_' in t and first: scratch += 1
         if t.startswith('global_load_lds'):
             pending.append((i, []))          # LDS-DMA: a place in the in-order vmcnt queue, no destination registers
-            nload += 1
+            nload += first
             continue
         if inasm and (t.startswith('global_load') or t.startswith('buffer_load')):
             pending.append((i, regs(t.split()[1].rstrip(','))))
-            nload += 1
+            nload += first
             continue
         if t.startswith('global_store') or t.startswith('buffer_store'):
             pending.append((i, []))          # stores take a place in the in-order vmcnt queue (no destination registers)
