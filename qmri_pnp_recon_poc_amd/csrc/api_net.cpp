@@ -622,12 +622,15 @@ extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const flo
     d.K = K; d.s = s; d.Q = Q;
     d.ntiles = (K + 31) / 32;
     const int npair = (s + 1) / 2;
-    std::vector<float> pack((size_t)d.ntiles * npair * 64, 0.f);
+    // [tile][lane][NPL] with NPL = 4 or 8 floats per lane (its A-fragment value of every channel pair, zero padded): a lane fetches its
+    // share of a tile with one or two 16-byte requests (dict_kernels.hip)
+    const int npl = (npair <= 4) ? 4 : 8;
+    std::vector<float> pack((size_t)d.ntiles * 64 * npl, 0.f);
     for (int t = 0; t < d.ntiles; ++t)
         for (int q = 0; q < npair; ++q)
             for (int lane = 0; lane < 64; ++lane) {
                 const int atom = t * 32 + (lane & 31), c = 2 * q + (lane >> 5);
-                if (atom < K && c < s) pack[((size_t)t * npair + q) * 64 + lane] = D[(size_t)atom + (size_t)K * c];
+                if (atom < K && c < s) pack[((size_t)t * 64 + lane) * npl + q] = D[(size_t)atom + (size_t)K * c];
             }
     QMRI_TRY(dev_alloc(ctx, &d.d_pack, pack.size()));
     QMRI_TRY(dev_alloc(ctx, &d.d_normD, (size_t)K));

@@ -57,7 +57,8 @@ __device__ __forceinline__ void sqrt_preimage(float s, float m2, float& lo, floa
     if ((double)lo <= bl) lo = __uint_as_float(__float_as_uint(lo) + 1u);
 }
 
-// D packed as MFMA A-fragments: pack[tile][pair q][lane] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s)
+// D packed as MFMA A-fragments, all pairs of a lane together: pack[tile][lane][q] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s;
+// NPL = 4 or 8 floats per lane, so a tile is one or two 16-byte requests per lane instead of one 4-byte request per pair)
 template <int NPAIR>
 __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X, int Npix, int s, const float* __restrict__ pack,
                                                     int ntiles_all, int K, const float* __restrict__ normD,
@@ -88,24 +89,26 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
     const int tbeg = (int)blockIdx.y * tper, ntiles = min(ntiles_all, tbeg + tper);
     // The atom fragments of tile t + 4 are requested before the products of tile t (register double buffer): the loop used to
     // request a tile's fragments and wait for them at once, one L2 latency per tile hidden only by occupancy.
-    float a[NPAIR], an[NPAIR];
+    constexpr int NPL = (NPAIR <= 4) ? 4 : 8, NV = NPL / 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 av[NV], avn[NV];
     {
-        const float* ap = pack + ((size_t)((tbeg + wave < ntiles) ? tbeg + wave : 0) * NPAIR) * 64 + lane;
+        const f32x4* ap = (const f32x4*)(pack + ((size_t)((tbeg + wave < ntiles) ? tbeg + wave : 0) * 64 + lane) * NPL);
 #pragma unroll
-        for (int q = 0; q < NPAIR; ++q) a[q] = ap[q * 64];
+        for (int v = 0; v < NV; ++v) av[v] = ap[v];
     }
     for (int t = tbeg + wave; t < ntiles; t += 4) {
         {
             const int tn = (t + 4 < ntiles) ? t + 4 : t;           // (clamped: the last tile is requested twice)
-            const float* ap = pack + ((size_t)tn * NPAIR) * 64 + lane;
+            const f32x4* ap = (const f32x4*)(pack + ((size_t)tn * 64 + lane) * NPL);
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q) an[q] = ap[q * 64];
+            for (int v = 0; v < NV; ++v) avn[v] = ap[v];
         }
         f32x16 are = {0}, aim = {0};
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
-            are = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bre[q], are, 0, 0, 0);
-            aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bim[q], aim, 0, 0, 0);
+            are = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bre[q], are, 0, 0, 0);
+            aim = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bim[q], aim, 0, 0, 0);
         }
         // |ip|^2 = fma(im, im, re * re), two rows per packed instruction (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations as the
         // scalar forms, so the bits the oracle computes).  The file is compiled with -amdgpu-mfma-vgpr-form (Makefile): the products
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             bidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;          // C/D row of the 32x32 MFMA tile
         }
 #pragma unroll
-        for (int q = 0; q < NPAIR; ++q) a[q] = an[q];
+        for (int v = 0; v < NV; ++v) av[v] = avn[v];
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
     {
