@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void k_synth_tsmi(const double* __restrict__ q
     const int a = idx[p] - 1;
     const int npair = (s + 1) / 2, t = a >> 5;
     const float nd = normD[a], pd = (float)fabs(qmap[(size_t)2 * Npix + p]);
-    auto atom = [&](int c) { return pack[((size_t)t * npair + (c >> 1)) * 64 + (a & 31) + 32 * (c & 1)]; };   // (qmri_set_dictionary's fragment order)
+    const int npl = (npair <= 4) ? 4 : 8;                                  // (qmri_set_dictionary's fragment order: [tile][lane][npl])
+    auto atom = [&](int c) { return pack[((size_t)t * 64 + (a & 31) + 32 * (c & 1)) * npl + (c >> 1)]; };
     const float x0 = atom(0) * nd * pd;
     const float sg = (x0 > 0.f) ? 1.f : ((x0 < 0.f) ? -1.f : 0.f);        // MATLAB sign(): 0 at 0
     for (int c = 0; c < s; ++c) X[(size_t)c * Npix + p] = atom(c) * nd * pd * sg;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_synth_tsmi_complex(const double* __rest
     const int npair = (s + 1) / 2, t = a >> 5;
     const float nd = normD[a], pr = (float)qmap[(size_t)2 * Npix + p], pi = pd_imag ? (float)pd_imag[p] : 0.f;
     for (int c = 0; c < s; ++c) {
-        const float base = pack[((size_t)t * npair + (c >> 1)) * 64 + (a & 31) + 32 * (c & 1)] * nd;
+        const float base = pack[((size_t)t * 64 + (a & 31) + 32 * (c & 1)) * ((npair <= 4) ? 4 : 8) + (c >> 1)] * nd;
         X[(size_t)c * Npix + p] = base * pr;
         X[(size_t)(s + c) * Npix + p] = base * pi;
     }
