@@ -312,3 +312,55 @@ def test_seq_conv_width_not_multiple_of_8_runs_planar(engine_mod, oracle, synth)
     e.set_denoiser(w, 36, 28, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1)
     assert rel_err(e.denoise(x), oracle.Net(w, in_nc=10, out_nc=10, nc=(width, 0, 0, 0), nb=nb, arch=1).denoise(x)) < 1e-5
     e.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_unetres_random_shapes_and_batches(engine_mod, oracle, synth, seed):
+    """Seeded sweep over what selects a kernel variant: image extents (multiples of 8 that are not multiples of the 16- / 8-pixel tiles),
+    channel widths (multiples of 8 from 8 to 72: partial 64-row tiles, odd chunk counts), blocks per level and the batch size (one
+    launch shape per layer at B = 1, the persistent kernel once a launch has more tiles than CUs), against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(2, 9)) * 8, int(rng.integers(2, 9)) * 8
+    nc = tuple(int(rng.integers(1, 10)) * 8 for _ in range(4))
+    nb = int(rng.integers(1, 3))
+    B = int(rng.integers(1, 5))
+    in_nc = int(rng.choice([10, 11]))
+    n = _unet_nparams(in_nc, 10, nc, nb)
+    w = ((synth.uniform01(30 + seed, n) - 0.5) * 0.25).astype(np.float32)
+    xs = synth.uniform01(40 + seed, H * W * in_nc * B).reshape(H, W, in_nc, B)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, H, W, in_nc=in_nc, out_nc=10, nc=nc, nb=nb, max_batch=B)
+    net = oracle.Net(w, in_nc=in_nc, out_nc=10, nc=nc, nb=nb)
+    yb = e.denoise(xs if B > 1 else xs[..., 0])
+    for b in range(B):
+        yo = net.denoise(xs[..., b])
+        yg = yb[..., b] if B > 1 else yb
+        assert rel_err(yg, yo) < 2e-5, (H, W, nc, nb, B, b)
+    e.close()
+
+
+@pytest.mark.parametrize("cfg", ["QMRI_CONV_MIDCFG=0 QMRI_CONV_DEEPCFG=0 QMRI_CONV_DEEPKS=8", "QMRI_CONV_MIDCFG=1 QMRI_CONV_DEEPCFG=1",
+                                 "QMRI_CONV_MIDCFG=2 QMRI_CONV_DEEPCFG=2 QMRI_CONV_DEEPKS=2", "QMRI_CONV_SPLITK=0", "QMRI_CONV_PERSIST=0"],
+                         ids=["tiles256_splitK8", "tiles128_splitK", "tiles64", "no_splitK", "no_persistent"])
+def test_every_tile_configuration_gives_the_same_network(synth, cfg):
+    """The tuning switches select other tile shapes / K splits for the deep levels (conv6_launch): each must reproduce the default
+    configuration's output of the full-size network to fp32 summation-order noise (a fresh process per setting: the switches are read once)."""
+    import subprocess, sys, tempfile
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from qmri_pnp_recon_poc_amd import engine as E, synth\n"
+        "e = E.Engine(0)\n"
+        "e.set_denoiser(synth.structured_weights(seed=2, eps=0.02), 224, 224, max_batch=3)\n"
+        "x = synth.uniform01(77, 224 * 224 * 10 * 3).reshape(224, 224, 10, 3)\n"
+        "np.save(sys.argv[1], np.concatenate([e.denoise(x[..., 0])[..., None], e.denoise(x)], axis=3))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, envs in enumerate(["", cfg]):
+            env = dict(os.environ)
+            for kv in envs.split():
+                k, v = kv.split("="); env[k] = v
+            out = os.path.join(d, f"y{i}.npy")
+            subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+            outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and rel_err(outs[1], outs[0]) < 5e-6
