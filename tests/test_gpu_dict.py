@@ -79,3 +79,34 @@ def test_dict_match_magnitude_ties(engine_mod, oracle):
     print("pixels where argmax |ip|^2 (numpy, unfused) differs from max(abs(ip)):",
           float(np.mean((np.argmax(re * re + im * im, axis=0) + 1) != gq["dm"].ravel())))
     e.close()
+
+
+@pytest.mark.parametrize("K,npix_side", [(40000, 40), (32768, 224)], ids=["ties_across_atom_parts", "full_slice_four_parts"])
+def test_dict_match_atoms_split_over_workgroups(engine_mod, oracle, synth, case224, K, npix_side):
+    """Large dictionaries are matched in P parts of the atom range per pixel tile and merged by k_dict_merge (larger magnitude, then lower
+    index): the same answer as one pass, bit for bit -- also when thousands of atoms ACROSS the parts tie within a few ulps."""
+    rng = np.random.default_rng(21)
+    s = 10
+    e = engine_mod.Engine(0)
+    if npix_side == 224:
+        dic = synth.make_dictionary(T=200, n_t1=256, n_t2=128)
+        assert dic["K"] == K
+        D, nd, lut = dic["D"], dic["normD"], dic["lut"]
+        X = synth.synthesize_tsmi(case224["q"], dic)
+        X = X + 0.01 * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape))
+    else:
+        base = rng.standard_normal(s).astype(np.float32)
+        base /= np.linalg.norm(base)
+        D = np.repeat(base[None, :], K, axis=0)
+        D = (D.view(np.int32) + rng.integers(-3, 4, size=D.shape, dtype=np.int32)).view(np.float32).copy()
+        nd = np.ones(K, np.float32)
+        lut = np.stack([np.arange(K), np.arange(K)], axis=1).astype(np.float32)
+        X = (base[None, None, :] * (1.0 + rng.random((npix_side, npix_side, 1)))) * np.exp(1j * rng.random((npix_side, npix_side, 1)) * 6.28)
+        X = X + 1e-7 * rng.standard_normal(X.shape)
+    e.set_dictionary(D, nd, lut)
+    g = e.dict_match(X)
+    o = oracle.dict_match(X, D, nd, lut)
+    assert np.array_equal(g["dm"], o["dm"]) and np.array_equal(g["mt"], o["mt"]) and np.array_equal(g["pd"], o["pd"]) and np.array_equal(g["qmap"], o["qmap"])
+    if npix_side != 224:
+        print("distinct winning atoms:", len(np.unique(g["dm"])), "largest index", int(g["dm"].max()))
+    e.close()
