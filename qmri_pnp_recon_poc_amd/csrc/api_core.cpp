@@ -383,7 +383,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &o.d_pd, B * ((size_t)N + 2 * ls.nblk_z)));
     QMRI_HIP(ctx, hipMemset(ls.st, 0, B * sizeof(LsqrState)));
     QMRI_HIP(ctx, hipHostMalloc((void**)&o.h_state, B * sizeof(LsqrState), hipHostMallocDefault));
-    ks.st = ls.st; ks.pz = ls.pz; ks.nblk_z = ls.nblk_z; ks.yk = ls.yk; ks.pdiag = nullptr;
+    ks.hst = nullptr; ks.st = ls.st; ks.pz = ls.pz; ks.nblk_z = ls.nblk_z; ks.yk = ls.yk; ks.pdiag = nullptr;
     o.xhat_valid = false;
     o.ginv_r = -1.0;
     o.ready = true;
@@ -534,6 +534,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     const OpDev op = qmri_opdev(ctx);
     KsDev ks = o.ks;
     ks.sr = std::sqrt(r); ks.tol = tol; ks.maxit = maxit; ks.ii = 0; ks.pdiag = pdiag;
+    ks.hst = o.h_state;
     if (!o.xhat_valid) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_x, o.d_tmp, ks.xhat, nullptr));
     QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_z, o.d_tmp, ks.zhat, nullptr));
     QMRI_TRY(ks_launch_init(ctx, op, ks, B));
@@ -552,7 +553,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
             QMRI_TRY(ks_launch_iter(ctx, op, ks, B));
         }
         launched += std::max(nthis, 0);
-        QMRI_HIP(ctx, hipMemcpyAsync(o.h_state, ks.st, (size_t)B * sizeof(LsqrState), hipMemcpyDeviceToHost, ctx->stream));
+        // (no copy of the state: k_ks_b writes iter / done / flag of every slice to the pinned host array itself, ks.hst)
         QMRI_HIP(ctx, hipEventRecord(ctx->ev_state, ctx->stream));
         QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));              // reads ks.xhat (x0), writes ks.xhat_out
         QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));

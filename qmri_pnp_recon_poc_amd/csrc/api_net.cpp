@@ -119,11 +119,19 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     QMRI_HIP(ctx, hipMemcpy(&f, p.d_range_flag, sizeof f, hipMemcpyDeviceToHost));
     if (!f) return QMRI_OK;
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
-    if (p.h_range_flag) *p.h_range_flag = 0;
+    if (p.h_range_flag) std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
     QMRI_TRY(net_set_scheme(ctx, 3));
     p.fallbacks += 1;
     tripped = true;
     return QMRI_OK;
+}
+
+// any bit in the pinned host words of the range guards (k_act_check, conv6_kernels.hip)
+static bool host_range_tripped(const NetPlan& p) {
+    if (!p.h_range_flag) return false;
+    const int n = std::min(p.h_range_words, (int)p.layers.size() + 1);
+    for (int i = 0; i < n; ++i) if (p.h_range_flag[i]) return true;
+    return false;
 }
 
 template <typename T> static int dev_alloc(qmri_ctx* ctx, T** p, size_t count) {
@@ -219,8 +227,9 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     if (p.sp6 == 2 && !conv6_weights_fit_f16(weights, nbytes / 4)) p.sp6 = 3;     // weights beyond the f16 range: bf16 scheme
     QMRI_HIP(ctx, hipMalloc((void**)&p.d_range_flag, sizeof(unsigned)));
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof(unsigned)));
-    QMRI_HIP(ctx, hipHostMalloc((void**)&p.h_range_flag, sizeof(unsigned), hipHostMallocDefault));
-    *p.h_range_flag = 0;
+    p.h_range_words = 4096;
+    QMRI_HIP(ctx, hipHostMalloc((void**)&p.h_range_flag, (size_t)p.h_range_words * sizeof(unsigned), hipHostMallocDefault));
+    std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
     const float* w = weights;
     const int nb = desc->nb;
     const size_t B = (size_t)max_batch;
@@ -523,7 +532,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
             // qmri_lsqr_run has just waited for the LSQR state, which is behind the previous iteration's forward in the stream: its
             // range guard is on the host.  A tripped guard ends this attempt at once instead of after all iterations.
-            if (it > 0 && net.sp6 == 2 && *net.h_range_flag) { range_trip = true; break; }
+            if (it > 0 && net.sp6 == 2 && host_range_tripped(net)) { range_trip = true; break; }
         } else {
             QMRI_TRY(dc_launch_direct(ctx, op, B, o.d_z, o.d_chat, prm->gamma, o.d_tmp, o.d_x));
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = 0;
@@ -542,7 +551,9 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_elementwise);
         tm.start();
         QMRI_TRY(net_forward(ctx, B));
-        if (net.sp6 == 2)   // the range guard of this forward, read at the next x-update's synchronisation point (or at the end)
+        // the range guard of this forward is read at the next x-update's synchronisation point (or at the end): k_act_check has written it
+        // to the pinned host words; only a network with more layers than words copies the device flag
+        if (net.sp6 == 2 && (int)net.layers.size() + 1 > net.h_range_words)
             QMRI_HIP(ctx, hipMemcpyAsync(net.h_range_flag, net.d_range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v

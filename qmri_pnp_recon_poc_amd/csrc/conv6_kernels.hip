@@ -1681,8 +1681,10 @@ __global__ __launch_bounds__(256) void k_conv6_reduce_blk(const float* __restric
 // end of a forward pass (f16 scheme): per layer, the largest |output| over the slots its kernels reported.  record != 0 (the set-up
 // probe): store it as the layer's calibrated magnitude; else raise bit 1 of the range flag if the layer collapsed (see ACT_LOW).
 // The counts are cleared for the next pass.
+// host_words (pinned, or null): [0] = the overflow bit the conv kernels of this pass raised, [1 + layer] = 2 if that layer collapsed -- the
+// host reads them after its next synchronisation instead of copying the device flag back after every forward pass.
 __global__ __launch_bounds__(256) void k_act_check(const float* __restrict__ slots, int* __restrict__ count, float* __restrict__ ref,
-                                                     int record, unsigned* range_flag) {
+                                                     int record, unsigned* range_flag, unsigned* host_words) {
     __shared__ float red[4];
     const int layer = blockIdx.x, n = count[layer];
     const float* row = slots + (size_t)layer * ACT_MAXSLOT;
@@ -1697,11 +1699,18 @@ __global__ __launch_bounds__(256) void k_act_check(const float* __restrict__ slo
     m = __builtin_bit_cast(float, wave_max_bits(m));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0 && n > 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        if (record) ref[layer] = m;
-        else if (m > 0.f && m < ACT_LOW && m < ref[layer] * ACT_DROP) atomicOr(range_flag, 2u);
-        count[layer] = 0;
+    if (threadIdx.x == 0) {
+        bool low = false;
+        if (n > 0) {
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            if (record) ref[layer] = m;
+            else if (m > 0.f && m < ACT_LOW && m < ref[layer] * ACT_DROP) { atomicOr(range_flag, 2u); low = true; }
+            count[layer] = 0;
+        }
+        if (host_words) {
+            host_words[1 + layer] = low ? 2u : 0u;
+            if (layer == 0) host_words[0] = __hip_atomic_load(range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;   // (bit 0: set by kernels that are over)
+        }
     }
 }
 
@@ -1748,7 +1757,8 @@ int conv6_act_end(qmri_ctx* ctx) {
         }
         fprintf(stderr, "\n");
     }
-    k_act_check<<<dim3(net.act_cap), dim3(256), 0, ctx->stream>>>(net.d_act_slots, net.d_act_count, net.d_act_ref, net.act_record ? 1 : 0, net.d_range_flag);
+    k_act_check<<<dim3(net.act_cap), dim3(256), 0, ctx->stream>>>(net.d_act_slots, net.d_act_count, net.d_act_ref, net.act_record ? 1 : 0, net.d_range_flag,
+                                                                  (net.act_cap + 1 <= net.h_range_words) ? net.h_range_flag : nullptr);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }

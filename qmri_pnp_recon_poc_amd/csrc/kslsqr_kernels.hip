@@ -304,6 +304,7 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
             st->iter = fin ? 0 : ks.maxit;
             st->flag = fin ? 0 : 1;
             st->done = fin ? 1 : 0;
+            if (ks.hst) { LsqrState* h = ks.hst + b; h->iter = st->iter; h->flag = st->flag; h->done = st->done; }     // (visible to the host when the launch is over)
         }
         if (fin) return;
         inv_beta = 1.0 / beta0;
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
         S.ub = ub_n;
         if (writer) {
             st->sc[ks.ii & 1] = S;
-            if (conv) { st->done = 1; st->flag = 0; st->iter = ks.ii - 1; }
+            if (conv) {
+                st->done = 1; st->flag = 0; st->iter = ks.ii - 1;
+                if (ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = 0; h->iter = ks.ii - 1; }
+            }
             else st->ue_final = S.ue;
         }
         if (conv) return;

@@ -76,6 +76,7 @@ struct KsDev {
     const KsGroup* grp;                          // scatter groups, block after block
     const int32_t* sgrp;                         // [ns+1] first group of each slot
     LsqrState* st;                               // [B]
+    LsqrState* hst;                              // [B] pinned host copy: the kernel that changes iter / done / flag writes them here too (no copy launch per x-update)
     double* pu[2];                               // [B][2G] partial |u|^2 (image part, then samples), by iteration parity
     double* pv[2];                               // [B][G]  partial |v|^2
     double* pinit;                               // [B][2N] partial |u|^2 of the initial residual, per k-row
@@ -172,7 +173,8 @@ struct NetPlan {
     int fwd_calls[9] = {};
     bool force_f32 = false;             // calibration (qmri_set_denoiser): run the f32-MFMA kernels whatever the scheme
     unsigned* d_range_flag = nullptr;   // f16 scheme: raised by a conv kernel whose output leaves the f16-splittable range
-    unsigned* h_range_flag = nullptr;   // pinned host copy, refreshed after every forward of the ADMM loop (checked at the loop's next sync point)
+    unsigned* h_range_flag = nullptr;   // pinned host words written by k_act_check at the end of every forward pass: [0] overflow bit, [1 + layer] low-magnitude bit
+    int h_range_words = 0;              // ... how many (1 + layers must fit, else the ADMM loop copies the device flag instead)
     int fallbacks = 0;                  // times a run-time guard moved the network from the f16 to the bf16 scheme since qmri_set_denoiser
     float* d_act_slots = nullptr;       // f16 scheme: largest |output| per (reporting launch, wave) of the current forward pass (conv6_kernels.hip, ACT_LOW)
     int* d_act_count = nullptr;         // ... valid slots per reporting launch
