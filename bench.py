@@ -345,15 +345,17 @@ def worker(args):
                         # MFMA and SIMD (tools/ubench/mfma_f16x3_loop.hip, profiles/r01_g_ubench_mfma_f16x3_loop.txt) -- not the roofline
                         # peak, reported beside it
                         "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4)}
-        # stage split of one short run (profile level 1 synchronises per stage; not part of the timed region)
+        # stage split of one more run of the SAME workload (profile level 1 synchronises per stage; not part of the timed region): all
+        # args.steps iterations, because the x-update is not uniform over a reconstruction -- LSQR needs 16 iterations in the first
+        # x-updates and 5-8 in the later ones (lsqr_iters_mean)
         if args.workload == "admm":
             eng.profile_enable(1)
-            run(min(10, max(args.steps, 1)))
+            run(max(args.steps, 1))
             pr = eng.profile_get(reset=True)
             eng.profile_enable(0)
             it = max(pr["admm_iters"], 1)
             result_extra["stage_ms_per_iter"] = {"xupdate": round(pr["ms_xupdate"] / it, 4), "denoiser": round(pr["ms_denoiser"] / it, 4),
-                                                 "elementwise": round(pr["ms_elementwise"] / it, 4)}
+                                                 "elementwise": round(pr["ms_elementwise"] / it, 4), "over_admm_iters": int(it)}
 
     # ---- CPU baseline + parity: the oracle on this box's host cores, bounded sample -----------------------
     cpu = None
