@@ -6,7 +6,9 @@
  *   main_files/subsampling_patterns/setup_subsampling_epi.m:20-33
  * MATLAB built-ins restated from documentation: linspace, round (half away from zero == C round()),
  * fftshift (swap halves in both dims), find (ascending column-major order).
- * Parity unpinned against MATLAB (no fixtures exist); pinned by the survey-derived counts in tests/.
+ * Parity unpinned against MATLAB itself (no MATLAB output exists in this pipeline); cross-checked bit for bit against
+ * the independent literal restatement of the same .m lines (tools/gen_matlab_rows.py -> tests/golden/matlab_rows_*.npz,
+ * tests/test_oracle_matlab_rows.py), which is builder-written code, not reference output.
  */
 #include "orc_internal.h"
 

@@ -205,6 +205,17 @@ def unetres_weight_shapes(in_nc: int = 10, out_nc: int = 10, nc=(64, 128, 256, 5
     return shapes
 
 
+def unetres_weight_slice(name: str, in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4) -> slice:
+    """Position of one state-dict tensor inside the flat weight blob."""
+    off = 0
+    for nm, shp in unetres_weight_shapes(in_nc, out_nc, nc, nb):
+        n = int(np.prod(shp))
+        if nm == name:
+            return slice(off, off + n)
+        off += n
+    raise KeyError(name)
+
+
 def unetres_nparams(in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4) -> int:
     return int(sum(int(np.prod(s)) for _, s in unetres_weight_shapes(in_nc, out_nc, nc, nb)))
 
@@ -223,6 +234,16 @@ def random_weights(in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4, seed=1, ga
         u = uniform01(seed * 1000003 + i, n)
         out.append(((2.0 * u - 1.0) * a).astype(np.float32))
     return np.concatenate(out)
+
+
+def golden224_input(in_nc: int = 10, seed: int = 9300) -> np.ndarray:
+    """[in_nc][224][224] float32 input of the random-weight 224 x 224 golden vectors (tools/gen_golden.py,
+    `unetres_full_224_random_*`): uniform [0,1) image channels; with 11 channels the last plane is the constant
+    noise map 0.01 (`PnP_ADMM.m:132`, `build_noise_map.m:19`)."""
+    x = uniform01(seed + in_nc, in_nc * 224 * 224).astype(np.float32).reshape(in_nc, 224, 224)
+    if in_nc == 11:
+        x[10] = np.float32(0.01)
+    return x
 
 
 def structured_weights(in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4, seed=2, eps=0.02) -> np.ndarray:

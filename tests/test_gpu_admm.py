@@ -45,6 +45,32 @@ def test_admm_224_single_level_vs_oracle(engine_mod, oracle, synth, case224):
     e.close()
 
 
+def test_admm_224_with_an_interior_that_matters(engine_mod, oracle, synth, case224):
+    """The 224 x 224 loop with a network whose interior layers carry weight (round 3): structured_weights(eps=0.02), the stable
+    bench network, is numerically head + tail, so the ADMM parity runs above cannot see the deep-level kernels.  With eps = 0.5
+    the loop is still bounded over a few iterations (max|x| ~ 4) and one interior layer times 1.01 moves x by 4e-4 ... 2e-3
+    (asserted on the oracle first: the guard that keeps this test from going blind); GPU vs oracle must agree to 1e-4."""
+    iters = 4
+    w = synth.structured_weights(seed=2, eps=0.5)
+    xo, _, lo = oracle.pnp_admm(case224["op"], oracle.Net(w), case224["y"], iters=iters)
+    for name in ("m_body.1.res.2.weight", "m_down1.2.res.0.weight"):
+        w2 = w.copy()
+        w2[synth.unetres_weight_slice(name)] *= np.float32(1.01)
+        x2, _, _ = oracle.pnp_admm(case224["op"], oracle.Net(w2), case224["y"], iters=iters)
+        moved = rel_err(x2, xo)
+        print(f"sensitivity guard: {name} x 1.01 moves x after {iters} iterations by {moved:.2e}")
+        assert moved > 2e-4, f"the ADMM parity network went blind to {name}"
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, case224["dic"]["V"], case224["fp"], case224["k"])
+    e.set_denoiser(w, 224, 224)
+    xg, _, lg = e.pnp_admm(case224["y"], iters=iters)
+    err = rel_err(xg, xo)
+    print(f"224 eps=0.5: lsqr gpu {lg.tolist()} oracle {lo.tolist()}, rel_err {err:.3e}, max|x| {np.abs(xo).max():.3g}, scheme {e.denoiser_scheme()}")
+    assert np.array_equal(lg, lo)
+    assert err < 1e-4
+    e.close()
+
+
 def _small_case(oracle, synth, N=32, T=24, s=6, S=120, in_extra=0, seed=0):
     dic = synth.make_dictionary(T=T, n_t1=24, n_t2=16, s=s)
     q = synth.make_phantom_qmaps(N, seed=seed)

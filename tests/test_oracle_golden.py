@@ -50,6 +50,29 @@ def test_full_unetres_224_matches_reference(oracle, synth):
     assert dev < 10 * max(ref_dev, 1e-6)
 
 
+@pytest.mark.parametrize("in_nc", [10, 11])
+def test_full_unetres_224_random_weights_matches_reference(oracle, synth, in_nc):
+    """G3b: weights under which every level of the network matters (random_weights(seed=1, gain=0.7)); the structured
+    weights of G3 leave the 62 interior layers at 1.5e-4 of the output.  The sensitivity is asserted here so that the fixture
+    can never go blind: one layer of the 28 x 28 body times 1.01 must move the oracle's output by what it moved the reference's."""
+    g = np.load(os.path.join(GOLDEN, f"unetres_full_224_random_{in_nc}ch.npz"))
+    w = synth.random_weights(in_nc=in_nc, seed=int(g["weight_seed"]), gain=float(g["gain"]))
+    x = synth.golden224_input(in_nc)
+    y = oracle.Net(w, in_nc=in_nc).forward_f32(x.transpose(1, 2, 0)).transpose(2, 0, 1)
+    assert abs(float(np.abs(y).max()) - float(g["absmax"])) < 1e-3 * float(g["absmax"])
+    assert rel_err(y[:, 96:128, 64:96], g["crop_a"]) < 1e-5 and rel_err(y[:, 0:32, 192:224], g["crop_b"]) < 1e-5
+    assert rel_err(y[:, ::37, ::41], g["rows"]) < 1e-5
+    y64 = y.astype(np.float64)
+    assert np.abs(y64.sum(axis=(1, 2)) - g["ch_sum"]).max() / np.abs(g["ch_sum"]).max() < 1e-5
+    assert np.abs(np.sqrt((y64 ** 2).sum(axis=(1, 2))) - g["ch_l2"]).max() / g["ch_l2"].max() < 1e-6
+    if in_nc == 10:
+        w2 = w.copy()
+        w2[synth.unetres_weight_slice("m_body.1.res.2.weight", in_nc=in_nc)] *= np.float32(1.01)
+        y2 = oracle.Net(w2, in_nc=in_nc).forward_f32(x.transpose(1, 2, 0)).transpose(2, 0, 1)
+        sens = rel_err(y2, y)
+        assert sens > 1e-4 and abs(sens - float(g["sens_body_1pct"])) < 0.02 * float(g["sens_body_1pct"])
+
+
 def test_denoise_wrapper_casts_and_residual(oracle, synth):
     g = np.load(os.path.join(GOLDEN, "unetres_tiny_10ch.npz"))
     net = oracle.Net(g["weights"], in_nc=10, out_nc=10, nc=tuple(int(v) for v in g["nc"]), nb=int(g["nb"]))

@@ -16,12 +16,19 @@ Fixtures
                                                   10 x 64 x 64, full output + L2 norms of x1..x4 / body
   unetres_full_224.npz                            G3: same arch, synth.structured_weights(seed=2), input
                                                   10 x 224 x 224 in [0,1]; per-channel sums / norms + a 32x32 crop
+  unetres_full_224_random_{10,11}ch.npz           G3b (round 3): same arch (in_nc 10 / 11), synth.random_weights(seed=1,
+                                                  gain=0.7) -- weights under which EVERY level matters (1 % of one layer
+                                                  moves the output by > 1e-3); input C x 224 x 224 in [0,1] (11-ch: last
+                                                  plane = 0.01, the noise map of PnP_ADMM.m:132); per-channel sums / norms,
+                                                  two 32x32 crops, L2 norms of x1..x4 / body / up3..up1 / pre-tail, and the
+                                                  output's change when m_body.1.res.2.weight is scaled by 1.01 (the
+                                                  sensitivity figure the tests re-check on the oracle)
   unetres_homogeneity.npz                         G4: net(3x) vs 3 net(x) relative deviation of the reference itself
   checkpoint_small.pt (+ checkpoint_small.npz)    G5: a checkpoint in the layout main_train.py:407-411 saves (epoch,
                                                   model_state_dict, optimizer_state_dict after one Adam step, loss) of
                                                   UNetRes(11,10,[4,8,8,16],nb=2), written by torch.save; the .npz holds
                                                   the expected flat weights, an input and the reference's output
-`python tools/gen_golden.py [tiny full64 full224 checkpoint]` regenerates a subset.
+`python tools/gen_golden.py [tiny full64 full224 full224random checkpoint]` regenerates a subset.
 Tensor layout in the fixtures is PyTorch's [C][H][W]; tests transpose to the MATLAB order.
 """
 import os
@@ -114,6 +121,34 @@ def full224():
     print("full224: ch_sum", y.sum(axis=(1, 2))[:3], "homogeneity dev", dev)
 
 
+def full224_random(in_nc):
+    nc, nb = [64, 128, 256, 512], 4
+    net = UNetRes(in_nc=in_nc, out_nc=10, nc=nc, nb=nb, act_mode="R", downsample_mode="strideconv",
+                  upsample_mode="convtranspose").eval()
+    check_order(net, in_nc, 10, nc, nb)
+    w = synth.random_weights(in_nc, 10, nc, nb, seed=1, gain=0.7)
+    load_flat(net, w)
+    x = synth.golden224_input(in_nc)
+    xt = torch.from_numpy(x)[None]
+    x1 = net.m_head(xt); x2 = net.m_down1(x1); x3 = net.m_down2(x2); x4 = net.m_down3(x3); xb = net.m_body(x4)
+    u3 = net.m_up3(xb + x4); u2 = net.m_up2(u3 + x3); u1 = net.m_up1(u2 + x2)      # network_unet.py:106-117
+    y = net.m_tail(u1 + x1)[0].numpy()
+    assert np.array_equal(y, net(xt)[0].numpy())
+    norms = np.array([float(t.double().norm()) for t in (x1, x2, x3, x4, xb, u3, u2, u1, u1 + x1)])
+    # sensitivity of the reference itself: one deep layer times 1.01
+    sd = net.state_dict()
+    sd["m_body.1.res.2.weight"] = sd["m_body.1.res.2.weight"] * 1.01
+    net.load_state_dict(sd)
+    y2 = net(xt)[0].numpy()
+    sens = float(np.linalg.norm(y2 - y) / np.linalg.norm(y))
+    y64 = y.astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, f"unetres_full_224_random_{in_nc}ch.npz"), in_nc=in_nc, weight_seed=1, gain=0.7,
+                        ch_sum=y64.sum(axis=(1, 2)), ch_l2=np.sqrt((y64 ** 2).sum(axis=(1, 2))),
+                        crop_a=y[:, 96:128, 64:96].copy(), crop_b=y[:, 0:32, 192:224].copy(),
+                        rows=y[:, ::37, ::41].copy(), norms=norms, sens_body_1pct=sens, absmax=float(np.abs(y).max()))
+    print(f"full224 random {in_nc}ch: |y| {np.abs(y).max():.4g}, norms {norms}, 1% of m_body.1.res.2 moves y by {sens:.3e}")
+
+
 def checkpoint():
     in_nc, nc, nb = 11, [4, 8, 8, 16], 2
     torch.manual_seed(4321)
@@ -137,7 +172,7 @@ def checkpoint():
 
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["tiny", "full64", "full224", "checkpoint"]
+    todo = sys.argv[1:] or ["tiny", "full64", "full224", "full224random", "checkpoint"]
     if "tiny" in todo:
         tiny(10)
         tiny(11)
@@ -145,5 +180,8 @@ if __name__ == "__main__":
         full64()
     if "full224" in todo:
         full224()
+    if "full224random" in todo:
+        full224_random(10)
+        full224_random(11)
     if "checkpoint" in todo:
         checkpoint()
