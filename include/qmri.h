@@ -117,7 +117,8 @@ int qmri_onnx_read_unetres(const char* path, qmri_net_desc* desc_out, float* wei
 int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C, int B, double* out);
 /* raw network forward on device fp32 tensors [B][C][W][H] (no casts); the dominant kernel chain.  Precondition of the default
  * (f16-split) arithmetic: inputs at ordinary scale, as the [0, 1] images of PnP_ADMM.m:121 are; the call synchronises, reads the
- * range guard and -- like qmri_denoise / qmri_pnp_admm -- repeats itself on the bf16 scheme if an activation left the f16 range. */
+ * range guard and -- like qmri_denoise / qmri_pnp_admm -- repeats itself on the bf16 scheme if an activation left the f16 range.
+ * The repeated pass reads d_in again: d_in and d_out must not overlap (QMRI_ERR_INVALID_ARG otherwise). */
 int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, float* d_out);
 /* Which arithmetic the convolutions run on: *scheme_out = 2 (f16 pieces, 3 MFMA products per fp32 product) or 3 (bf16 pieces, 6
  * products: no range limits, twice the matrix time); *fallbacks_out = how often a run-time guard has moved the network from 2

@@ -389,6 +389,11 @@ extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, flo
     NetPlan& p = ctx->net;
     if (!p.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
     QMRI_CHECK_ARG(ctx, d_in && d_out && B >= 1 && B <= p.maxB, "qmri_net_forward_dev arguments / batch > max_batch");
+    {   // the guarded second attempt reads d_in again: input and output must not overlap
+        const size_t hw = (size_t)p.H * p.W * B * sizeof(float);
+        const char *a = (const char*)d_in, *b = (const char*)d_out;
+        QMRI_CHECK_ARG(ctx, a + hw * p.desc.in_nc <= b || b + hw * p.desc.out_nc <= a, "qmri_net_forward_dev: d_in and d_out must not overlap");
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {        // (second pass only after the f16 range guard switched the scheme)
         QMRI_TRY(ew_launch_pack(ctx, B, p.desc.in_nc, p.H, p.W, d_in, 0, p.in32));
         QMRI_TRY(net_forward(ctx, B));
@@ -499,6 +504,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     const size_t plane = (size_t)o.N * o.M, n = plane * o.s, nb = (size_t)B * n * sizeof(double2);
     const double2* y = (const double2*)d_y;
     StageTimer tm(ctx);
+    const auto prof_at_entry = ctx->prof;                  // (an attempt the range guard aborts must not stay in the profile)
 
     QMRI_TRY(dc_launch_sort_y(ctx, op, o.ls, B, y));
     if (d_x0) QMRI_HIP(ctx, hipMemcpyAsync(o.d_x, d_x0, nb, hipMemcpyDeviceToDevice, ctx->stream));        // x = param.X0
@@ -532,7 +538,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
             // qmri_lsqr_run has just waited for the LSQR state, which is behind the previous iteration's forward in the stream: its
             // range guard is on the host.  A tripped guard ends this attempt at once instead of after all iterations.
-            if (it > 0 && net.sp6 == 2 && host_range_tripped(net)) { range_trip = true; break; }
+            if (it > 0 && net.sp6 == 2 && host_range_tripped(net)) { range_trip = true; tm.stop(ctx->prof.ms_xupdate); break; }
         } else {
             QMRI_TRY(dc_launch_direct(ctx, op, B, o.d_z, o.d_chat, prm->gamma, o.d_tmp, o.d_x));
             if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = 0;
@@ -563,8 +569,9 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_elementwise);
         ctx->prof.admm_iters += 1;
     }
-    if (!range_trip)
-    QMRI_HIP(ctx, hipMemcpyAsync(d_x_out, o.d_x, nb, hipMemcpyDeviceToDevice, ctx->stream));                 // returns x, not v
+    if (!range_trip) {
+        QMRI_HIP(ctx, hipMemcpyAsync(d_x_out, o.d_x, nb, hipMemcpyDeviceToDevice, ctx->stream));             // returns x, not v
+    }
     if (prm->want_diag && diag_out && prm->iters > 0 && !range_trip)
         QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -572,7 +579,10 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         // f16 range guard: the network now runs on the bf16 scheme; the inputs are untouched (d_x_out must not alias d_x0), run again
         bool again = false;
         QMRI_TRY(net_range_tripped(ctx, again));
-        if (again) return qmri_pnp_admm_dev(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+        if (again) {
+            ctx->prof = prof_at_entry;                     // the repeated run is the one that counts
+            return qmri_pnp_admm_dev(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+        }
     }
     return QMRI_OK;
 }

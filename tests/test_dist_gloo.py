@@ -56,6 +56,14 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["plumbing_only"] is True and out["steps"] == 3
     assert out["max_rank_seconds"] >= 0.02                 # the slower rank (rank 1 sleeps 20 ms) sets the time
+    # north_star's slices workload: a FIXED total of 120 slices sharded over the ranks (the same job at every N), 15 at a time per GPU
+    for n, on0, batches in ((1, 120, 8), (2, 60, 4), (3, 40, 3)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--plumbing-only", "--workload", "slices",
+                            "--total-slices", "120", "--batch", "15"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert out["n_gpus"] == n and out["scaling"] == "strong" and out["slices_total"] == 120 and out["slices_owned_once"] == 120
+        assert out["slices_on_rank0"] == on0 and out["batches_on_rank0"] == batches
     # a failing rank must take the job down with a non-zero exit code, not hang it
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
                         "--no-roofline", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)

@@ -110,3 +110,20 @@ def test_dict_match_atoms_split_over_workgroups(engine_mod, oracle, synth, case2
     if npix_side != 224:
         print("distinct winning atoms:", len(np.unique(g["dm"])), "largest index", int(g["dm"].max()))
     e.close()
+
+
+def test_dict_match_bench_K_98304_full_slice(engine_mod, oracle, synth, case224):
+    """The dictionary size of the slices bench (384 x 256 grid, K = 98 304) on a full 224 x 224 slice: bit-exact maps against the
+    oracle's blocked match (mrf_dtm_cpu.m:74: blockSize 1e9 -> 10 172 pixels per block at this K)."""
+    dic = synth.make_dictionary(T=200, n_t1=384, n_t2=256)
+    assert dic["K"] == 98304
+    rng = np.random.default_rng(5)
+    X = synth.synthesize_tsmi(case224["q"], dic)
+    X = X + 0.005 * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape))
+    e = engine_mod.Engine(0)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    g = e.dict_match(X)
+    o = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"])
+    assert np.array_equal(g["dm"], o["dm"]) and np.array_equal(g["mt"], o["mt"]) and np.array_equal(g["pd"], o["pd"]) and np.array_equal(g["qmap"], o["qmap"])
+    assert len(np.unique(g["dm"])) > 500
+    e.close()
