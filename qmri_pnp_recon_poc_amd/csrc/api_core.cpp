@@ -85,6 +85,7 @@ void qmri_free_operator(qmri_ctx* ctx) {
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
     for (void* p : ptrs) free_dev(p);
     if (o.h_state) (void)hipHostFree(o.h_state);
+    free_dev(ctx->d_ks_gran); ctx->d_ks_gran = nullptr; ctx->ks_persist_cap = -1;    // (sized for this operator's work units)
     o = OpHost();
 }
 
@@ -543,10 +544,39 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     // while the host wakes up and enqueues the next stage.  If a slice was not done yet (rare: counts fall from one x-update
     // to the next), two more iterations at a time follow and the final kernels run again from the untouched inputs.
     if (!ctx->ev_state) QMRI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_state, hipEventDisableTiming));
+    // Round 3: all iterations in ONE launch when the grid is resident at once (k_ks_persist: the iteration's state stays on chip, the
+    // two sums per iteration are in-kernel hand-offs instead of kernel boundaries); the two-launch iteration otherwise (EPI masks,
+    // cut0, slice batches) and after a time-out of the persistent kernel (never seen; the inputs are untouched then).
+    bool persisted = false;
+    if (ctx->ks_persist < 0) ctx->ks_persist = (getenv("QMRI_LSQR_PERSIST") && atoi(getenv("QMRI_LSQR_PERSIST")) == 0) ? 0 : 1;
+    if (ctx->ks_persist > 0 && maxit >= 1) {
+        if (!ctx->d_ks_gran) {
+            const size_t nb = ks_gran_bytes(ks.G, o.maxB);
+            QMRI_HIP(ctx, hipMalloc(&ctx->d_ks_gran, nb));
+            QMRI_HIP(ctx, hipMemsetAsync(ctx->d_ks_gran, 0, nb, ctx->stream));      // (tag 0 is never used)
+        }
+        const unsigned tag0 = ctx->ks_tag;
+        QMRI_TRY(ks_launch_persist(ctx, op, ks, B, ctx->d_ks_gran, tag0, &persisted));
+        if (persisted) {
+            ctx->ks_tag += 2u * (unsigned)(maxit + 2);
+            QMRI_HIP(ctx, hipEventRecord(ctx->ev_state, ctx->stream));
+            QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));
+            QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
+            QMRI_HIP(ctx, hipEventSynchronize(ctx->ev_state));
+            bool timed_out = false;
+            for (int b = 0; b < B; ++b) timed_out = timed_out || o.h_state[b].flag == 77;
+            if (timed_out) {                                       // repeat with the two-launch iteration, from the untouched inputs
+                fprintf(stderr, "libqmri: the one-launch LSQR timed out waiting for a partial sum; using the two-launch iteration from now on\n");
+                ctx->ks_persist = 0;
+                persisted = false;
+                QMRI_TRY(ks_launch_init(ctx, op, ks, B));
+            }
+        }
+    }
     int launched = 0;
     int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
-    bool all_done = false;
-    do {
+    bool all_done = persisted;
+    while (!persisted && launched < maxit && !all_done) {
         const int nthis = std::min(chunk, maxit - launched);
         for (int k = 0; k < nthis; ++k) {
             ks.ii = launched + k + 1;
@@ -561,7 +591,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         all_done = true;
         for (int b = 0; b < B; ++b) all_done = all_done && o.h_state[b].done;
         chunk = 2;
-    } while (launched < maxit && !all_done);
+    }
     std::swap(o.ks.xhat, o.ks.xhat_out);                                  // the assembled spectrum is the next solve's xhat0
     o.xhat_valid = true;
     int worst = 0;
@@ -606,6 +636,13 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
     }
     QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_x, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+// test / A-B hook: 1 = all LSQR iterations in one launch where the grid is resident (default), 0 = the two-launch iteration
+extern "C" int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    ctx->ks_persist = on ? 1 : 0;
     return QMRI_OK;
 }
 

@@ -39,6 +39,7 @@ constexpr int NEQ = (KS_SCAP * DC_MAXS + KT - 1) / KT;   // (slot, channel) elem
 constexpr int NSQ = KS_ECAP / KT;                          // samples per thread
 constexpr int NGQ = KS_GCAPB * SL / KT;                    // scatter groups per 8 lanes
 constexpr int NVQ = 8;                                     // V values per thread requested up front (8 * 256 = 2048)
+constexpr int KS_GRAN_MAXG = 320;                          // k_ks_persist: most work units per slice (its all-reduce holds 2G granules in 64 x 10 registers)
 
 #define KS_STAMP(KID, k)                                                                         \
     do {                                                                                         \
@@ -429,6 +430,274 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_ks_persist (round 3): ALL iterations of one LSQR solve in ONE launch.
+//
+// The state of the iteration on a work unit -- v, u(m+1:end), d, x of its <= 64 slots and u(1:m) of its <= 1024 samples -- is 19 KB:
+// it stays in this workgroup's registers and LDS for the whole solve, so an iteration touches no global vector at all.  What is
+// left of an iteration is exactly its two grid-wide sums (|u|^2 -> beta, |v|^2 -> alpha): every workgroup publishes its partial as
+// a tagged granule (two 8-byte words {lo32(value), tag}, {hi32(value), tag}, agent-scope relaxed atomic stores = write-through sc1
+// stores) and one wave per workgroup polls the G (2G) granules of its slice with agent-scope relaxed atomic loads (sc1: served
+// past the L1) until every tag carries this iteration's number, then adds them in the SAME canonical order as wave_sum() -- so
+// alpha, beta, the stopping decision and every vector carry the same bits as k_ks_a / k_ks_b produce (tested bit for bit).  No
+// fence, no counter: a granule is its own flag (8-byte agent atomics on both sides, MI355X_MICROARCH.md "Valid forms").
+// The work that does not depend on a sum is placed in front of the wait for it (staging v in LDS; the scatter sums V' u per group),
+// so most of a hand-off's latency is covered.
+// Requirement: the G x B workgroups must be resident together (the host checks the occupancy and falls back to the two-launch
+// iteration otherwise -- EPI masks, cut0, slice batches).  Every spin is bounded: on a time-out the kernel stores nothing but the
+// abort flag (state 77), and the host repeats the solve with the two-launch iteration from the untouched inputs.
+// ---------------------------------------------------------------------------------------------------------------
+struct KsGran { unsigned long long w0, w1; };                       // {lo32(value) | tag << 32}, {hi32(value) | tag << 32}
+constexpr int KS_SPIN_MAX = 1 << 17;                                 // polls before a waiting wave gives up (~0.1-0.3 s)
+
+__device__ __forceinline__ void gran_store(KsGran* g, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+    __hip_atomic_store(&g->w0, (b & 0xFFFFFFFFull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&g->w1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// canonical sum of n granules (n <= 64 * NQ) by one wave, in the order of wave_sum(); returns false on time-out.  Lane 0 holds the sum.
+template <int NQ>
+__device__ __forceinline__ bool gran_sum(KsGran* g, int n, unsigned tag, double& out) {
+    const int lane = threadIdx.x & 63;
+    double r[NQ];
+    bool ok = false;
+    for (int spin = 0; spin < KS_SPIN_MAX; ++spin) {
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = lane + 64 * q;
+            KsGran* e = g + ((i < n) ? i : 0);
+            const unsigned long long a = __hip_atomic_load(&e->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(&e->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            all = all && ((unsigned)(a >> 32) == tag) && ((unsigned)(b >> 32) == tag);
+            r[q] = __longlong_as_double((long long)((a & 0xFFFFFFFFull) | (b << 32)));
+        }
+        if (__builtin_amdgcn_ballot_w64(all) == ~0ull) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a += (lane + 64 * q < n) ? r[q] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    out = a;
+    return ok;
+}
+
+__global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0) {
+    __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]   (k_ks_a)
+    __shared__ double2 ulds[KS_ECAP];                      // u(1:m) of the unit's samples        (k_ks_b)
+    __shared__ cd part[KS_GCAPB * DC_MAXS];
+    __shared__ unsigned short tlds[KS_ECAP];
+    __shared__ int sgl[KS_SCAP + 1];
+    __shared__ double red[2 * KT / 64 + 4];
+    __shared__ int abort_flag;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* vlds = (double*)smem;
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, s = op.s, G = ks.G;
+    LsqrState* st = ks.st + b;
+    const KsUnit un = ks.unit[g];
+    const int s0 = un.s0, s1 = un.s1, nsl = s1 - s0, ne = nsl * s;
+    const int e0 = un.e0, nsamp = un.e1 - e0;
+    const int g0 = un.g0, ng = un.g1 - g0;
+    const size_t cb = ((size_t)b * ks.ns + s0) * s, mb = (size_t)b * op.m + e0;
+    KsGran* gu[2] = {gu_all + (size_t)b * 4 * G, gu_all + (size_t)b * 4 * G + 2 * G};     // [parity][2G]
+    KsGran* gv[2] = {gv_all + (size_t)b * 2 * G, gv_all + (size_t)b * 2 * G + G};         // [parity][G]
+    // ---- the unit's state, once
+    double2 rcv[NEQ], rub[NEQ], rd[NEQ], rx[NEQ];
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) {
+        const int i = (tid + KT * q < ne) ? tid + KT * q : 0;
+        rcv[q] = ks.cv[cb + i]; rub[q] = ks.cub[cb + i]; rd[q] = ks.cd[cb + i]; rx[q] = ks.cx[cb + i];
+    }
+    KSample res[NSQ];
+    double2 rut[NSQ];
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+        const int j = (tid + KT * q < nsamp) ? tid + KT * q : 0;
+        res[q] = ks.es[e0 + j]; rut[q] = ks.ut[mb + j];
+    }
+    KsGroup rg[NGQ];
+#pragma unroll
+    for (int q = 0; q < NGQ; ++q) { const int gi = (tid + KT * q) / SL; rg[q] = ks.grp[g0 + ((gi < ng) ? gi : 0)]; }
+    const int rsg = ks.sgrp[s0 + ((tid <= nsl) ? tid : 0)] - g0;
+    double rv[NVQ];
+    load_v(op, rv);
+    LsqrScalars O = st->sc[0];                                      // written by k_ks_b<INIT>
+    const double R = st->R, tolb = st->tolb, sr = ks.sr;
+    if (st->done) return;                                           // x0 already exact, or b = 0 (uniform over the grid)
+    if (tid < 64) {
+        const double pa0 = wave_sum(ks.pv[0] + (size_t)b * G, G);   // |v|^2 partials of the INIT launch (plain: another kernel's output)
+        if (tid == 0) red[0] = pa0;
+    }
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) { const int j = tid + KT * q; if (j < nsamp) tlds[j] = res[q].t; }
+    if (tid <= nsl) sgl[tid] = rsg;
+    if (tid == 0) abort_flag = 0;
+    store_v(op, rv, vlds);
+    const bool writer = g == 0 && tid == 0;
+    double ue_final = 0.0;
+    int conv_iter = -1;
+    bool aborted = false;
+
+    for (int ii = 1; ii <= ks.maxit; ++ii) {
+        const unsigned tagA = tag0 + 2u * (unsigned)ii, tagB = tagA + 1u;
+        // ================= k_ks_a: u = B v - alpha (u / beta_prev) =================
+#pragma unroll
+        for (int q = 0; q < NEQ; ++q) { const int i = tid + KT * q; if (i < ne) vl[i] = rcv[q]; }
+        if (ii > 1 && tid < 64) {                                   // |v|^2 of the previous iteration: all-reduce over the slice's workgroups
+            double pa;
+            const bool ok = gran_sum<(KS_GRAN_MAXG + 63) / 64>(gv[(ii - 1) & 1], G, tagB - 2u, pa);
+            if (tid == 0) { red[0] = pa; if (!ok) abort_flag = 1; }
+        }
+        lds_barrier();
+        if (abort_flag) { aborted = true; break; }
+        const double pa = red[0];
+        const double alpha = sqrt(pa + (O.ua * O.ua) * R);
+        const double inv_alpha = 1.0 / alpha, inv_bprev = 1.0 / O.beta;
+        double acc_b = 0.0, acc_t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NEQ; ++q) {
+            if (tid + KT * q < ne) {
+                const double2 ub = ub_update(make_double2(rcv[q].x * inv_alpha, rcv[q].y * inv_alpha), rub[q], sr, alpha, inv_bprev);
+                acc_b += ub.x * ub.x + ub.y * ub.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NSQ; ++q) {
+            const int j = tid + KT * q;
+            if (j < nsamp) {
+                const cd* vrow = vl + res[q].ls * s;
+                const double* Vt = vlds + res[q].t * s;
+                double re = 0.0, im = 0.0;
+                for (int c = 0; c < s; ++c) { re += Vt[c] * vrow[c].x; im += Vt[c] * vrow[c].y; }
+                double2 u;
+                u.x = re * inv_alpha - alpha * (rut[q].x * inv_bprev);     // A v - alpha (u / beta_prev)
+                u.y = im * inv_alpha - alpha * (rut[q].y * inv_bprev);
+                rut[q] = u;
+                ulds[j] = u;
+                acc_t += u.x * u.x + u.y * u.y;
+            }
+        }
+        block_sum2(acc_b, acc_t, red + 4);
+        if (tid == 0) { gran_store(gu[ii & 1] + g, acc_b, tagA); gran_store(gu[ii & 1] + G + g, acc_t, tagA); }
+        // ================= k_ks_b: what does not need beta first -- sum_t V(t,c) u(t,k) per scatter group =================
+        // (block_sum2's barriers follow the stores into ulds)
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q) {
+            const int gi = (tid + KT * q) / SL, sub = tid & (SL - 1);
+            if (gi < ng) {
+                const KsGroup gr = rg[q];
+                double xr[DC_MAXS], xi[DC_MAXS];
+#pragma unroll
+                for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
+                double2 u[DC_GCAP / SL];
+                int t[DC_GCAP / SL];
+#pragma unroll
+                for (int j = 0; j < DC_GCAP / SL; ++j) {
+                    const int e = gr.b + sub + SL * j;
+                    const bool okk = e < gr.e;
+                    u[j] = ulds[okk ? e : 0]; t[j] = tlds[okk ? e : 0];
+                    if (!okk) u[j] = make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < DC_GCAP / SL; ++j) {
+#pragma unroll
+                    for (int c = 0; c < DC_MAXS; ++c) {
+                        const double v = vlds[t[j] * s + c];
+                        xr[c] += v * u[j].x; xi[c] += v * u[j].y;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group8_sum(xr[c]); xi[c] = group8_sum(xi[c]); }
+                if (sub == 0) {
+#pragma unroll
+                    for (int c = 0; c < DC_MAXS; ++c) part[gi * DC_MAXS + c] = mk(xr[c], xi[c]);
+                }
+            }
+        }
+        if (tid < 64) {                                             // |u|^2: all-reduce
+            double pb;
+            const bool ok = gran_sum<(2 * KS_GRAN_MAXG + 63) / 64>(gu[ii & 1], 2 * G, tagA, pb);
+            if (tid == 0) { red[1] = pb; if (!ok) abort_flag = 1; }
+        }
+        lds_barrier();
+        if (abort_flag) { aborted = true; break; }
+        const double pb = red[1];
+        // ---- scalars + stopping tests (every thread, identical bits), exactly as k_ks_b<false>
+        const double ua_n = O.ua * inv_alpha;
+        const double ub_n = __fma_rn(ua_n, sr, -(alpha * (O.ub * inv_bprev)));
+        const double beta = sqrt(pb + (ub_n * ub_n) * R);
+        LsqrScalars S;
+        const double normar = alpha * O.factor;
+        S.norma = sqrt(O.norma * O.norma + alpha * alpha + beta * beta);
+        S.thet = -O.s * alpha;
+        const double rhot = O.c * alpha;
+        S.rho = sqrt(rhot * rhot + beta * beta);
+        S.c = rhot / S.rho;
+        S.s = -beta / S.rho;
+        S.phi = S.c * O.phibar;
+        S.phibar = S.s * O.phibar;
+        S.beta = beta; S.alpha = alpha;
+        bool conv = false;
+        if (normar == 0.0) conv = true;
+        if (normar / (S.norma * O.normr) <= ks.tol) conv = true;
+        if (O.normr <= tolb) conv = true;
+        S.normr = fabs(S.s) * O.normr;
+        S.factor = fabs(S.s * S.phi);
+        const double inv_beta = 1.0 / beta, thet = S.thet, inv_rho = 1.0 / S.rho, phi = S.phi;
+        S.uc = (ua_n - thet * O.uc) * inv_rho;
+        S.ue = O.ue + phi * S.uc;
+        S.ua = ((ub_n * inv_beta) * sr) - beta * ua_n;
+        S.ub = ub_n;
+        if (conv) { conv_iter = ii - 1; break; }
+        ue_final = S.ue;
+        // ---- vector updates on the unit's (slot, channel) elements, in registers
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < NEQ; ++q) {
+            const int i = tid + KT * q;
+            if (i < ne) {
+                const int ls = i / s, c = i - ls * s;
+                double qx = 0.0, qy = 0.0;
+                for (int gi = sgl[ls]; gi < sgl[ls + 1]; ++gi) { const cd p = part[gi * DC_MAXS + c]; qx += p.x; qy += p.y; }
+                const double vx = qx * inv_beta, vy = qy * inv_beta;
+                const double2 vh = make_double2(rcv[q].x * inv_alpha, rcv[q].y * inv_alpha);   // v = v/alpha
+                const double2 ub = ub_update(vh, rub[q], sr, alpha, inv_bprev);
+                rub[q] = ub;
+                double2 dd = rd[q];
+                dd.x = (vh.x - thet * dd.x) * inv_rho;            // d = (v - thet d)/rho
+                dd.y = (vh.y - thet * dd.y) * inv_rho;
+                rd[q] = dd;
+                rx[q].x += phi * dd.x; rx[q].y += phi * dd.y;     // x = x + phi d
+                const double2 vr = make_double2((vx + (ub.x * inv_beta) * sr) - beta * vh.x,
+                                                (vy + (ub.y * inv_beta) * sr) - beta * vh.y);   // v = B'u - beta v
+                rcv[q] = vr;
+                acc += vr.x * vr.x + vr.y * vr.y;
+            }
+        }
+        const double tot = block_sum(acc, red + 4);
+        if (tid == 0) gran_store(gv[ii & 1] + g, tot, tagB);
+        O = S;
+        lds_barrier();                                              // (vl / ulds / part / red are rewritten by the next iteration)
+    }
+    if (aborted) {
+        if (writer) { st->flag = 77; if (ks.hst) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; } }
+        return;
+    }
+    // ---- the solution x on the unit's slots (k_ks_final_w assembles the spectrum); scalars for the final kernels and the host
+#pragma unroll
+    for (int q = 0; q < NEQ; ++q) { const int i = tid + KT * q; if (i < ne) st_wt(ks.cx + cb + i, rx[q]); }
+    if (writer) {
+        st->ue_final = ue_final;
+        if (conv_iter >= 0) {
+            st->done = 1; st->flag = 0; st->iter = conv_iter;
+            if (ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = 0; h->iter = conv_iter; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_ks_final_w : one block per k-row kh.  Assemble xhat_out (the next x-update's xhat0; xhat itself stays untouched so the
 // kernel can be re-run), ||y - P xhat||^2 of the
 // row's samples (PnP_ADMM.m:106), then the conj-domain inverse w-pass into tmp (k_adj_h finishes the transform).
@@ -595,6 +864,35 @@ int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
+
+// All iterations in one launch (k_ks_persist).  *ran = false when the grid would not be resident at once, or the option is off:
+// the caller then iterates with ks_launch_iter.
+int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran) {
+    *ran = false;
+    if (ks.G > KS_GRAN_MAXG || ks.maxit < 1) return QMRI_OK;
+    const size_t vb = (size_t)ks.vcap * 8;
+    if (ctx->ks_persist_cap < 0) {
+        hipFuncAttributes fa;
+        QMRI_HIP(ctx, hipFuncGetAttributes(&fa, (const void*)k_ks_persist));
+        int nb = 0, ncu = 0;
+        if (fa.sharedSizeBytes + vb <= KS_LDS_TOTAL) {
+            QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_persist));
+            QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_ks_persist, KT, vb));
+        }
+        QMRI_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        // residency actually granted to 256-thread blocks = min(API answer, 8, floor(800 / (ceil(sgpr / 16) * 16 + 16))) per CU
+        // (MI355X_MICROARCH.md, "Residency and cooperative launch"); a kernel can use at most 102 SGPRs + VCC, i.e. >= 6 by that term
+        ctx->ks_persist_cap = std::min(nb, 6) * ncu;
+    }
+    if ((long)ks.G * B > ctx->ks_persist_cap) return QMRI_OK;
+    KsGran* gu = (KsGran*)gran;
+    KsGran* gv = gu + (size_t)B * 4 * ks.G;
+    k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0);
+    QMRI_HIP(ctx, hipGetLastError());
+    *ran = true;
+    return QMRI_OK;
+}
+size_t ks_gran_bytes(int G, int B) { return (size_t)B * 6 * G * sizeof(KsGran); }
 
 int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp) {
     switch (op.N) {

@@ -251,6 +251,10 @@ struct qmri_ctx {
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
+    int ks_persist = -1;                // k_ks_persist (all LSQR iterations in one launch): -1 = QMRI_LSQR_PERSIST (default on), 0 / 1 set by qmri_debug_lsqr_persist
+    int ks_persist_cap = -1;            // ... workgroups of it the device holds at once (occupancy query, first use)
+    void* d_ks_gran = nullptr;          // ... its tagged partial sums (granules)
+    unsigned ks_tag = 16;               // ... tag of the next solve's first granule (tags are unique across solves)
     int conv_ncu = 0;                   // f32-MFMA conv kernels (conv_kernels.hip): CU count and resident workgroups per CU by (kind, MT)
     int conv_occ[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 };
@@ -269,7 +273,9 @@ int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, d
 // k-space LSQR (kslsqr_kernels.hip)
 int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
 int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
-int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);   // tmp <- conj-domain inverse w-pass of xhat
+int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);
+int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran);   // all iterations in one launch
+size_t ks_gran_bytes(int G, int B);   // tmp <- conj-domain inverse w-pass of xhat
 int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok);   // V (vcap doubles) fits the LDS of every k-space LSQR kernel
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
                      double2* tmp, double2* x_out);

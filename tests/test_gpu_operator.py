@@ -68,6 +68,36 @@ def test_epi_operator_vs_oracle(engine_mod, oracle, case224):
     e.close()
 
 
+def test_lsqr_one_launch_equals_two_launch_iteration_bit_for_bit(engine_mod, oracle, case224):
+    """k_ks_persist (all iterations of a solve in one launch; the partial sums of the two norms per iteration cross workgroups as tagged
+    granules) against k_ks_a / k_ks_b (two launches per iteration): same arithmetic in the same order, so x, the iteration count and the
+    flag must be IDENTICAL -- at tol 1e-4 (the reference's), at a tight tolerance (45 iterations) and at the maxit cap; also on a grid
+    whose work units do not fill the chip (64 x 64) and with a warm start."""
+    rng = np.random.default_rng(11)
+    for N, S, T in ((224, 771, 200), (64, 200, 48)):
+        if N == 224:
+            V, fp, k, op, y = case224["dic"]["V"], case224["fp"], case224["k"], case224["op"], case224["y"]
+        else:
+            V = np.linalg.qr(rng.standard_normal((T, 10)))[0]
+            fp, k = oracle.spiral_mask(N, S, T)
+            op = oracle.Operator(N, N, V, fp, k)
+            y = op.forward(rng.standard_normal((N, N, 10))) + 0.01 * (rng.standard_normal(int(fp[-1])) + 1j * rng.standard_normal(int(fp[-1])))
+        e = engine_mod.Engine(0)
+        e.set_operator(N, N, V, fp, k)
+        x0 = op.adjoint(y)
+        z = x0 + 0.1 * (rng.standard_normal(x0.shape) + 1j * rng.standard_normal(x0.shape))
+        for tol, maxit, start in ((1e-4, 100, x0), (1e-10, 100, x0), (1e-12, 7, x0), (1e-4, 100, 0.5 * z), (1e-4, 1, x0)):
+            e.lsqr_persist(True)
+            xa, ita, fla = e.xupdate(y, z, 0.05, tol, maxit, start, solver="lsqr")
+            e.lsqr_persist(False)
+            xb, itb, flb = e.xupdate(y, z, 0.05, tol, maxit, start, solver="lsqr")
+            assert (ita, fla) == (itb, flb), (N, tol, maxit, ita, itb, fla, flb)
+            assert np.array_equal(xa, xb), (N, tol, maxit, rel_err(xa, xb))
+            xo, ito, flo, _ = op.lsqr(y, z, 0.05, tol, maxit, start)
+            assert (ita, fla) == (ito, flo) and rel_err(xa, xo) < 1e-10
+        e.close()
+
+
 def test_lsqr_xupdate_vs_oracle(eng, case224):
     op, y = case224["op"], case224["y"]
     x0 = op.adjoint(y)
