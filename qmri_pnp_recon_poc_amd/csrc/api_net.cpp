@@ -49,9 +49,6 @@ void qmri_free_net(qmri_ctx* ctx) {
     if (p.d_act_slots) (void)hipFree(p.d_act_slots);
     if (p.d_act_count) (void)hipFree(p.d_act_count);
     if (p.d_act_ref) (void)hipFree(p.d_act_ref);
-    if (p.chain_stream) { (void)hipStreamSynchronize(p.chain_stream); (void)hipStreamDestroy(p.chain_stream); }
-    if (p.chain_ev) (void)hipEventDestroy(p.chain_ev);
-    if (p.d_chain_cnt) (void)hipFree(p.d_chain_cnt);
     p = NetPlan();
 }
 
@@ -123,16 +120,9 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     if (!f) return QMRI_OK;
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
     if (p.h_range_flag) std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
-    tripped = true;
-    if (f & 4u) {
-        // bit 2: a chained conv launch gave up waiting for a tile of its predecessor (k_conv6<.., CHAIN>; never seen).  The tensors hold
-        // garbage: chaining is switched off for this network and the caller repeats its work with ordinary launches.
-        fprintf(stderr, "libqmri: a chained convolution timed out waiting for its input tiles; layers are launched one after the other from now on\n");
-        p.chain_on = 0;
-        if (!(f & 3u)) return QMRI_OK;
-    }
     QMRI_TRY(net_set_scheme(ctx, 3));
     p.fallbacks += 1;
+    tripped = true;
     return QMRI_OK;
 }
 
@@ -302,62 +292,14 @@ static int run_conv(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const
 
 // nb ResBlocks: cur <- cur + conv(relu(conv(cur)))  (basicblock.py:211-223).  `src` is the block input of the first
 // ResBlock (may be a skip tensor that must stay intact); results land in `cur`; `skip` is added by the last conv.
-// Two-stream chain (round 3): may the 2 nb layers starting at li run as a chain?  All of them on k_conv6 with one tile geometry, a grid
-// smaller than the device, one slice, f16 scheme, no graph capture / stamp diagnostics.
-static bool chain_run_possible(qmri_ctx* ctx, size_t li, int nlayers, int B, const PTensor& src, const PTensor& cur, const PTensor& tmp) {
-    NetPlan& p = ctx->net;
-    if (p.chain_on < 0) p.chain_on = (getenv("QMRI_CONV_CHAIN") && atoi(getenv("QMRI_CONV_CHAIN")) == 0) ? 0 : 1;
-    if (!p.chain_on || B != 1 || p.sp6 != 2 || p.force_f32 || !conv6_enabled() || p.d_stamps) return false;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    int cfg0 = -1, tiles0 = 0;
-    for (int k = 0; k < nlayers; ++k) {
-        const PTensor& in = (k & 1) ? tmp : (k == 0 ? src : cur);
-        const PTensor& out = (k & 1) ? cur : tmp;
-        int cfg, tiles;
-        conv6_chain_geometry(ctx, p.layers[li + k], B, in, out, &cfg, &tiles);
-        if (cfg < 0 || (k > 0 && (cfg != cfg0 || tiles != tiles0))) return false;
-        cfg0 = cfg; tiles0 = tiles;
-    }
-    if (!p.chain_stream) {
-        if (hipStreamCreateWithFlags(&p.chain_stream, hipStreamNonBlocking) != hipSuccess) { p.chain_stream = nullptr; return false; }
-        if (hipEventCreateWithFlags(&p.chain_ev, hipEventDisableTiming) != hipSuccess) return false;
-        p.chain_layers = (int)p.layers.size();
-        const size_t nb_ = (size_t)p.chain_layers * NetPlan::CHAIN_MAXT * sizeof(unsigned);
-        if (hipMalloc((void**)&p.d_chain_cnt, nb_) != hipSuccess) { p.d_chain_cnt = nullptr; return false; }
-        if (hipMemsetAsync(p.d_chain_cnt, 0, nb_, ctx->stream) != hipSuccess) return false;
-        p.chain_layer_gen.assign(p.layers.size(), 0u);
-    }
-    return p.d_chain_cnt != nullptr;
-}
-
-// nb ResBlocks: cur <- cur + conv(relu(conv(cur)))  (basicblock.py:211-223).  `src` is the block input of the first
-// ResBlock (may be a skip tensor that must stay intact); results land in `cur`; `skip` is added by the last conv.
 static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, const PTensor& src, const PTensor& cur, const PTensor& tmp,
                          const PTensor* skip) {
     NetPlan& p = ctx->net;
     const PTensor* in = &src;
-    // Chained form: the 2 nb launches alternate between the context's stream and chain_stream; every launch but the first waits, tile by
-    // tile, for the pixel tiles of its predecessor that it reads (k_conv6<.., CHAIN>) instead of for the predecessor's end.
-    const bool chain = chain_run_possible(ctx, li, 2 * nb, B, src, cur, tmp);
-    int k = 0;
-    bool last_alt = false;
     for (int b = 0; b < nb; ++b) {
-        p.chain_role = chain ? (k == 0 ? 1 : 2) : 0; p.chain_alt = chain ? (k & 1) : 0; p.chain_launched = false;
-        int st = run_conv(ctx, p.layers[li++], B, *in, tmp, nullptr, nullptr, 1);
-        last_alt = p.chain_launched && p.chain_alt; ++k;
-        if (st == QMRI_OK) {
-            p.chain_role = chain ? 2 : 0; p.chain_alt = chain ? (k & 1) : 0; p.chain_launched = false;
-            st = run_conv(ctx, p.layers[li++], B, tmp, cur, in, (b == nb - 1) ? skip : nullptr, 0);
-            last_alt = p.chain_launched && p.chain_alt; ++k;
-        }
-        p.chain_role = 0; p.chain_alt = 0;
-        if (st != QMRI_OK) return st;
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, *in, tmp, nullptr, nullptr, 1));
+        QMRI_TRY(run_conv(ctx, p.layers[li++], B, tmp, cur, in, (b == nb - 1) ? skip : nullptr, 0));
         in = &cur;
-    }
-    if (chain && last_alt) {                                       // the run's last launch went to the second stream: the context's stream continues behind it
-        QMRI_HIP(ctx, hipEventRecord(p.chain_ev, p.chain_stream));
-        QMRI_HIP(ctx, hipStreamWaitEvent(ctx->stream, p.chain_ev, 0));
     }
     return QMRI_OK;
 }

@@ -75,11 +75,6 @@ struct Conv6Args {
     ActMax am;                    // f16 scheme: where this launch reports the largest |output| (see ACT_LOW)
     float descale_hi, descale_lo; // f16 scheme: the layer's weights are packed times 2^k (largest |w| in [1, 2)): 2^-k and 2^-k / 2^11
     unsigned long long* stamps;   // diagnostic (QMRI_CONV_STAMPS): [16 workgroups][2 roles][128] barrier-arrival times, 100 MHz clock
-    // CHAIN (round 3): consecutive 3x3 layers of one UNet level run on TWO streams, so that a layer's workgroups start while its predecessor
-    // still runs; what orders them is a counter per pixel tile of the producing layer (see conv6_body)
-    const unsigned* chain_wait;   // the producing layer's counters [tiles_w][tiles_h], or null (first layer of a run)
-    unsigned chain_target;        // ... the value each of the <= 9 tiles this tile reads must have reached
-    unsigned* chain_done;         // this layer's counters, or null
 };
 
 // Workgroup tile = 64 output channels x (TH x TW) pixels.  A wave owns MW cout tiles (32 rows) x NCT pixel blocks of
@@ -153,7 +148,6 @@ __device__ __forceinline__ unsigned usgpr(unsigned v) {
 }
 __device__ __forceinline__ void bload4(u32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bload4f(f32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
-__device__ __forceinline__ void bload4f_sc1(f32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bload4f_o16(f32x4& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bstore4_o16(f32x4 x, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:16 sc1\n\ts_nop 1" ::"v"(x), "v"(voff), "s"(srd), "s"(soff) : "memory"); }
 __device__ __forceinline__ void bload1(float& dst, unsigned voff, u32x4 srd, unsigned soff) { asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory"); }
@@ -294,20 +288,7 @@ __device__ __forceinline__ void act_report(const ActMax& am, float tmax, int wav
 // (Measured and removed: streaming the residual operand into an LDS tile during the last 8 steps of the loop, so that the epilogue
 //  finds it on chip.  The loop is bound by the loader waves (tools/conv6p_stamps.py), so what the epilogue saved the loop lost:
 //  634.9 vs 634.9 ADMM it/s, residual layers 21.3 us either way against 17.8 us for layers without a residual operand.)
-// CHAIN (round 3; SP = 2, blocked tensors, one slice, no split-K): the launch may run BESIDE the launch of the layer that produces its input
-// (the host puts consecutive layers of a level on two streams).  Hand-off per pixel tile, the valid form "sc1 stores -> every storing
-// wave's vmcnt(0) -> workgroup barrier -> one lane's agent-scope atomic add; consumer: sc1 poll of the counter -> workgroup barrier ->
-// sc1 loads" of MI355X_MICROARCH.md (one workgroup per CU, hipMalloc memory, 16-byte accesses):
-//   producer  every wave waits for its write-through stores, the workgroup meets, one lane adds 1 to chain_done[pixel tile]
-//             (n_ct * MH workgroups add to one counter: all output channels of the tile);
-//   consumer  each loader wave polls the counters of the <= 9 tiles its halo tile reads (lanes 0..8, sc1 loads) until all have
-//             reached chain_target, then issues its requests -- every request of the handed-off tensors (B operand, residual
-//             operands) is an sc1 load; the MFMA waves' residual requests follow barrier 0 .. n, which the loader waves join
-//             after their poll.
-// This also covers the write-after-read side: a tile of layer n+1 overwrites `a` / `t` only after the 9 tiles of layer n that read
-// that region are done.  A time-out of the poll raises bit 2 of the range flag; the host then repeats the call without chaining.
-constexpr int CHAIN_SPIN_MAX = 1 << 16;
-template <int CFG, int SP, bool STAMP, bool INB, bool CHAIN = false>
+template <int CFG, int SP, bool STAMP, bool INB>
 __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     constexpr int AST = ast6(SP);
     typedef Cfg6<CFG> C;
@@ -414,8 +395,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #define LOAD_B(c_, part_, rb_)                                                                                   \
         {                                                                                                        \
             const unsigned so_ = ibase + (unsigned)(((c_) < A.nchunk) ? (c_) : A.nchunk - 1) * chunkB;           \
-            if constexpr (INB && CHAIN) { _Pragma("unroll") for (int q = 0; q < NBH; ++q) bload4f_sc1(rb_.q[q], boff[part_][q], srdI, so_); } \
-            else if constexpr (INB) { _Pragma("unroll") for (int q = 0; q < NBH; ++q) bload4f(rb_.q[q], boff[part_][q], srdI, so_); } \
+            if constexpr (INB) { _Pragma("unroll") for (int q = 0; q < NBH; ++q) bload4f(rb_.q[q], boff[part_][q], srdI, so_); } \
             else { _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_.v[j], boff[part_][j], srdI, so_); }  \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
@@ -457,22 +437,6 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         // only after the first batch had arrived: 1.36 us for step 0 against 0.8 in steady state).  The first chunk's second and third
         // part travel in prologue-only registers.
         C6_STAMP(2, 0);
-        if constexpr (CHAIN) {
-            if (A.chain_wait) {                                     // (wave-uniform) the tiles this halo tile reads must be complete
-                const int l9 = (int)(threadIdx.x & 63);
-                const int nth = th + l9 / 3 - 1, ntw = tw + l9 % 3 - 1;
-                const bool need = l9 < 9 && nth >= 0 && nth < A.tiles_h && ntw >= 0 && ntw < A.tiles_w;
-                const unsigned* cp = A.chain_wait + (need ? ntw * A.tiles_h + nth : tw * A.tiles_h + th);
-                bool ok = false;
-                for (int spin = 0; spin < CHAIN_SPIN_MAX; ++spin) {
-                    const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool mine = !need || (int)(v - A.chain_target) >= 0;
-                    if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) { ok = true; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                if (!ok && A.range_flag && l9 == 0) atomicOr(A.range_flag, 4u);
-            }
-        }
         {
             u32x4 pa1[NAQ], pa2[NAQ];
             BR pb1, pb2;
@@ -656,17 +620,6 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 off[k] = ok ? (unsigned)(((size_t)cb * A.out_plane + (size_t)(ow + 1) * A.out_hp + (oh + 1)) * 8 + 4 * half) : ~0u;
                 r1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r2[k] = r1[k];
             }
-            if constexpr (CHAIN) {
-                // (handed-off tensors: sc1 requests; asm loads are invisible to hipcc's counters, so the wait below names every destination)
-                if (has1) {
-#pragma unroll
-                    for (int k = 0; k < HQ; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r1[k]) : "v"(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 8u)) : "memory");
-                }
-                if (has2) {
-#pragma unroll
-                    for (int k = 0; k < HQ; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r2[k]) : "v"(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 8u)) : "memory");
-                }
-            } else {
             if (has1) {
 #pragma unroll
                 for (int k = 0; k < HQ; ++k) r1[k] = *(const f32x4*)(A.add1 + (size_t)b * A.add1_bs + ((off[k] != ~0u) ? off[k] : 8u));
@@ -675,12 +628,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 #pragma unroll
                 for (int k = 0; k < HQ; ++k) r2[k] = *(const f32x4*)(A.add2 + (size_t)b * A.add2_bs + ((off[k] != ~0u) ? off[k] : 8u));
             }
-            }
             lds_barrier6();                                         // the output tile is complete
-            if constexpr (CHAIN) {
-#pragma unroll
-                for (int k = 0; k < HQ; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r1[k]), "+v"(r2[k])::"memory");
-            }
 #pragma unroll
             for (int k = 0; k < HQ; ++k) {
                 const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
@@ -772,18 +720,11 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             act_report(A.am, tmax, NT6 / 64);
         }
     }
-    if constexpr (CHAIN) {
-        if (A.chain_done) {                                         // (uniform) publish the tile: stores acknowledged by every wave, then one add
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier6();
-            if (tid == 0) __hip_atomic_fetch_add(A.chain_done + tw * A.tiles_h + th, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     C6_STAMP(0, nsteps + 2);
     if constexpr (STAMP) { if (A.stamps && tid == 0 && blockIdx.x == 0) A.stamps[8192 + (A.launch_idx & 127) * 4 + 2] = wall_clock64(); }
 }
 
-template <int CFG, int SP, bool INB, bool STAMP = false, bool CHAIN = false> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP, STAMP, INB, CHAIN>(A); }
+template <int CFG, int SP, bool INB, bool STAMP = false> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP, STAMP, INB>(A); }
 
 // =====================================================================================================================
 // k_conv6p : persistent, software-pipelined form of k_conv6 (f16 x 3 scheme) for launches with several tiles per CU -- slice
@@ -1546,33 +1487,11 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     if (!ctx->conv6_attr[CFG][SP - 2]) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if constexpr (SP == 2 && CFG != 2) QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->conv6_attr[CFG][SP - 2] = true;
     }
     const int grid = C::MH * A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
-    A.chain_wait = nullptr; A.chain_target = 0; A.chain_done = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));                  // (profile level 2 only)
-    if constexpr (SP == 2 && CFG != 2) {
-        // CHAIN: the layer is part of a run of 3x3 layers of one level that the host spreads over two streams (net_chain_run, api_net.cpp)
-        NetPlan& net = ctx->net;
-        if (net.chain_role && in.blk && A.out_blk && !partial && ksplit == 1 && B == 1 && A.wt && !A.stamps) {
-            const int ntile_px = A.tiles_h * A.tiles_w, nprod = A.n_ct * C::MH;
-            if (ntile_px <= NetPlan::CHAIN_MAXT && L.index >= 0 && L.index < net.chain_layers) {
-                A.chain_done = net.d_chain_cnt + (size_t)L.index * NetPlan::CHAIN_MAXT;
-                net.chain_layer_gen[L.index] += 1u;                 // this launch adds nprod to each of its counters
-                if (net.chain_role == 2 && L.index >= 1) {           // (the producer is the previous layer, launched chained just before: same geometry)
-                    A.chain_wait = net.d_chain_cnt + (size_t)(L.index - 1) * NetPlan::CHAIN_MAXT;
-                    A.chain_target = net.chain_layer_gen[L.index - 1] * (unsigned)nprod;
-                }
-                hipStream_t st = net.chain_alt ? net.chain_stream : ctx->stream;
-                net.chain_launched = true;
-                hipExtLaunchKernelGGL((k_conv6<CFG, SP, true, false, true>), dim3(grid), dim3(NT6), (std::uint32_t)lds, st, e0, e1, 0, A);
-                QMRI_HIP(ctx, hipGetLastError());
-                return QMRI_OK;
-            }
-        }
-    }
     if constexpr (SP == 2 && CFG < 2) {
         if (A.stamps) {                                             // QMRI_CONV_STAMPS: the diagnostic instantiation (tools/conv6_stamps.py)
             if (in.blk) {
@@ -1790,7 +1709,7 @@ __global__ __launch_bounds__(256) void k_act_check(const float* __restrict__ slo
         }
         if (host_words) {
             host_words[1 + layer] = low ? 2u : 0u;
-            if (layer == 0) host_words[0] = __hip_atomic_load(range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 5u;   // (bits 0 and 2 -- overflow, chain time-out: set by kernels that are over)
+            if (layer == 0) host_words[0] = __hip_atomic_load(range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;   // (bit 0: set by kernels that are over)
         }
     }
 }
@@ -2005,15 +1924,14 @@ int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, c
     return QMRI_OK;
 }
 
-// Tile configuration (Cfg6) and K split of a 3x3 layer.  The largest pixel tile that still gives most CUs a workgroup (one workgroup per CU is
-// the design point); tiles may overhang the image -- the kernel masks its stores -- as long as the padded area stays below 1.35 x the image.
-// Small feature maps with many channels: see the comments at the measurements below.
-static void conv6_pick(const ConvLayer& L, int B, const PTensor& in, int& cfg, int& ksplit) {
+int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
+                 const PTensor* add2, int relu_out) {
+    // the largest pixel tile that still gives most CUs a workgroup (one workgroup per CU is the design point)
     auto ntiles = [&](int th, int tw) { return (long)L.n_ct6 * ((in.H + th - 1) / th) * ((in.W + tw - 1) / tw) * B; };
+    // (tiles may overhang the image -- the kernel masks its stores -- as long as the padded area stays below 1.35 x the image)
     auto waste = [&](int th, int tw) { return (double)(((in.H + th - 1) / th) * th) * (((in.W + tw - 1) / tw) * tw) / ((double)in.H * in.W); };
-    ksplit = 1;
-    if (ntiles(16, 16) >= 160 && waste(16, 16) <= 1.35) { cfg = 0; return; }
-    if (ntiles(16, 8) >= 160 && waste(16, 8) <= 1.35) { cfg = 1; return; }
+    if (ntiles(16, 16) >= 160 && waste(16, 16) <= 1.35) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
+    if (ntiles(16, 8) >= 160 && waste(16, 8) <= 1.35) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
     // Small feature maps with many channels (the 28 x 28 x 512 level): a 64-pixel tile would re-read the layer's weights
     // once per tile (16 x 14 MB); instead keep the 256-pixel tile and split K over workgroups, then add the partial
     // outputs in slice order (deterministic) in a second, elementwise kernel.
@@ -2033,52 +1951,16 @@ static void conv6_pick(const ConvLayer& L, int B, const PTensor& in, int& cfg, i
         // 28 x 28 level: tile config and largest K split.  Measured with blocked tensors on one box (ADMM it/s, two runs each):
         // 256-pixel tiles x 8 slices (the round-1 choice) 701.6 | x 4: 695 | 128-pixel x 4: 715 | x 2: 695 | 64-pixel x 2: 717.6 | x 1: 679;
         // then, on another box: 64-pixel x 2 (and 64-pixel unsplit at 56 x 56) 743 | configuration 3 at both levels, K over 2: 751.6 | over 4: 756
+        const int deep_cfg = deep_cfg_g;
         static const int deep_ks = getenv("QMRI_CONV_DEEPKS") ? atoi(getenv("QMRI_CONV_DEEPKS")) : 4;
         const bool deep = in.H <= 32;
-        const int c = deep ? deep_cfg_g : mid_cfg;
-        const long nt = (c == 0) ? ntiles(16, 16) : (c == 1) ? ntiles(16, 8) : (c == 2) ? ntiles(8, 8) : 2 * ntiles(16, 8);
-        int ks = 1;
-        while ((deep || c < 2) && c >= 0 && ks * 2 * nt <= 256 && ks * 2 <= (deep ? deep_ks : 8) && L.nchunk6 % (ks * 2) == 0 &&
-               L.nchunk6 / (ks * 2) >= 4)
-            ks *= 2;
-        if (ks > 1 && in.H <= 64) { cfg = (c >= 0 && c <= 3) ? c : 3; ksplit = ks; return; }
-    }
-    cfg = (L.nchunk6 >= 16 && L.Cout % 64 == 0 && ((in.H <= 32) ? deep_cfg_g : mid_cfg) == 3) ? 3 : 2;
-}
-
-// Can this layer take part in a two-stream chain (k_conv6<.., CHAIN>)?  Returns the pixel-tile grid it would use, 0 x 0 if not.
-void conv6_chain_geometry(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, int* cfg_out, int* tiles_out) {
-    *cfg_out = -1; *tiles_out = 0;
-    if (B != 1 || L.sp6 != 2 || !L.wp6 || !in.blk || !out.blk || (L.kind != CONV_3X3 && L.kind != CONV_3X3N)) return;
-    int cfg, ks;
-    conv6_pick(L, B, in, cfg, ks);
-    if (ks != 1 || cfg == 2) return;
-    const int th = 16, tw = (cfg == 0) ? 16 : 8;
-    const int tiles = ((in.H + th - 1) / th) * ((in.W + tw - 1) / tw);
-    const int mh = (cfg == 3) ? 2 : 1;
-    if (!ctx->conv_ncu) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return;
-        ctx->conv_ncu = prop.multiProcessorCount;
-    }
-    // every workgroup of the launch must find a CU while the producing launch still holds its own (one workgroup per CU by LDS size):
-    // a launch of fewer workgroups than CUs always leaves the other launch room to finish
-    if ((long)tiles * L.n_ct6 * mh >= ctx->conv_ncu || tiles > NetPlan::CHAIN_MAXT) return;
-    *cfg_out = cfg; *tiles_out = tiles;
-}
-
-int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
-                 const PTensor* add2, int relu_out) {
-    int cfg, ksplit;
-    conv6_pick(L, B, in, cfg, ksplit);
-    if (ksplit == 1) {
-        if (cfg == 0) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
-        if (cfg == 1) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
-        if (cfg == 3) return launch6<3>(ctx, L, B, in, out, add1, add2, relu_out);
-        return launch6<2>(ctx, L, B, in, out, add1, add2, relu_out);
-    }
-    {
-        {
+        const int cfg = deep ? deep_cfg : mid_cfg;
+        const long nt = (cfg == 0) ? ntiles(16, 16) : (cfg == 1) ? ntiles(16, 8) : (cfg == 2) ? ntiles(8, 8) : 2 * ntiles(16, 8);
+        int ksplit = 1;
+        while ((deep || cfg < 2) && cfg >= 0 && ksplit * 2 * nt <= 256 && ksplit * 2 <= (deep ? deep_ks : 8) && L.nchunk6 % (ksplit * 2) == 0 &&
+               L.nchunk6 / (ksplit * 2) >= 4)
+            ksplit *= 2;
+        if (ksplit > 1 && in.H <= 64) {
             const long out_ks = (long)B * out.Cal * out.plane();
             const size_t need = (size_t)ksplit * out_ks + 8192;
             NetPlan& net = ctx->net;
@@ -2116,4 +1998,6 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
             return QMRI_OK;
         }
     }
+    if (L.nchunk6 >= 16 && L.Cout % 64 == 0 && ((in.H <= 32) ? deep_cfg_g : mid_cfg) == 3) return launch6<3>(ctx, L, B, in, out, add1, add2, relu_out);
+    return launch6<2>(ctx, L, B, in, out, add1, add2, relu_out);
 }

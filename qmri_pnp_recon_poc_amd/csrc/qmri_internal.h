@@ -188,17 +188,6 @@ struct NetPlan {
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
-    // Two-stream chains of 3x3 layers (round 3; conv6_kernels.hip CHAIN, api_net.cpp run_resblocks): the layers of one UNet level alternate
-    // between the context's stream and chain_stream, ordered by per-pixel-tile counters instead of kernel boundaries
-    static constexpr int CHAIN_MAXT = 256;        // pixel tiles per layer (counters per layer)
-    hipStream_t chain_stream = nullptr;
-    hipEvent_t chain_ev = nullptr;
-    unsigned* d_chain_cnt = nullptr;              // [chain_layers][CHAIN_MAXT] completed workgroups per pixel tile, ever increasing
-    int chain_layers = 0;
-    std::vector<unsigned> chain_layer_gen;        // chained launches of each layer so far (host mirror of what its counters will reach)
-    int chain_on = -1;                            // -1: QMRI_CONV_CHAIN (default on); 0 after a poll time-out
-    int chain_role = 0, chain_alt = 0;            // set around a launch by run_resblocks: 1 = first layer of a run, 2 = later layer; second stream
-    bool chain_launched = false;                  // the launcher took the chained form
     bool ready = false;
 };
 
@@ -326,7 +315,6 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
                  const PTensor* add2, int relu_out);
 void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);   // 2x2 / stride-2 layers
 bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out);
-void conv6_chain_geometry(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, int* cfg_out, int* tiles_out);
 int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out);
 size_t conv_pack_weights(const ConvLayer& L, const float* w_src, std::vector<float>& packed);
 void conv_plan_layer(ConvLayer& L, ConvKind kind, int Cin, int Cout);
