@@ -236,7 +236,9 @@ int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset);
 int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out);
 int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int reserved);
 /* Test / A-B hook: the LSQR x-update (PnP_ADMM.m:102) runs all its iterations in ONE launch where the operator's work units are resident at
- * once (default; same bits as the two-launch iteration); on = 0 selects the two-launch iteration.  Also QMRI_LSQR_PERSIST=0. */
+ * once (default; same bits as the two-launch iteration); on = 0 selects the two-launch iteration (also QMRI_LSQR_PERSIST=0); on = 2 makes
+ * the one-launch kernel lose a partial sum on purpose: its waits time out, the library reports it on stderr and repeats the solve with the
+ * two-launch iteration (the recovery path, tested). */
 int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on);
 
 #ifdef __cplusplus

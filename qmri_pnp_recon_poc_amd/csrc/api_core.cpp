@@ -642,7 +642,7 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
 // test / A-B hook: 1 = all LSQR iterations in one launch where the grid is resident (default), 0 = the two-launch iteration
 extern "C" int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
-    ctx->ks_persist = on ? 1 : 0;
+    ctx->ks_persist = (on == 2) ? 2 : (on ? 1 : 0);               // (2: test hook -- one partial sum is withheld, the time-out path must take over)
     return QMRI_OK;
 }
 

@@ -484,7 +484,7 @@ __device__ __forceinline__ bool gran_sum(KsGran* g, int n, unsigned tag, double&
     return ok;
 }
 
-__global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0) {
+__global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop) {
     __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]   (k_ks_a)
     __shared__ double2 ulds[KS_ECAP];                      // u(1:m) of the unit's samples        (k_ks_b)
     __shared__ cd part[KS_GCAPB * DC_MAXS];
@@ -580,7 +580,8 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
             }
         }
         block_sum2(acc_b, acc_t, red + 4);
-        if (tid == 0) { gran_store(gu[ii & 1] + g, acc_b, tagA); gran_store(gu[ii & 1] + G + g, acc_t, tagA); }
+        // (test_drop: the test hook of the time-out path -- one workgroup withholds one partial sum, every waiter must give up cleanly)
+        if (tid == 0 && !(test_drop && g == 1 && ii == 2)) { gran_store(gu[ii & 1] + g, acc_b, tagA); gran_store(gu[ii & 1] + G + g, acc_t, tagA); }
         // ================= k_ks_b: what does not need beta first -- sum_t V(t,c) u(t,k) per scatter group =================
         // (block_sum2's barriers follow the stores into ulds)
 #pragma unroll
@@ -887,7 +888,7 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, vo
     if ((long)ks.G * B > ctx->ks_persist_cap) return QMRI_OK;
     KsGran* gu = (KsGran*)gran;
     KsGran* gv = gu + (size_t)B * 4 * ks.G;
-    k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0);
+    k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0);
     QMRI_HIP(ctx, hipGetLastError());
     *ran = true;
     return QMRI_OK;

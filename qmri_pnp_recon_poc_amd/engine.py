@@ -196,7 +196,7 @@ class Engine:
 
     def lsqr_persist(self, on: bool):
         """Test / A-B hook (qmri_debug_lsqr_persist): all LSQR iterations of an x-update in one launch (default) or two launches per iteration."""
-        self._check(self.L.qmri_debug_lsqr_persist(self.h, int(bool(on))))
+        self._check(self.L.qmri_debug_lsqr_persist(self.h, 2 if on == 2 else int(bool(on))))
 
     def denoiser_scheme(self):
         """(scheme, fallbacks): 2 = f16 x 3 products, 3 = bf16 x 6 products; how often a run-time guard switched 2 -> 3."""

@@ -98,6 +98,27 @@ def test_lsqr_one_launch_equals_two_launch_iteration_bit_for_bit(engine_mod, ora
         e.close()
 
 
+def test_lsqr_one_launch_time_out_falls_back_to_two_launch_iteration(engine_mod, oracle, case224, capfd):
+    """The recovery path of k_ks_persist: with the test hook (mode 2) one workgroup withholds a partial sum, every waiting wave gives up after
+    its bounded spin, nothing is stored, the library says so on stderr, repeats the solve with the two-launch iteration from the untouched
+    inputs -- same x, count and flag -- and stays on the two-launch iteration afterwards."""
+    op, y = case224["op"], case224["y"]
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, case224["dic"]["V"], case224["fp"], case224["k"])
+    x0 = op.adjoint(y)
+    z = 0.9 * x0
+    e.lsqr_persist(False)
+    xb, itb, flb = e.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    e.lsqr_persist(2)
+    xa, ita, fla = e.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    err = capfd.readouterr().err
+    assert "timed out" in err
+    assert (ita, fla) == (itb, flb) and np.array_equal(xa, xb)
+    xc, itc, flc = e.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")     # (now on the two-launch iteration: no second message)
+    assert "timed out" not in capfd.readouterr().err and np.array_equal(xc, xb)
+    e.close()
+
+
 def test_lsqr_xupdate_vs_oracle(eng, case224):
     op, y = case224["op"], case224["y"]
     x0 = op.adjoint(y)
