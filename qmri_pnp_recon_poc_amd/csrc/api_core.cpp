@@ -299,7 +299,13 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
             for (int kp = 0; kp < NM; ++kp) if (kslot[kp] >= 0) sptr[j++] = o.kptr_h[kp];
             sptr[ns] = m;
         }
-        const int target = std::max(1, (m + 255) / 256);
+        // Units of similar sample count, about one per CU.  The one-launch iteration (k_ks_persist) is paced by its slowest workgroup, and two
+        // workgroups that share a CU are the slow ones: where the caps allow, the cut is repeated with fewer, larger units until at most
+        // 250 result (263 at the headline operator with the first cut: 7 CUs held two).
+        int want = 256;
+        for (int attempt = 0; attempt < 8; ++attempt, want -= 8) {
+        bslot.clear(); gptr.clear(); grp.clear();
+        const int target = std::max(1, (m + want - 1) / want);
         int j = 0;
         while (j < ns) {
             const int first = j, e0 = sptr[j];
@@ -321,6 +327,8 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
                 ngr += gj;
                 ++j;
             }
+        }
+        if ((int)bslot.size() <= 250 || (int)bslot.size() > 320) break;     // (> 320: an operator with many more units than CUs; nothing to gain)
         }
         bslot.push_back(ns);
         gptr.push_back((int32_t)grp.size());

@@ -449,10 +449,11 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
 struct KsGran { unsigned long long w0, w1; };                       // {lo32(value) | tag << 32}, {hi32(value) | tag << 32}
 constexpr int KS_SPIN_MAX = 1 << 17;                                 // polls before a waiting wave gives up (~0.1-0.3 s)
 
+typedef __attribute__((address_space(1))) unsigned long long gu64;   // global address space: global_load / global_store ... sc1, never flat_
 __device__ __forceinline__ void gran_store(KsGran* g, double v, unsigned tag) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
-    __hip_atomic_store(&g->w0, (b & 0xFFFFFFFFull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&g->w1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu64*)&g->w0, (b & 0xFFFFFFFFull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu64*)&g->w1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // canonical sum of n granules (n <= 64 * NQ) by one wave, in the order of wave_sum(); returns false on time-out.  Lane 0 holds the sum.
@@ -467,8 +468,8 @@ __device__ __forceinline__ bool gran_sum(KsGran* g, int n, unsigned tag, double&
         for (int q = 0; q < NQ; ++q) {
             const int i = lane + 64 * q;
             KsGran* e = g + ((i < n) ? i : 0);
-            const unsigned long long a = __hip_atomic_load(&e->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long b = __hip_atomic_load(&e->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long a = __hip_atomic_load((gu64*)&e->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load((gu64*)&e->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             all = all && ((unsigned)(a >> 32) == tag) && ((unsigned)(b >> 32) == tag);
             r[q] = __longlong_as_double((long long)((a & 0xFFFFFFFFull) | (b << 32)));
         }
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     __shared__ int abort_flag;
     extern __shared__ __align__(16) unsigned char smem[];
     double* vlds = (double*)smem;
-    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, s = op.s, G = ks.G;
+    constexpr int s = DC_MAXS;                             // (the launcher requires op.s == DC_MAXS, the reference's 10 channels: row pitches become constants)
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, G = ks.G;
     LsqrState* st = ks.st + b;
     const KsUnit un = ks.unit[g];
     const int s0 = un.s0, s1 = un.s1, nsl = s1 - s0, ne = nsl * s;
@@ -540,11 +542,32 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     int conv_iter = -1;
     bool aborted = false;
 
+// (diagnostic, QMRI_LSQR_STAMPS=1: 100 MHz stamps of iteration 50, read by tools/lsqr_persist_stamps.py)
+#define PS(k) do { if (ks.stamps && ii == 50 && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 512) ks.stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
     for (int ii = 1; ii <= ks.maxit; ++ii) {
         const unsigned tagA = tag0 + 2u * (unsigned)ii, tagB = tagA + 1u;
+        PS(0);
         // ================= k_ks_a: u = B v - alpha (u / beta_prev) =================
+        // alpha = |v| needs the all-reduce of the previous iteration's partial sums; A v (un-normalised: sum_c V(t,c) v(k,c) per sample) does
+        // not, so it is computed in front of the wait and covers the hand-off's latency
 #pragma unroll
         for (int q = 0; q < NEQ; ++q) { const int i = tid + KT * q; if (i < ne) vl[i] = rcv[q]; }
+        lds_barrier();
+        double sre[NSQ], sim[NSQ];
+#pragma unroll
+        for (int q = 0; q < NSQ; ++q) {
+            const int j = tid + KT * q;
+            sre[q] = 0.0; sim[q] = 0.0;
+            if (j < nsamp) {
+                const cd* vrow = vl + res[q].ls * s;
+                const double* Vt = vlds + res[q].t * s;
+                double re = 0.0, im = 0.0;
+#pragma unroll
+                for (int c = 0; c < s; ++c) { re += Vt[c] * vrow[c].x; im += Vt[c] * vrow[c].y; }
+                sre[q] = re; sim[q] = im;
+            }
+        }
+        PS(1);
         if (ii > 1 && tid < 64) {                                   // |v|^2 of the previous iteration: all-reduce over the slice's workgroups
             double pa;
             const bool ok = gran_sum<(KS_GRAN_MAXG + 63) / 64>(gv[(ii - 1) & 1], G, tagB - 2u, pa);
@@ -567,19 +590,17 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
         for (int q = 0; q < NSQ; ++q) {
             const int j = tid + KT * q;
             if (j < nsamp) {
-                const cd* vrow = vl + res[q].ls * s;
-                const double* Vt = vlds + res[q].t * s;
-                double re = 0.0, im = 0.0;
-                for (int c = 0; c < s; ++c) { re += Vt[c] * vrow[c].x; im += Vt[c] * vrow[c].y; }
                 double2 u;
-                u.x = re * inv_alpha - alpha * (rut[q].x * inv_bprev);     // A v - alpha (u / beta_prev)
-                u.y = im * inv_alpha - alpha * (rut[q].y * inv_bprev);
+                u.x = sre[q] * inv_alpha - alpha * (rut[q].x * inv_bprev);     // A v - alpha (u / beta_prev)
+                u.y = sim[q] * inv_alpha - alpha * (rut[q].y * inv_bprev);
                 rut[q] = u;
                 ulds[j] = u;
                 acc_t += u.x * u.x + u.y * u.y;
             }
         }
+        PS(2);
         block_sum2(acc_b, acc_t, red + 4);
+        PS(3);
         // (test_drop: the test hook of the time-out path -- one workgroup withholds one partial sum, every waiter must give up cleanly)
         if (tid == 0 && !(test_drop && g == 1 && ii == 2)) { gran_store(gu[ii & 1] + g, acc_b, tagA); gran_store(gu[ii & 1] + G + g, acc_t, tagA); }
         // ================= k_ks_b: what does not need beta first -- sum_t V(t,c) u(t,k) per scatter group =================
@@ -617,12 +638,14 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
                 }
             }
         }
+        PS(4);
         if (tid < 64) {                                             // |u|^2: all-reduce
             double pb;
             const bool ok = gran_sum<(2 * KS_GRAN_MAXG + 63) / 64>(gu[ii & 1], 2 * G, tagA, pb);
             if (tid == 0) { red[1] = pb; if (!ok) abort_flag = 1; }
         }
         lds_barrier();
+        PS(5);
         if (abort_flag) { aborted = true; break; }
         const double pb = red[1];
         // ---- scalars + stopping tests (every thread, identical bits), exactly as k_ks_b<false>
@@ -653,6 +676,7 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
         S.ub = ub_n;
         if (conv) { conv_iter = ii - 1; break; }
         ue_final = S.ue;
+        PS(6);
         // ---- vector updates on the unit's (slot, channel) elements, in registers
         double acc = 0.0;
 #pragma unroll
@@ -677,10 +701,12 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
                 acc += vr.x * vr.x + vr.y * vr.y;
             }
         }
+        PS(7);
         const double tot = block_sum(acc, red + 4);
         if (tid == 0) gran_store(gv[ii & 1] + g, tot, tagB);
         O = S;
         lds_barrier();                                              // (vl / ulds / part / red are rewritten by the next iteration)
+        PS(8);
     }
     if (aborted) {
         if (writer) { st->flag = 77; if (ks.hst) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; } }
@@ -870,7 +896,7 @@ int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
 // the caller then iterates with ks_launch_iter.
 int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran) {
     *ran = false;
-    if (ks.G > KS_GRAN_MAXG || ks.maxit < 1) return QMRI_OK;
+    if (ks.G > KS_GRAN_MAXG || ks.maxit < 1 || op.s != DC_MAXS) return QMRI_OK;    // (the kernel is written for the reference's s = 10)
     const size_t vb = (size_t)ks.vcap * 8;
     if (ctx->ks_persist_cap < 0) {
         hipFuncAttributes fa;
