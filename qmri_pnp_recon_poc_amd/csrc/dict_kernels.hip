@@ -69,7 +69,10 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
     __shared__ int s_idx[4][32];
     __shared__ float s_re[4][32];
     __shared__ float s_im[4][32];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (the wave number as a SCALAR: the tile counter, its bound checks and the fragment pointers of the loop below then live on the scalar
+    //  unit -- round 3: a PMC pass showed the f32 MFMA and the vector ALU not to overlap (MFMA busy 0.67 + VALU 0.35 of the launch), so every
+    //  vector instruction of the loop is paid in full; 8 of its ~43 were tile-address arithmetic)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
     const int p = blockIdx.x * 32 + j;
     // B fragments: B[k = 2q + h][j] = x(p, c = 2q + h)  (real chain) and -imag (conjugate) for the imaginary chain
@@ -97,13 +100,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
 #pragma unroll
         for (int v = 0; v < NV; ++v) av[v] = ap[v];
     }
-    for (int t = tbeg + wave; t < ntiles; t += 4) {
-        {
-            const int tn = (t + 4 < ntiles) ? t + 4 : t;           // (clamped: the last tile is requested twice)
-            const f32x4* ap = (const f32x4*)(pack + ((size_t)tn * 64 + lane) * NPL);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) avn[v] = ap[v];
-        }
+    auto tile_body = [&](int t, const f32x4 (&av)[NV]) __attribute__((always_inline)) {
         f32x16 are = {0}, aim = {0};
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
@@ -136,8 +133,21 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; cre = are[r]; cim = aim[r]; }     // (ascending rows = ascending atoms)
             bidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;          // C/D row of the 32x32 MFMA tile
         }
+    };
+    {
+        int t = tbeg + wave;
+        for (; t + 4 < ntiles; t += 8) {
+            { const f32x4* ap = (const f32x4*)(pack + ((size_t)(t + 4) * 64 + lane) * NPL);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) av[v] = avn[v];
+              for (int v = 0; v < NV; ++v) avn[v] = ap[v]; }
+            tile_body(t, av);
+            { const int tn = (t + 8 < ntiles) ? t + 8 : t + 4;      // (clamped: the last tile is requested twice)
+              const f32x4* ap = (const f32x4*)(pack + ((size_t)tn * 64 + lane) * NPL);
+#pragma unroll
+              for (int v = 0; v < NV; ++v) av[v] = ap[v]; }
+            tile_body(t + 4, avn);
+        }
+        if (t < ntiles) tile_body(t, av);                           // an odd last tile (its fragments are in `av` either way)
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
     {
