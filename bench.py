@@ -168,17 +168,18 @@ def parity_numbers(x_gpu, x_cpu, maps_gpu, maps_cpu, iters, dic=None) -> dict:
 
 
 def load_traffic(B: int):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes.  The passes were taken on ONE kernel at ONE
-    batch size (recorded in the file: `batch`, default 1 = k_conv6<0, 2> with 196 workgroups); a run whose dominant kernel is another
-    one (the persistent k_conv6p of slice batches) reports null instead of bytes that describe a different grid."""
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes.  The passes are taken per kernel and batch size
+    (recorded in the file): profiles/conv_traffic.json = k_conv6<0, 2> at one slice per launch, profiles/conv_traffic_batch<B>.json = the
+    persistent k_conv6p of slice batches.  A run whose dominant kernel / batch has no pass reports null, not another grid's bytes."""
+    path = TRAFFIC_FILE if B == 1 else os.path.join(ROOT, "profiles", f"conv_traffic_batch{B}.json")
     try:
-        with open(TRAFFIC_FILE) as f:
+        with open(path) as f:
             t = json.load(f)
         if int(t.get("batch", 1)) != B:
-            return None, f"no PMC pass for batch {B} (profiles/conv_traffic.json was measured at batch {int(t.get('batch', 1))}: {t.get('kernel')})"
+            return None, f"no PMC pass for batch {B}"
         return int(t["corrected_bytes_per_launch_per_slice"] * B), t.get("source")
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, (None if B == 1 else f"no PMC pass for batch {B} (profiles/conv_traffic_batch{B}.json)")
 
 
 def atom_tolerance(K: int) -> float:

@@ -6,6 +6,8 @@ that guide's HBM section prescribes, written to profiles/conv_traffic.json (whic
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_net.py 1 3
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_net.py 1 3
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [profiles/rNN_pmc_conv_traffic.txt]
+    python tools/pmc_traffic.py --batch 15 gpurun_out/pmc_fetch15 gpurun_out/pmc_write15 [txt]     (passes taken on tools/prof_net.py 15 2: the
+        persistent k_conv6p<0, ..> of slice batches; writes profiles/conv_traffic_batch15.json, which bench.py --workload slices reports)
 
 Corrections.  FETCH_SIZE / WRITE_SIZE are in KB (x 1024).  On gfx950 FETCH_SIZE counts a 16-byte-per-lane coalesced read at exactly half
 its bytes; WRITE_SIZE is exact for 16-byte-per-lane stores.  With BLOCKED interior tensors (k_conv6<.., true, ..>: DESIGN.md section 4)
@@ -33,8 +35,55 @@ def rows(d, counter):
     return sorted(out)
 
 
+def main_batch(dfetch, dwrite, batch):
+    """The persistent kernel of slice batches at the 224 x 224 x 64 level: k_conv6p<0, NRES>, one launch = `batch` slices = batch * 196 tiles
+    on 256 workgroups.  Populations by the template argument NRES (0 plain, 1 one residual operand, 2 residual + skip)."""
+    per = {}
+    for nres in (0, 1, 2):
+        tagname = "k_conv6p<0, %d" % nres
+        f = sorted(v for (_, n, g, v) in rows(dfetch, "FETCH_SIZE") if tagname in n)
+        w = sorted(v for (_, n, g, v) in rows(dwrite, "WRITE_SIZE") if tagname in n)
+        # the 224 x 224 level's launches are the ones that write batch * 12.8 MB (the 112 x 112 level writes half of that)
+        w224 = [v for v in w if abs(v * 1024 - batch * ALG["output"]) < 0.05 * batch * ALG["output"]]
+        n224 = len(w224)
+        if not n224 or not f:
+            continue
+        f224 = f[-n224:] if nres else f[len(f) - n224:]              # the level with the largest tensors fetches most
+        med = lambda a: sorted(a)[len(a) // 2]
+        per[nres] = {"launches": n224, "fetch_counted": int(med(f224) * 1024), "write": int(med(w224) * 1024)}
+    if 0 not in per or 1 not in per:
+        raise SystemExit("no k_conv6p<0, 0 / 1> launches of the 224 x 224 level found: " + str(per))
+    alg_plain = batch * (ALG["input_with_halo"] + ALG["output"]) + ALG["weights_f16_pairs"] * 256       # (every workgroup streams the layer's weights once per tile: from L2)
+    alg = {0: batch * (ALG["input_with_halo"] + ALG["output"]), 1: batch * (ALG["input_with_halo"] + ALG["output"] + ALG["residual"]),
+           2: batch * (ALG["input_with_halo"] + ALG["output"] + 2 * ALG["residual"])}
+    res_counted = per[1]["fetch_counted"] - per[0]["fetch_counted"]
+    out = {"kernel": "k_conv6p<0, NRES> (224 x 224 x 64 level, %d slices per launch, 256 persistent workgroups)" % batch, "batch": batch,
+           "per_nres": {}, "residual_read_as_counted": int(res_counted), "residual_read_true": batch * ALG["residual"],
+           "tensor_format": "blocked [c/8][w][h][8]",
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/prof_net.py %d 2; tools/pmc_traffic.py --batch; FETCH x2 "
+                     "(16 B per lane requests; the residual share as counted = half its bytes confirms the factor)" % batch}
+    tot_b, tot_n = 0.0, 0
+    for nres, d in per.items():
+        corr = 2 * d["fetch_counted"] + d["write"]
+        out["per_nres"][str(nres)] = {**d, "corrected_bytes": int(corr), "algorithmic_bytes": int(alg[nres]), "ratio": round(corr / alg[nres], 3)}
+        tot_b += corr * d["launches"]; tot_n += d["launches"]
+    out["corrected_bytes_per_launch_per_slice"] = int(tot_b / tot_n / batch)
+    with open(os.path.join(ROOT, "profiles", "conv_traffic_batch%d.json" % batch), "w") as fh:
+        json.dump(out, fh, indent=1)
+    txt = json.dumps(out, indent=1)
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as fh:
+            fh.write(txt + "\n")
+    print(txt)
+
+
 def main():
+    batch = 1
+    if sys.argv[1] == "--batch":
+        batch = int(sys.argv[2]); del sys.argv[1:3]
     dfetch, dwrite = sys.argv[1], sys.argv[2]
+    if batch > 1:
+        return main_batch(dfetch, dwrite, batch)
     sel = lambda rs: [v for (_, n, g, v) in rs if "k_conv6<0, 2" in n and g == 196 * 512]
     f, w = sel(rows(dfetch, "FETCH_SIZE")), sel(rows(dwrite, "WRITE_SIZE"))
     if not f or not w:
@@ -60,7 +109,7 @@ def main():
     mean_raw = (n_p * (fp + wm) + n_r * (fr + wm)) / (n_p + n_r)
     alg_plain = ALG["input_with_halo"] + ALG["output"] + ALG["weights_f16_pairs"]
     alg_res = alg_plain + ALG["residual"]
-    out = {"kernel": "k_conv6<0, 2> (224 x 224 x 64 level, 196 workgroups)", "launches": {"plain": n_p, "residual": n_r},
+    out = {"kernel": "k_conv6<0, 2> (224 x 224 x 64 level, 196 workgroups)", "batch": 1, "launches": {"plain": n_p, "residual": n_r},
            "raw": {"fetch_plain_bytes": int(fp), "fetch_residual_bytes": int(fr), "write_bytes": int(wm)},
            "corrected": {"fetch_plain_bytes": int(corr_plain), "fetch_residual_bytes": int(corr_res), "write_bytes": int(wm),
                          "residual_read_as_counted": int(res_counted), "residual_read_true": ALG["residual"]},
