@@ -29,9 +29,41 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// lane exchange inside groups of 8 lanes on the VALU (DPP), no LDS traffic
+template <int CTRL> __device__ __forceinline__ double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;   // lane i <-> 7-i ; quad_perm [1,0,3,2] ; [2,3,0,1]
+// a[0..7] of an aligned group of 8 lanes -> ((a0+a7)+(a1+a6)) + ((a2+a5)+(a3+a4)) in lane 0 of the group (fixed tree)
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_get<DPP_HALF_MIRROR>(v);
+    v += dpp_get<DPP_XOR1>(v);
+    v += dpp_get<DPP_XOR2>(v);
+    return v;
+}
+
+// Sum over the 64 lanes of a wave in one fixed order, valid in EVERY lane: four DPP steps inside each row of 16 lanes (pairs, quads, halves, row),
+// then the four row sums through v_readlane, ((r0 + r1) + (r2 + r3)).  Round 3: the __shfl_down trees used before compile to ds_bpermute_b32
+// (12 dependent LDS-crossbar round trips per double, ~0.3 us); the one-launch LSQR iteration does four such reductions per iteration.
+constexpr int DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v += dpp_get<DPP_XOR1>(v);
+    v += dpp_get<DPP_XOR2>(v);
+    v += dpp_get<DPP_HALF_MIRROR>(v);
+    v += dpp_get<DPP_ROW_MIRROR>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sh) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum_all(v);
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lds_barrier();
     if (lane == 0) sh[wid] = v;
@@ -84,8 +116,7 @@ template <int R1, int R2> struct Cfg {
 
 // two sums at once (one pair of barriers)
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    a = wave_sum_all(a); b = wave_sum_all(b);
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lds_barrier();
     if (lane == 0) { sh[wid] = a; sh[NT / 64 + wid] = b; }
@@ -107,25 +138,7 @@ __device__ __forceinline__ double wave_sum(const double* __restrict__ p, int n) 
 #pragma unroll
     for (int q = 0; q < 8; ++q) a += (lane + 64 * q < n) ? r[q] : 0.0;
     for (int i = lane + 512; i < n; i += 64) a += p[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    return a;
-}
-
-// lane exchange inside groups of 8 lanes on the VALU (DPP), no LDS traffic
-template <int CTRL> __device__ __forceinline__ double dpp_get(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-constexpr int DPP_HALF_MIRROR = 0x141, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;   // lane i <-> 7-i ; quad_perm [1,0,3,2] ; [2,3,0,1]
-// a[0..7] of an aligned group of 8 lanes -> ((a0+a7)+(a1+a6)) + ((a2+a5)+(a3+a4)) in lane 0 of the group (fixed tree)
-__device__ __forceinline__ double group8_sum(double v) {
-    v += dpp_get<DPP_HALF_MIRROR>(v);
-    v += dpp_get<DPP_XOR1>(v);
-    v += dpp_get<DPP_XOR2>(v);
-    return v;
+    return wave_sum_all(a);
 }
 
 // u(m+1:end) update, shared by both kernels so that they produce the same bits:  sqrt(r) v - alpha (u / beta_prev)

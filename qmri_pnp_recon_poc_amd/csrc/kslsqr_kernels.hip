@@ -479,9 +479,7 @@ __device__ __forceinline__ bool gran_sum(KsGran* g, int n, unsigned tag, double&
     double a = 0.0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) a += (lane + 64 * q < n) ? r[q] : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    out = a;
+    out = wave_sum_all(a);                                          // (the same tree as wave_sum())
     return ok;
 }
 
