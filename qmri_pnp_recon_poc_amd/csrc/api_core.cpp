@@ -85,6 +85,7 @@ void qmri_free_operator(qmri_ctx* ctx) {
                      o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
     for (void* p : ptrs) free_dev(p);
     if (o.h_state) (void)hipHostFree(o.h_state);
+    if (o.h_ring) (void)hipHostFree(o.h_ring);
     free_dev(ctx->d_ks_gran); ctx->d_ks_gran = nullptr; ctx->ks_persist_cap = -1;    // (sized for this operator's work units)
     o = OpHost();
 }
@@ -537,13 +538,19 @@ int qmri_prepare_direct(qmri_ctx* ctx, double r) {
 // LSQR on B slices, iterated in k-space (kslsqr_kernels.hip).  Requires ls.yk / ny2 (dc_launch_sort_y) and ls.pz
 // (dc_launch_prepare_z) to be current.  d_x holds x0 on entry and the solution on return; when o.xhat_valid the spectrum of
 // x0 is taken from the previous solve instead of being recomputed.  pdiag (or null) receives [B][N] partials of ||y - A x||^2.
+// hslot / deferred (round 3): a caller that does not need the iteration count at once passes B pinned LsqrState entries of its own and a flag;
+// when the one-launch kernel runs, the call returns WITHOUT waiting (*deferred = true, iters_out / flag_out untouched): the kernel leaves
+// iter / done / flag in hslot, to be read after the caller's next synchronisation (state 77 there = the kernel timed out: the caller repeats
+// its work with ctx->ks_persist = 0).  The ADMM loop uses this so that the host never waits inside a reconstruction.
 int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
-                  int32_t* iters_out, int32_t* flag_out, double* pdiag) {
+                  int32_t* iters_out, int32_t* flag_out, double* pdiag, LsqrState* hslot, bool* deferred) {
     OpHost& o = ctx->op;
     const OpDev op = qmri_opdev(ctx);
     KsDev ks = o.ks;
     ks.sr = std::sqrt(r); ks.tol = tol; ks.maxit = maxit; ks.ii = 0; ks.pdiag = pdiag;
-    ks.hst = o.h_state;
+    LsqrState* const hs = hslot ? hslot : o.h_state;
+    ks.hst = hs;
+    if (deferred) *deferred = false;
     if (!o.xhat_valid) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_x, o.d_tmp, ks.xhat, nullptr));
     QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_z, o.d_tmp, ks.zhat, nullptr));
     QMRI_TRY(ks_launch_init(ctx, op, ks, B));
@@ -567,12 +574,30 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         QMRI_TRY(ks_launch_persist(ctx, op, ks, B, ctx->d_ks_gran, tag0, &persisted));
         if (persisted) {
             ctx->ks_tag += 2u * (unsigned)(maxit + 2);
-            QMRI_HIP(ctx, hipEventRecord(ctx->ev_state, ctx->stream));
             QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));
             QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
-            QMRI_HIP(ctx, hipEventSynchronize(ctx->ev_state));
+            if (deferred) {                                        // the caller reads hslot after its own synchronisation
+                *deferred = true;
+                std::swap(o.ks.xhat, o.ks.xhat_out);
+                o.xhat_valid = true;
+                return QMRI_OK;
+            }
+            // the kernel's last act is a system-scope release of this solve's tag into the pinned state (no event packet in the stream: one
+            // costs 5.7 us of idle GPU): spin on it, with the stream's own end as the bound
+            {
+                bool seen = false;
+                for (long spin = 0; !seen; ++spin) {
+                    seen = true;
+                    for (int b = 0; b < B; ++b) seen = seen && (unsigned)__atomic_load_n(&hs[b].pad, __ATOMIC_ACQUIRE) == tag0;
+                    if (!seen && (spin & 1023) == 1023 && hipStreamQuery(ctx->stream) == hipSuccess) {      // everything has run: the word must be there
+                        seen = true;
+                        for (int b = 0; b < B; ++b) seen = seen && (unsigned)__atomic_load_n(&hs[b].pad, __ATOMIC_ACQUIRE) == tag0;
+                        if (!seen) { qmri_set_error(ctx, "the one-launch LSQR kernel ended without reporting its state"); return QMRI_ERR_HIP; }
+                    }
+                }
+            }
             bool timed_out = false;
-            for (int b = 0; b < B; ++b) timed_out = timed_out || o.h_state[b].flag == 77;
+            for (int b = 0; b < B; ++b) timed_out = timed_out || hs[b].flag == 77;
             if (timed_out) {                                       // repeat with the two-launch iteration, from the untouched inputs
                 fprintf(stderr, "libqmri: the one-launch LSQR timed out waiting for a partial sum; using the two-launch iteration from now on\n");
                 ctx->ks_persist = 0;
@@ -597,16 +622,16 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
         QMRI_HIP(ctx, hipEventSynchronize(ctx->ev_state));
         all_done = true;
-        for (int b = 0; b < B; ++b) all_done = all_done && o.h_state[b].done;
+        for (int b = 0; b < B; ++b) all_done = all_done && hs[b].done;
         chunk = 2;
     }
     std::swap(o.ks.xhat, o.ks.xhat_out);                                  // the assembled spectrum is the next solve's xhat0
     o.xhat_valid = true;
     int worst = 0;
     for (int b = 0; b < B; ++b) {
-        const int it = o.h_state[b].done ? o.h_state[b].iter : maxit;
+        const int it = hs[b].done ? hs[b].iter : maxit;
         if (iters_out) iters_out[b] = it;
-        if (flag_out) flag_out[b] = o.h_state[b].done ? o.h_state[b].flag : 1;
+        if (flag_out) flag_out[b] = hs[b].done ? hs[b].flag : 1;
         worst = std::max(worst, it);
         ctx->prof.lsqr_iters += it;
     }
@@ -630,7 +655,7 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
         QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, n * sizeof(double2), ctx->stream));
         QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, 1, o.d_z, o.d_u, o.d_vv));
         o.xhat_valid = false;
-        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out, nullptr));
+        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out, nullptr, nullptr, nullptr));
     } else if (solver == QMRI_SOLVER_DIRECT) {
         QMRI_TRY(qmri_prepare_direct(ctx, r));
         QMRI_TRY(dc_launch_adj(ctx, op, 1, o.d_ya, o.d_tmp, o.d_xa));

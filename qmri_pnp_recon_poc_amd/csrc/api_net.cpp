@@ -14,7 +14,7 @@
 void qmri_free_operator(qmri_ctx* ctx);
 int qmri_prepare_direct(qmri_ctx* ctx, double r);
 int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
-                  int32_t* iters_out, int32_t* flag_out, double* pdiag);
+                  int32_t* iters_out, int32_t* flag_out, double* pdiag, LsqrState* hslot, bool* deferred);
 
 // ---------------------------------------------------------------------------------------------------
 // denoiser
@@ -528,16 +528,30 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     o.xhat_valid = false;                                  // x was just set: its spectrum is not known yet
     const bool diag = prm->want_diag && diag_out;
     bool range_trip = false;
+    // LSQR state per (ADMM iteration, slice) in pinned memory: with the one-launch LSQR kernel the host does not wait inside the loop at all
+    // (qmri_lsqr_run, "deferred") -- the kernels of all iterations are queued back to back and the counts are read after the final
+    // synchronisation; an event or a host round trip per x-update left the GPU idle for ~6 us each
+    std::vector<char> deferred_it((size_t)std::max(prm->iters, 1), 0);
+    if (prm->solver == QMRI_SOLVER_LSQR && (size_t)prm->iters * B > o.h_ring_cap) {
+        if (o.h_ring) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(o.h_ring); o.h_ring = nullptr; o.h_ring_cap = 0; }
+        const size_t cap = std::max<size_t>((size_t)prm->iters * B, 128);
+        QMRI_HIP(ctx, hipHostMalloc((void**)&o.h_ring, cap * sizeof(LsqrState), hipHostMallocDefault));
+        o.h_ring_cap = cap;
+    }
     for (int it = 0; it < prm->iters; ++it) {
         // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
         tm.start();
         if (it == 0) QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, B, o.d_vv, o.d_u, o.d_z));   // later: fused into the dual update
         if (prm->solver == QMRI_SOLVER_LSQR) {
+            bool deferred = false;
             QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr,
-                                   diag ? o.d_pd : nullptr));          // (the data-fidelity partials come with the solve)
-            if (lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
-            // qmri_lsqr_run has just waited for the LSQR state, which is behind the previous iteration's forward in the stream: its
-            // range guard is on the host.  A tripped guard ends this attempt at once instead of after all iterations.
+                                   diag ? o.d_pd : nullptr,            // (the data-fidelity partials come with the solve)
+                                   o.h_ring + (size_t)it * B, &deferred));
+            deferred_it[it] = deferred ? 1 : 0;
+            if (!deferred && lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
+            // The range guard of earlier forwards is on the host (pinned words written by k_act_check).  After a wait inside qmri_lsqr_run (the
+            // two-launch iteration) it is current up to the previous iteration; without one it is whatever has arrived.  A tripped guard ends
+            // this attempt at once instead of after all iterations.
             if (it > 0 && net.sp6 == 2 && host_range_tripped(net)) { range_trip = true; tm.stop(ctx->prof.ms_xupdate); break; }
         } else {
             QMRI_TRY(dc_launch_direct(ctx, op, B, o.d_z, o.d_chat, prm->gamma, o.d_tmp, o.d_x));
@@ -575,6 +589,25 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     if (prm->want_diag && diag_out && prm->iters > 0 && !range_trip)
         QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (prm->solver == QMRI_SOLVER_LSQR && !range_trip) {          // LSQR counts of the iterations whose state was deferred; a timed-out one-launch kernel
+        bool timed_out = false;
+        for (int it = 0; it < prm->iters; ++it) {
+            if (!deferred_it[it]) continue;
+            for (int b = 0; b < B; ++b) {
+                const LsqrState& h = o.h_ring[(size_t)it * B + b];
+                if (h.flag == 77) timed_out = true;
+                const int n_it = h.done ? h.iter : prm->cg_maxit;
+                if (lsqr_iters_out) lsqr_iters_out[(size_t)b * prm->iters + it] = n_it;
+                ctx->prof.lsqr_iters += n_it;
+            }
+        }
+        if (timed_out) {                                           // (never seen) everything after it is garbage: once more with the two-launch iteration
+            fprintf(stderr, "libqmri: the one-launch LSQR timed out waiting for a partial sum; repeating the reconstruction with the two-launch iteration\n");
+            ctx->ks_persist = 0;
+            ctx->prof = prof_at_entry;
+            return qmri_pnp_admm_dev(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+        }
+    }
     if (prm->iters > 0) {
         // f16 range guard: the network now runs on the bf16 scheme; the inputs are untouched (d_x_out must not alias d_x0), run again
         bool again = false;

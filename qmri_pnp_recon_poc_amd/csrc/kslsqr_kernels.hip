@@ -483,6 +483,13 @@ __device__ __forceinline__ bool gran_sum(KsGran* g, int n, unsigned tag, double&
     return ok;
 }
 
+// the solve is over: tell the host through the pinned state (system-scope release: iter / done / flag of this thread are visible before the
+// sequence word).  The host spins on that word instead of waiting for an event: an event record between this launch and the next kernel
+// left the GPU idle for 5.7 us per x-update (tools/iter_times.py).
+__device__ __forceinline__ void ks_tell_host(LsqrState* h, unsigned seq) {
+    if (h) __hip_atomic_store(&h->pad, (int32_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop) {
     __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]   (k_ks_a)
     __shared__ double2 ulds[KS_ECAP];                      // u(1:m) of the unit's samples        (k_ks_b)
@@ -525,7 +532,10 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     load_v(op, rv);
     LsqrScalars O = st->sc[0];                                      // written by k_ks_b<INIT>
     const double R = st->R, tolb = st->tolb, sr = ks.sr;
-    if (st->done) return;                                           // x0 already exact, or b = 0 (uniform over the grid)
+    if (st->done) {                                                 // x0 already exact, or b = 0 (uniform over the grid)
+        if (g == 0 && tid == 0 && ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = st->flag; h->iter = st->iter; ks_tell_host(h, tag0); }
+        return;
+    }
     if (tid < 64) {
         const double pa0 = wave_sum(ks.pv[0] + (size_t)b * G, G);   // |v|^2 partials of the INIT launch (plain: another kernel's output)
         if (tid == 0) red[0] = pa0;
@@ -707,7 +717,7 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
         PS(8);
     }
     if (aborted) {
-        if (writer) { st->flag = 77; if (ks.hst) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; } }
+        if (writer) { st->flag = 77; if (ks.hst) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; ks_tell_host(h, tag0); } }
         return;
     }
     // ---- the solution x on the unit's slots (k_ks_final_w assembles the spectrum); scalars for the final kernels and the host
@@ -715,10 +725,12 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     for (int q = 0; q < NEQ; ++q) { const int i = tid + KT * q; if (i < ne) st_wt(ks.cx + cb + i, rx[q]); }
     if (writer) {
         st->ue_final = ue_final;
-        if (conv_iter >= 0) {
-            st->done = 1; st->flag = 0; st->iter = conv_iter;
-            if (ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = 0; h->iter = conv_iter; }
+        if (conv_iter >= 0) { st->done = 1; st->flag = 0; st->iter = conv_iter; }
+        if (ks.hst) {                                               // (every field the host reads, from this thread, before the release below)
+            LsqrState* h = ks.hst + b;
+            h->done = conv_iter >= 0 ? 1 : 0; h->flag = conv_iter >= 0 ? 0 : 1; h->iter = conv_iter >= 0 ? conv_iter : ks.maxit;
         }
+        ks_tell_host(ks.hst ? ks.hst + b : nullptr, tag0);
     }
 }
 

@@ -219,6 +219,8 @@ struct OpHost {
     double* d_pd = nullptr;             // diag partials
     int32_t* h_flags = nullptr;         // pinned host mirror of done flags
     LsqrState* h_state = nullptr;       // pinned
+    LsqrState* h_ring = nullptr;        // pinned [ADMM iteration][slice]: LSQR state of a reconstruction whose host never waits (api_net.cpp)
+    size_t h_ring_cap = 0;
 };
 
 struct DictHost {

@@ -13,7 +13,7 @@ rows.sort()
 ends = [i for i, r in enumerate(rows) if 'k_act_check' in r[2]]
 lo, hi = ends[-2] + 1, ends[-1] + 1
 fw = rows[lo:hi]
-short = lambda n: n.split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')[:44]
+short = lambda n: n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:44]
 tot = (fw[-1][1] - fw[0][0]) / 1e3
 print(f'last forward: {len(fw)} launches, {tot:.1f} us from first start to last end, sum of kernel durations {sum(e - s for s, e, _ in fw) / 1e3:.1f} us')
 by = collections.defaultdict(list)
