@@ -137,7 +137,8 @@ __global__ __launch_bounds__(NT) void k_unnormalise_dual(size_t n, int plane, in
         st_wt(z + (size_t)b * n + i, zz);
         acc += zz.x * zz.x + zz.y * zz.y;
     }
-    // block total in the order of dc_kernels.hip's block_sum (shuffle tree, then the waves in order)
+    // block total: shuffle tree, then the waves in order (k_prepare_z, which only the first iteration uses, has dc_device.h's DPP tree:
+    // either is one fixed order, the partials only ever meet inside one solve's ||b||)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
