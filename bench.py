@@ -46,7 +46,10 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 / f16 matrix peak (v_mfma_f32_32x32x16_{bf16,f16}, 32 cycles)
-SUSTAINED_MFMA_TFLOPS = round(2 * 32 * 32 * 16 * 1024 / 22.1e-9 / 1e12, 1)      # 1024 SIMDs x one 32x32x16 MFMA per 22.1 ns = 1518.3
+# what the chip sustains on toggling f16 operands at its power limit, in the conv kernels' own instruction mix (f16 x 3 products on a 64 x 64 wave
+# tile, every fragment read from LDS, one wave per SIMD on all 256 CUs): 1325-1345 TFLOP/s at 1.75-1.92 GHz (tools/ubench/mfma_shape_f16.hip,
+# profiles/r03_h_ubench_mfma_shape_f16.txt; bare MFMAs without LDS reads: 22.1 ns each = 1518, profiles/r01_g_ubench_mfma_f16x3_loop.txt)
+SUSTAINED_MFMA_TFLOPS = 1335.0
 BF16X6 = os.environ.get("QMRI_CONV_SCHEME", "") == "bf16x6"
 SPLIT_PRODUCTS = 6 if BF16X6 else 3   # MFMA products per fp32-equivalent product (conv6_kernels.hip: bf16 x 6 / f16 x 3)
 SCHEME_TEXT = ("v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate" if BF16X6 else
@@ -405,9 +408,8 @@ def worker(args):
                         "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches_timed": int(pr["n_conv3x3"]), "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B,
                         "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3), "fp32_equivalent_flop_per_launch": CONV3X3_FLOP * B,
-                        # what the chip sustains on toggling operands with every SIMD issuing MFMAs back to back: 22.1 ns per 32x32x16
-                        # MFMA and SIMD (tools/ubench/mfma_f16x3_loop.hip, profiles/r01_g_ubench_mfma_f16x3_loop.txt) -- not the roofline
-                        # peak, reported beside it
+                        # what the chip sustains on toggling operands at its power limit (see SUSTAINED_MFMA_TFLOPS) -- not the roofline peak,
+                        # reported beside it
                         "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4)}
         # stage split of one more run of the SAME workload (profile level 1 synchronises per stage; not part of the timed region): all
         # args.steps iterations, because the x-update is not uniform over a reconstruction -- LSQR needs 16 iterations in the first
