@@ -72,7 +72,7 @@ __global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks) {
     const size_t n = (size_t)s * N * M;
     const double sr = ks.sr;
     // ---- request everything (clamped, not predicated): one memory latency for the whole row
-    constexpr int NQ = (DC_MAXS * N + KT - 1) / KT, NE = 4;
+    constexpr int NQ = (DC_MAXS * N + KT - 1) / KT, NE = 10;   // (NE: samples per thread requested up front -- the busiest k-rows of the spiral hold 2 400 samples against a mean of 550, and every further round of the loop below is another dependent memory latency for the whole launch: 4 -> 10, 15.9 -> 12.2 us per launch)
     double2 xv[NQ], zv[NQ];
     int slot[NQ];
 #pragma unroll
