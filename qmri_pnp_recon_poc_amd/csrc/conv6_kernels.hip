@@ -97,6 +97,12 @@ template <> struct Cfg6<3> {     // 128 px x 32 cout: the workgroup takes ONE 32
     static constexpr int TH = 16, TW = 8, MW = 1, NCT = 1, MH = 2;
     static __device__ __forceinline__ void wave_map(int wave, int& pbh, int& pbw, int& m0) { pbh = 8 * (wave & 1); pbw = 4 * (wave >> 1); m0 = 0; }
 };
+// Output tile in LDS for BLOCKED output tensors: PIXEL-major, ot[pixel][OTP] with the tile's 64 output channels of a pixel contiguous (round 3).
+// In the MFMA C/D layout a lane's four consecutive registers are four consecutive output channels of one pixel, and an epilogue thread's
+// half-item is four consecutive channels of one pixel: one 16-byte LDS access on either side instead of four 4-byte ones (channel-major
+// ot[cout][pixel] needed 128 ds_write_b32 per matrix wave and tile; it stays the layout of PLANAR outputs, whose threads take four pixels of a
+// channel).  Pitch 68 floats: 16-byte aligned, 8-lane write groups on 32 distinct banks.
+constexpr int OTP = 68;
 constexpr int NABUF = 3;         // LDS buffers of A (one step each): step g lives in buffer g % 3 = its kh; a step's weights are complete one
                                  // barrier before the step starts, so the MFMA waves can request its first fragments across that barrier
 
@@ -318,6 +324,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     // stores into A precede the loop's last barrier, the tile is written after it).
     float* ot = (SP == 3) ? (float*)Bbuf : (float*)smem;
     static_assert(SP == 3 ? (64 * PP * 4 <= 2 * 3 * 2 * NPX * 16) : (64 * PP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "output tile must fit the operand buffers");
+    static_assert(SP == 3 ? (PXT * OTP * 4 <= 2 * 3 * 2 * NPX * 16) : (PXT * OTP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "pixel-major output tile must fit the operand buffers");
     const int tid = threadIdx.x;
     int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int mh = (MH > 1) ? bid % MH : 0;                         // which 32-row half of the 64-row tile (MH = 2)
@@ -581,6 +588,22 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 
     // ---- accumulators -> LDS tile ot[cout][pixel] (the B buffers are free now).  C/D layout: col = lane&31 (pixel),
     // row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (A.out_blk) {                                                // (uniform) pixel-major tile: see OTP
+#pragma unroll
+        for (int n = 0; n < NCT; ++n)
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[m][n][4 * rg + j];
+                        if constexpr (SP == 2) v[j] = v[j] * A.descale_hi + accl[m][n][4 * rg + j] * A.descale_lo;      // (powers of two: exact)
+                    }
+                    *(f32x4*)(ot + ((pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)) * OTP + (m0 + m) * 32 + 8 * rg + 4 * h2) = v;
+                }
+    } else {
 #pragma unroll
     for (int n = 0; n < NCT; ++n)
 #pragma unroll
@@ -592,6 +615,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 if constexpr (SP == 2) v = v * A.descale_hi + accl[m][n][r] * A.descale_lo;      // (powers of two: exact)
                 ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = v;
             }
+    }
     }   // MFMA waves
 
     // ---- all eight waves: residual adds, ReLU, stores.  Interior rows start on a 128-byte line (PTensor), tiles on a multiple
@@ -608,7 +632,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             // write every line in two half-filled pieces -- measured 2 us slower per 224 x 224 layer), and the LDS reads of a 32-lane
             // group fall on 32 different banks (4 channels further = 16 banks further, PP = 4 mod 32).
             constexpr int NHI = 16 * PXT, HQ = NHI / NT6;           // half-items of the tile; per thread
-            static_assert(NHI % NT6 == 0 && PP % 32 == 4, "epilogue");
+            static_assert(NHI % NT6 == 0, "epilogue");
             unsigned off[HQ];                                       // float offset of the half-item inside one image, ~0u = outside
             f32x4 r1[HQ], r2[HQ];
 #pragma unroll
@@ -633,10 +657,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             for (int k = 0; k < HQ; ++k) {
                 const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
                 const int g = e / PXT, px = e - g * PXT;
-                const float* op = ot + (g * 8 + 4 * half) * PP + px;
-                f32x4 x;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = op[j * PP];
+                f32x4 x = *(const f32x4*)(ot + px * OTP + g * 8 + 4 * half);
                 x = (x + r1[k]) + r2[k];
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
                 if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
@@ -786,7 +807,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
     constexpr int NAQ = (AST + NLD6 - 1) / NLD6;
     static_assert(NAQ == 3 && NBQ == 1, "gwait() is written for 3 + 2 loads per step");
     constexpr int NLOAD = NAQ + 2;                                  // (BLOCKED tensors throughout: conv6_launch checks)
-    constexpr int PXT = TH * TW, PP = PXT + 4;
+    constexpr int PXT = TH * TW;
     // epilogue: half-items (4 channels of a block at one pixel, 16 bytes; lane pairs = the two halves of a pixel, see k_conv6), 16 * PXT
     // per tile; a loader thread handles two per step: the same half at two pixels 128 apart (256-pixel tile) or in two blocks
     constexpr int NGS = NLD6 / PXT;                                 // channel blocks covered by the loader threads in one step
@@ -795,7 +816,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
     uint4* Bbuf = Abuf + NABUF * AST;                               // [2][SP][2 k-halves][NPX]
-    float* ot = (float*)(Bbuf + 2 * SP * 2 * NPX);                  // [64][PP] output tile, NOT aliased: read while the next tile computes
+    float* ot = (float*)(Bbuf + 2 * SP * 2 * NPX);                  // [PXT][OTP] pixel-major output tile, NOT aliased: read while the next tile computes
     const int tid = threadIdx.x;
     const int nsteps = 3 * A.nchunk, ntiles = A.ntiles, tstride = gridDim.x;
     int tile = blockIdx.x;
@@ -837,13 +858,13 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         const int ehalf = lt & 1;
         int ew[2], eh[2];
         unsigned evoff[2];                                          // + scalar (tile, slice)
-        const float* otp[2];                                        // + j * NGS * 8 * PP, channel c: + c * PP
+        const float* otp[2];                                        // + j * NGS * 8 (the next channel blocks of the same pixel)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int idx = (lt >> 1) + (NLD6 / 2) * q, epx = idx % PXT, egs = idx / PXT;
             ew[q] = epx / TH; eh[q] = epx - ew[q] * TH;
             evoff[q] = (unsigned)(((size_t)egs * A.out_plane + (size_t)(ew[q] + 1) * A.out_hp + (eh[q] + 1)) * 32 + 16 * ehalf);
-            otp[q] = ot + (egs * 8 + 4 * ehalf) * PP + epx;
+            otp[q] = ot + epx * OTP + egs * 8 + 4 * ehalf;
         }
         u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
         BRegs<true> rb0, rb1, rb2;
@@ -911,9 +932,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             const unsigned so_ = usgpr((t_).o + (unsigned)((j_) * NGS) * oplane32);                              \
             _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
                 const bool okhw_ = (t_).oh0 + eh[q] < A.H && (t_).ow0 + ew[q] < A.W;                             \
-                const float* op_ = otp[q] + (j_) * (NGS * 8 * PP);                                               \
-                f32x4 x;                                                                                         \
-                _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) x[c_] = op_[c_ * PP];                           \
+                f32x4 x = *(const f32x4*)(otp[q] + (j_) * (NGS * 8));                                            \
                 if constexpr (NRES > 0) x = x + rr_[0][q];                                                       \
                 if constexpr (NRES > 1) x = x + rr_[1][q];                                                       \
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); } \
@@ -1074,9 +1093,11 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 #pragma unroll
                                 for (int m = 0; m < MW; ++m)
 #pragma unroll
-                                    for (int r = 0; r < 16; ++r) {
-                                        const int co = (m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                                        ot[co * PP + (pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)] = acc[m][n][r] * A.descale_hi + accl[m][n][r] * A.descale_lo;
+                                    for (int rg = 0; rg < 4; ++rg) {
+                                        f32x4 v;
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * rg + j] * A.descale_hi + accl[m][n][4 * rg + j] * A.descale_lo;
+                                        *(f32x4*)(ot + ((pbw + (li >> 3)) * TH + pbh + 8 * n + (li & 7)) * OTP + (m0 + m) * 32 + 8 * rg + 4 * h2) = v;
                                     }
                         }
                         P_STAMP(0, sidx);
@@ -1098,7 +1119,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         const int ct = last.ct, oh0 = last.oh0, ow0 = last.ow0, b = last.b;
         bool bad = false;
         constexpr int NHI = 16 * PXT, HQ = NHI / NT6;
-        static_assert(NHI % NT6 == 0 && PP % 32 == 4, "epilogue");
+        static_assert(NHI % NT6 == 0, "epilogue");
         unsigned off[HQ];
         f32x4 r1[HQ], r2[HQ];
 #pragma unroll
@@ -1122,10 +1143,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         for (int k = 0; k < HQ; ++k) {
             const int e2 = k * NT6 + tid, half = e2 & 1, e = e2 >> 1;
             const int g = e / PXT, px = e - g * PXT;
-            const float* op = ot + (g * 8 + 4 * half) * PP + px;
-            f32x4 x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = op[j * PP];
+            f32x4 x = *(const f32x4*)(ot + px * OTP + g * 8 + 4 * half);
             x = (x + r1[k]) + r2[k];
             if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
             if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
@@ -1435,7 +1453,7 @@ template <int CFG> constexpr size_t conv6_lds(int SP) {
 }
 
 template <int CFG> constexpr size_t conv6p_lds() {
-    return conv6_lds<CFG>(2) + (size_t)64 * (Cfg6<CFG>::TH * Cfg6<CFG>::TW + 4) * 4;
+    return conv6_lds<CFG>(2) + (size_t)(Cfg6<CFG>::TH * Cfg6<CFG>::TW) * OTP * 4;
 }
 
 // where a launch of layer L reports (slot row = the layer's index in the network, so that the rows mean the same for every batch
