@@ -95,11 +95,6 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
     constexpr int NPL = (NPAIR <= 4) ? 4 : 8, NV = NPL / 4;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 av[NV], avn[NV];
-    {
-        const f32x4* ap = (const f32x4*)(pack + ((size_t)((tbeg + wave < ntiles) ? tbeg + wave : 0) * 64 + lane) * NPL);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) av[v] = ap[v];
-    }
     auto tile_body = [&](int t, const f32x4 (&av)[NV]) __attribute__((always_inline)) {
         f32x16 are = {0}, aim = {0};
 #pragma unroll
@@ -120,34 +115,62 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
         }
         tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
                      fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
-        if (tmax > thr) {          // some atom of this tile beats the incumbent (rare once the scan has passed the neighbourhood of the match)
-            // the new magnitude is sqrtf of the tile's largest |ip|^2; MATLAB's max keeps the FIRST atom with that magnitude, i.e. the
-            // lowest row of the tile whose |ip|^2 lies in the root's pre-image [lo, hi]: one square root per update, not per candidate
+        if (tmax > thr) {          // some atom of this tile reaches the incumbent's magnitude (rare: see the visiting order below)
+            // the tile's magnitude is sqrtf of its largest |ip|^2; MATLAB's max keeps the FIRST atom with the largest magnitude, i.e. the
+            // lowest row of the tile whose |ip|^2 lies in the root's pre-image [lo, hi]: one square root per update, not per candidate.
+            // Tiles are not visited in ascending order, so thr sits just BELOW the incumbent's pre-image: a tile holding an atom of the
+            // same magnitude comes here too and wins only with the lower index.
             float lo, hi;
-            best = sqrtf(tmax);
-            sqrt_preimage(best, tmax, lo, hi);
-            thr = hi;
+            const float mag = sqrtf(tmax);
+            sqrt_preimage(mag, tmax, lo, hi);
             int rsel = 15;                                                  // (the tile's maximum itself is >= lo: some row qualifies)
-            cre = are[15]; cim = aim[15];
+            float nre = are[15], nim = aim[15];
 #pragma unroll
-            for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; cre = are[r]; cim = aim[r]; }     // (ascending rows = ascending atoms)
-            bidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;          // C/D row of the 32x32 MFMA tile
+            for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; nre = are[r]; nim = aim[r]; }     // (ascending rows = ascending atoms)
+            const int nidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;    // C/D row of the 32x32 MFMA tile
+            if (mag > best || nidx < bidx) {                                // (mag >= best here: tmax > thr means tmax >= the incumbent's lo)
+                best = mag; bidx = nidx; cre = nre; cim = nim;
+                // (magnitude 0 -- an all-zero pixel -- has nothing below it: there the incumbent is row 0 of the wave's FIRST tile,
+                //  which is visited first and is the wave's lowest index, so only a non-zero product may come here again)
+                thr = (lo > 0.f) ? __uint_as_float(__float_as_uint(lo) - 1u) : 0.f;
+            }
         }
     };
+    // Visiting order.  Atoms lie on a (T1, T2) grid and neighbouring pixels have neighbouring matches: in ascending order the scan climbs
+    // towards the match row by row and 28 % of the tiles brought a new incumbent for some lane of the wave (measured on the bench slice;
+    // the update path costs three times the plain tile).  A wave therefore walks its tiles i = 0 .. n-1 (tile tbeg + wave + 4 i) in
+    // BIT-REVERSED order of i -- coarse to fine over its whole part: the incumbent is close to the final one after a few tiles and 4.5 %
+    // of the tiles reach the update path.  The order is scalar arithmetic (s_brev_b32); the result does not depend on it (see above).
     {
-        int t = tbeg + wave;
-        for (; t + 4 < ntiles; t += 8) {
-            { const f32x4* ap = (const f32x4*)(pack + ((size_t)(t + 4) * 64 + lane) * NPL);
+        const int n = (ntiles - tbeg - wave + 3) / 4;                  // this wave's tiles (<= 0: none)
+        int nb = 0;
+        while ((1 << nb) < n) ++nb;
+        const unsigned kend = 1u << nb;
+        auto next_i = [&](unsigned& k) __attribute__((always_inline)) -> int {      // next valid i at or after counter k (n when exhausted); k moves past it
+            while (k < kend) {
+                const int i = nb ? (int)(__builtin_bitreverse32(k) >> (32 - nb)) : 0;
+                ++k;
+                if (i < n) return i;
+            }
+            return n;
+        };
+        auto request = [&](int i, f32x4 (&dst)[NV]) __attribute__((always_inline)) {
+            const f32x4* ap = (const f32x4*)(pack + ((size_t)(tbeg + wave + 4 * i) * 64 + lane) * NPL);
 #pragma unroll
-              for (int v = 0; v < NV; ++v) avn[v] = ap[v]; }
-            tile_body(t, av);
-            { const int tn = (t + 8 < ntiles) ? t + 8 : t + 4;      // (clamped: the last tile is requested twice)
-              const f32x4* ap = (const f32x4*)(pack + ((size_t)tn * 64 + lane) * NPL);
-#pragma unroll
-              for (int v = 0; v < NV; ++v) av[v] = ap[v]; }
-            tile_body(t + 4, avn);
+            for (int v = 0; v < NV; ++v) dst[v] = ap[v];
+        };
+        unsigned k = 0;
+        int i0 = (n > 0) ? next_i(k) : n;
+        if (i0 < n) request(i0, av);
+        while (i0 < n) {
+            const int i1 = next_i(k);
+            if (i1 < n) request(i1, avn);
+            tile_body(tbeg + wave + 4 * i0, av);
+            if (i1 >= n) break;
+            i0 = next_i(k);
+            if (i0 < n) request(i0, av);
+            tile_body(tbeg + wave + 4 * i1, avn);
         }
-        if (t < ntiles) tile_body(t, av);                           // an odd last tile (its fragments are in `av` either way)
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
     {
