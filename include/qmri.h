@@ -240,6 +240,11 @@ int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int reserved)
  * the one-launch kernel lose a partial sum on purpose: its waits time out, the library reports it on stderr and repeats the solve with the
  * two-launch iteration (the recovery path, tested). */
 int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on);
+/* Test / A-B hook for the dictionary match (mrf_dtm_cpu.m:91-92): on = 1 (default) puts the f16 filter in front of the exact single-precision
+ * products (the result is the same, bit for bit: the filter only decides which 32-atom tiles need the exact products), on = 0 computes
+ * every product exactly.  margin_scale (default 1) multiplies the filter's margin: the tests shrink it to measure how far the proven
+ * margin is from the first wrong answer. */
+int qmri_debug_dict_filter(qmri_ctx* ctx, int on, float margin_scale);
 
 #ifdef __cplusplus
 }

@@ -658,10 +658,13 @@ extern "C" int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_param
 void qmri_free_dict(qmri_ctx* ctx) {
     DictHost& d = ctx->dict;
     if (d.d_pack) (void)hipFree(d.d_pack);
+    if (d.d_pack16) (void)hipFree(d.d_pack16);
     if (d.d_normD) (void)hipFree(d.d_normD);
     if (d.d_lut) (void)hipFree(d.d_lut);
     if (d.d_part) (void)hipFree(d.d_part);
+    const int filter_on = d.filter_on; const float margin_scale = d.margin_scale;
     d = DictHost();
+    d.filter_on = filter_on; d.margin_scale = margin_scale;
 }
 
 extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const float* D, const float* normD, const float* lut) {
@@ -692,7 +695,47 @@ extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const flo
     QMRI_HIP(ctx, hipMemcpy(d.d_pack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice));
     QMRI_HIP(ctx, hipMemcpy(d.d_normD, normD, (size_t)K * sizeof(float), hipMemcpyHostToDevice));
     QMRI_HIP(ctx, hipMemcpy(d.d_lut, lut, (size_t)K * Q * sizeof(float), hipMemcpyHostToDevice));
+    // f16 pieces for the filter: a = g D in (-1, 1) with one power of two g, hi = f16(a), lo = f16(a - hi) (the difference is exact in f32)
+    {
+        float dmax = 0.f; double r2max = 0.0; bool finite = true;
+        for (int a = 0; a < K && finite; ++a) {
+            double r2 = 0.0;
+            for (int c = 0; c < s; ++c) {
+                const float v = D[(size_t)a + (size_t)K * c];
+                if (!std::isfinite(v)) { finite = false; break; }
+                dmax = std::max(dmax, std::fabs(v)); r2 += (double)v * v;
+            }
+            r2max = std::max(r2max, r2);
+        }
+        if (finite && dmax > 1e-30f && dmax < 1e30f) {
+            int e = 0; (void)std::frexp(dmax, &e);
+            const float g = std::ldexp(1.f, -e);                            // g dmax in [0.5, 1)
+            std::vector<_Float16> p16((size_t)d.ntiles * 64 * 16, (_Float16)0.f);
+            for (int t = 0; t < d.ntiles; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int atom = t * 32 + (lane & 31);
+                    _Float16* hi = &p16[((size_t)t * 64 + lane) * 16], *lo = hi + 8;
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int c = 8 * (lane >> 5) + jj;
+                        if (atom >= K || c >= s) continue;
+                        const float a = D[(size_t)atom + (size_t)K * c] * g;
+                        hi[jj] = (_Float16)a; lo[jj] = (_Float16)(a - (float)hi[jj]);
+                    }
+                }
+            QMRI_HIP(ctx, hipMalloc((void**)&d.d_pack16, p16.size() * sizeof(_Float16)));
+            QMRI_HIP(ctx, hipMemcpy(d.d_pack16, p16.data(), p16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+            d.marg_coef = (float)(std::ldexp(1.0, -14) * r2max * (double)g * (double)g * 1.001);
+        }
+    }
     d.ready = true;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_debug_dict_filter(qmri_ctx* ctx, int on, float margin_scale) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_CHECK_ARG(ctx, margin_scale >= 0.f, "margin_scale must be >= 0");
+    ctx->dict.filter_on = on ? 1 : 0;
+    ctx->dict.margin_scale = margin_scale;
     return QMRI_OK;
 }
 

@@ -59,16 +59,20 @@ __device__ __forceinline__ void sqrt_preimage(float s, float m2, float& lo, floa
 
 // D packed as MFMA A-fragments, all pairs of a lane together: pack[tile][lane][q] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s;
 // NPL = 4 or 8 floats per lane, so a tile is one or two 16-byte requests per lane instead of one 4-byte request per pair)
-template <int NPAIR>
+// FILT: the f16 filter in front of the exact products (see the header): pack16[tile][lane] = {hi, lo} pieces of g*D as A-fragments of
+// v_mfma_f32_32x32x16_f16 (row = lane & 31, k = channel = 8 (lane >> 5) + 0..7), marg_coef = 2^-14 (g R)^2.
+constexpr int LCAP = 128;       // tiles a wave collects for the exact products before it works them off
+template <int NPAIR, bool FILT>
 __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X, int Npix, int s, const float* __restrict__ pack,
                                                     int ntiles_all, int K, const float* __restrict__ normD,
                                                     const float* __restrict__ lut, int Q, float* __restrict__ qmap,
                                                     float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm,
-                                                    float4* __restrict__ part) {
+                                                    float4* __restrict__ part, const uint4* __restrict__ pack16, float marg_coef) {
     __shared__ float s_best[4][32];
     __shared__ int s_idx[4][32];
     __shared__ float s_re[4][32];
     __shared__ float s_im[4][32];
+    __shared__ int s_list[FILT ? 4 : 1][FILT ? LCAP : 1];
     // (the wave number as a SCALAR: the tile counter, its bound checks and the fragment pointers of the loop below then live on the scalar
     //  unit -- round 3: a PMC pass showed the f32 MFMA and the vector ALU not to overlap (MFMA busy 0.67 + VALU 0.35 of the launch), so every
     //  vector instruction of the loop is paid in full; 8 of its ~43 were tile-address arithmetic)
@@ -141,24 +145,24 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
     // the update path costs three times the plain tile).  A wave therefore walks its tiles i = 0 .. n-1 (tile tbeg + wave + 4 i) in
     // BIT-REVERSED order of i -- coarse to fine over its whole part: the incumbent is close to the final one after a few tiles and 4.5 %
     // of the tiles reach the update path.  The order is scalar arithmetic (s_brev_b32); the result does not depend on it (see above).
-    {
-        const int n = (ntiles - tbeg - wave + 3) / 4;                  // this wave's tiles (<= 0: none)
-        int nb = 0;
-        while ((1 << nb) < n) ++nb;
-        const unsigned kend = 1u << nb;
-        auto next_i = [&](unsigned& k) __attribute__((always_inline)) -> int {      // next valid i at or after counter k (n when exhausted); k moves past it
-            while (k < kend) {
-                const int i = nb ? (int)(__builtin_bitreverse32(k) >> (32 - nb)) : 0;
-                ++k;
-                if (i < n) return i;
-            }
-            return n;
-        };
-        auto request = [&](int i, f32x4 (&dst)[NV]) __attribute__((always_inline)) {
-            const f32x4* ap = (const f32x4*)(pack + ((size_t)(tbeg + wave + 4 * i) * 64 + lane) * NPL);
+    const int n = (ntiles - tbeg - wave + 3) / 4;                      // this wave's tiles (<= 0: none)
+    int nb = 0;
+    while ((1 << nb) < n) ++nb;
+    const unsigned kend = 1u << nb;
+    auto next_i = [&](unsigned& k) __attribute__((always_inline)) -> int {          // next valid i at or after counter k (n when exhausted); k moves past it
+        while (k < kend) {
+            const int i = nb ? (int)(__builtin_bitreverse32(k) >> (32 - nb)) : 0;
+            ++k;
+            if (i < n) return i;
+        }
+        return n;
+    };
+    auto request = [&](int i, f32x4 (&dst)[NV]) __attribute__((always_inline)) {
+        const f32x4* ap = (const f32x4*)(pack + ((size_t)(tbeg + wave + 4 * i) * 64 + lane) * NPL);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) dst[v] = ap[v];
-        };
+        for (int v = 0; v < NV; ++v) dst[v] = ap[v];
+    };
+    if constexpr (!FILT) {
         unsigned k = 0;
         int i0 = (n > 0) ? next_i(k) : n;
         if (i0 < n) request(i0, av);
@@ -170,6 +174,107 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             i0 = next_i(k);
             if (i0 < n) request(i0, av);
             tile_body(tbeg + wave + 4 * i1, avn);
+        }
+    } else {
+        // ---- the f16 filter.  Per pixel the channels are scaled by a power of two to max |component| in [0.5, 1) and cut into f16 pieces
+        // hi + lo (22 bits); D likewise on the host with one power of two g for the whole dictionary.  Three f16 products
+        // (lo hi, hi lo, hi hi; K = 16 >= s in ONE instruction each) give ip to |error| <= 2^-19 B, B = g R |x| >= |ip| (R the largest row
+        // norm of D) -- the pieces' rounding, the dropped lo lo term and the accumulation, see DESIGN.md section 5.4 -- the exact chain
+        // itself is within 2^-20 B of the real product.  So |ip|^2 of the atom MATLAB's max picks (and of every atom of the same
+        // magnitude) is, as the filter sees it, within 2^-15.8 B^2 of the largest filtered |ip|^2 seen so far; a tile goes to the exact
+        // products iff some lane's filtered maximum comes within marg = 2^-14 B^2 of its running maximum.  Nothing else depends on
+        // the filter: the exact pass applies the rule above to the listed tiles, in any order.
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        f16x8 brh, brl, bih, bil;
+        float marg;
+        {
+            float xr[8], xi[8], mx = 0.f, n2 = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int c = 8 * h + jj;
+                double2 v = make_double2(0.0, 0.0);
+                if (p < Npix && c < s) v = X[(size_t)p + (size_t)Npix * c];
+                xr[jj] = (float)v.x; xi[jj] = -(float)v.y;
+                mx = fmaxf(mx, fmaxf(fabsf(xr[jj]), fabsf(xi[jj])));
+                n2 = fmaf(xr[jj], xr[jj], fmaf(xi[jj], xi[jj], n2));
+            }
+            mx = fmaxf(mx, __shfl(mx, lane ^ 32, 64));
+            n2 += __shfl(n2, lane ^ 32, 64);
+            const bool zero = (mx == 0.f) && (n2 == 0.f);
+            const bool ok = zero || (mx > 1e-30f && mx < 1e30f && n2 == n2);
+            int e = 0;
+            if (ok && !zero) (void)frexpf(mx, &e);
+            const float sc = ldexpf(1.f, -e);                               // max |component| * sc in [0.5, 1)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float a = ok ? xr[jj] * sc : 0.f, b = ok ? xi[jj] * sc : 0.f;
+                const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+                brh[jj] = ah; brl[jj] = (_Float16)(a - (float)ah);
+                bih[jj] = bh; bil[jj] = (_Float16)(b - (float)bh);
+            }
+            // (a pixel with a non-finite, tiny or huge channel is not filtered: marg = +inf sends every tile to the exact products)
+            marg = ok ? marg_coef * (n2 * sc * sc) * 1.001f : __builtin_inff();
+        }
+        float runa = -1.f, cut = -1.f - marg;
+        uint4 a16[2], a16n[2];
+        auto request16 = [&](int i, uint4 (&dst)[2]) __attribute__((always_inline)) {
+            const uint4* ap = pack16 + ((size_t)(tbeg + wave + 4 * i) * 64 + lane) * 2;
+            dst[0] = ap[0]; dst[1] = ap[1];
+        };
+        int cnt = 0;                                                        // listed tiles (scalar)
+        auto filter_body = [&](int i, const uint4 (&a)[2]) __attribute__((always_inline)) {
+            const f16x8 dh = __builtin_bit_cast(f16x8, a[0]), dl = __builtin_bit_cast(f16x8, a[1]);
+            f32x16 fr = {0}, fi = {0};
+            fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, brh, fr, 0, 0, 0);
+            fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, bih, fi, 0, 0, 0);
+            fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, brl, fr, 0, 0, 0);
+            fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, bil, fi, 0, 0, 0);
+            fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, brh, fr, 0, 0, 0);
+            fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, bih, fi, 0, 0, 0);
+            float m2[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 re = {fr[r], fr[r + 1]}, im = {fi[r], fi[r + 1]};
+                const f32x2 v = __builtin_elementwise_fma(im, im, re * re);
+                m2[r] = v[0]; m2[r + 1] = v[1];
+            }
+            const float tm = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
+                                   fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
+            const bool tr = !(tm <= cut);
+            if (__builtin_amdgcn_ballot_w64(tr)) {                          // (uniform)
+                if (tr) { runa = fmaxf(runa, tm); cut = runa - marg; }
+                if (lane == 0) s_list[wave][cnt] = i;
+                ++cnt;
+            }
+        };
+        auto exact_pass = [&]() __attribute__((always_inline)) {            // the listed tiles through the exact products
+            if (cnt == 0) return;
+            int i0 = __builtin_amdgcn_readfirstlane(s_list[wave][0]);
+            request(i0, av);
+            for (int l = 0; l < cnt; l += 2) {
+                int i1 = 0;
+                if (l + 1 < cnt) { i1 = __builtin_amdgcn_readfirstlane(s_list[wave][l + 1]); request(i1, avn); }
+                tile_body(tbeg + wave + 4 * i0, av);
+                if (l + 1 >= cnt) break;
+                if (l + 2 < cnt) { i0 = __builtin_amdgcn_readfirstlane(s_list[wave][l + 2]); request(i0, av); }
+                tile_body(tbeg + wave + 4 * i1, avn);
+            }
+            cnt = 0;
+        };
+        unsigned k = 0;
+        int i0 = (n > 0) ? next_i(k) : n;
+        if (i0 < n) request16(i0, a16);
+        while (i0 < n) {
+            while (i0 < n && cnt < LCAP - 2) {
+                const int i1 = next_i(k);
+                if (i1 < n) request16(i1, a16n);
+                filter_body(i0, a16);
+                if (i1 >= n) { i0 = n; break; }
+                i0 = next_i(k);
+                if (i0 < n) request16(i0, a16);
+                filter_body(i1, a16n);
+            }
+            exact_pass();                                                   // (the list is full or the scan is over)
         }
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
@@ -241,12 +346,14 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
     const int ptiles = (Npix + 31) / 32;
     // atom parts: none if the pixel tiles fill the device's resident workgroups at least four times over (a ragged last round then
     // costs little), else as many as give ~8 rounds, each part keeping >= 64 atom tiles per wave
+    const bool filt = D.d_pack16 && D.filter_on;
     if (!D.slots) {
-        int per_cu = 0;
+        int per_cu = 0, per_cu_f = 0;
         hipDeviceProp_t prop;
         QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dict_match<5>, NT, 0));
-        D.slots = std::max(1, per_cu) * prop.multiProcessorCount;
+        QMRI_HIP(ctx, (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dict_match<5, false>, NT, 0)));
+        QMRI_HIP(ctx, (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, k_dict_match<5, true>, NT, 0)));
+        D.slots = std::max(1, std::min(per_cu, per_cu_f)) * prop.multiProcessorCount;
     }
     int P = 1;
     if (ptiles < 4 * D.slots) {
@@ -264,9 +371,14 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
         part = D.d_part;
     }
     dim3 grid(ptiles, P), blk(NT);
-#define LAUNCH(NP)                                                                                                    \
-    k_dict_match<NP><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q, \
-                                                    d_qmap, d_pd, d_mt, d_dm, part)
+    const float mc = D.marg_coef * D.margin_scale;
+#define LAUNCH(NP)                                                                                                              \
+    do {                                                                                                                        \
+        if (filt) k_dict_match<NP, true><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q, \
+                                                                        d_qmap, d_pd, d_mt, d_dm, part, D.d_pack16, mc);        \
+        else k_dict_match<NP, false><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q,     \
+                                                                    d_qmap, d_pd, d_mt, d_dm, part, nullptr, 0.f);              \
+    } while (0)
     switch (npair) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;

@@ -230,6 +230,11 @@ struct DictHost {
     float* d_normD = nullptr; float* d_lut = nullptr;
     float4* d_part = nullptr; size_t part_cap = 0;        // (|ip|, atom index, re, im) per (atom part, pixel) when the atoms are split over workgroups
     int slots = 0;                                        // workgroups of k_dict_match the device holds at once (occupancy query, first launch)
+    // f16 filter in front of the exact products (dict_kernels.hip): hi / lo pieces of g D as A-fragments, [ntiles][64 lanes][2] of 16 bytes;
+    // nullptr when D holds a non-finite entry (no filter then).  marg_coef = 2^-14 (g R)^2, R = largest row 2-norm of D.
+    uint4* d_pack16 = nullptr;
+    float marg_coef = 0.f;
+    int filter_on = 1; float margin_scale = 1.f;          // qmri_debug_dict_filter
 };
 
 struct qmri_ctx {

@@ -198,6 +198,11 @@ class Engine:
         """Test / A-B hook (qmri_debug_lsqr_persist): all LSQR iterations of an x-update in one launch (default) or two launches per iteration."""
         self._check(self.L.qmri_debug_lsqr_persist(self.h, 2 if on == 2 else int(bool(on))))
 
+    def dict_filter(self, on: bool = True, margin_scale: float = 1.0):
+        """Test / A-B hook (qmri_debug_dict_filter): f16 filter in front of the exact dictionary products (default on; same results)."""
+        self.L.qmri_debug_dict_filter.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        self._check(self.L.qmri_debug_dict_filter(self.h, int(bool(on)), float(margin_scale)))
+
     def denoiser_scheme(self):
         """(scheme, fallbacks): 2 = f16 x 3 products, 3 = bf16 x 6 products; how often a run-time guard switched 2 -> 3."""
         sc, fb = C.c_int(0), C.c_int(0)

@@ -127,3 +127,81 @@ def test_dict_match_bench_K_98304_full_slice(engine_mod, oracle, synth, case224)
     assert np.array_equal(g["dm"], o["dm"]) and np.array_equal(g["mt"], o["mt"]) and np.array_equal(g["pd"], o["pd"]) and np.array_equal(g["qmap"], o["qmap"])
     assert len(np.unique(g["dm"])) > 500
     e.close()
+
+
+def _same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ("dm", "mt", "pd", "qmap"))
+
+
+def test_dict_match_f16_filter_changes_nothing_and_has_margin_to_spare(engine_mod, oracle, synth, case224):
+    """The f16 filter only decides which 32-atom tiles get the exact single-precision products (dict_kernels.hip): with it and without it
+    the maps are the oracle's, bit for bit -- on a noisy slice, on inputs built against the filter (channels over six decades, atoms with
+    components down to 1e-6, pixels nearly orthogonal to every atom so that the winner is a small number among thousands of close
+    ones) -- and the proven margin is far from the first wrong answer: the same inputs with the margin cut to 1/16 still agree."""
+    rng = np.random.default_rng(77)
+    e = engine_mod.Engine(0)
+    cases = []
+    dic = synth.make_dictionary(T=200, n_t1=96, n_t2=64)
+    X = synth.synthesize_tsmi(case224["q"], dic)
+    X = X + 0.02 * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape))
+    cases.append(("noisy slice", dic["D"], dic["normD"], dic["lut"], X[:96, :96]))
+    K, s = 9000, 10
+    D = rng.standard_normal((K, s)) * np.logspace(0, -6, s)[rng.permutation(s)][None, :]
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    lut = np.stack([np.arange(K), -np.arange(K)], axis=1).astype(np.float32)
+    Xw = (rng.standard_normal((48, 48, s)) + 1j * rng.standard_normal((48, 48, s))) * np.logspace(2, -4, s)[None, None, :]
+    cases.append(("six decades", D, np.ones(K, np.float32), lut, Xw))
+    # pixels orthogonal to the dictionary's dominant directions up to 1e-4: |ip| << |x| |d|, thousands of atoms within the margin
+    D2 = rng.standard_normal((K, s)); D2[:, 5:] *= 1e-4
+    D2 = (D2 / np.linalg.norm(D2, axis=1, keepdims=True)).astype(np.float32)
+    Xo = np.zeros((40, 40, s), np.complex128)
+    Xo[..., 5:] = rng.standard_normal((40, 40, 5)) + 1j * rng.standard_normal((40, 40, 5))
+    Xo[..., :5] = 1e-5 * rng.standard_normal((40, 40, 5))
+    cases.append(("nearly orthogonal", D2, np.ones(K, np.float32), lut, Xo))
+    s16 = 16
+    D3 = rng.standard_normal((5000, s16)).astype(np.float32)
+    D3 /= np.linalg.norm(D3, axis=1, keepdims=True)
+    X3 = rng.standard_normal((32, 32, s16)) + 1j * rng.standard_normal((32, 32, s16))
+    cases.append(("s = 16, scaled 1e12", D3 * np.float32(3.7), np.ones(5000, np.float32), lut[:5000], X3 * 1e12))
+    for name, Dm, nd, lt, Xc in cases:
+        o = oracle.dict_match(Xc, Dm, nd, lt)
+        e.set_dictionary(Dm, nd, lt)
+        e.dict_filter(False)
+        g0 = e.dict_match(Xc)
+        e.dict_filter(True)
+        g1 = e.dict_match(Xc)
+        assert _same(g0, o), name + ": exact products"
+        assert _same(g1, o), name + ": with the filter"
+        first_bad = None
+        for k in range(1, 15):
+            e.dict_filter(True, 2.0 ** -k)
+            if not _same(e.dict_match(Xc), o):
+                first_bad = k
+                break
+        e.dict_filter(True, 1.0)
+        print(f"{name}: distinct atoms {len(np.unique(o['dm']))}; first wrong answer with the margin cut to 2^-{first_bad}")
+        assert first_bad is None or first_bad > 4, name
+    e.close()
+
+
+def test_dict_match_filter_leaves_non_finite_and_extreme_pixels_to_the_exact_products(engine_mod, oracle, synth):
+    """Pixels the filter cannot scale (huge, tiny, non-finite channels) go through the exact products tile by tile; zero pixels tie
+    at 0 and keep the first atom."""
+    dic = synth.make_dictionary(T=100, n_t1=40, n_t2=30)
+    rng = np.random.default_rng(5)
+    X = np.zeros((8, 8, 10), np.complex128)
+    X[1] = dic["D"][rng.integers(0, dic["K"], 8)] * 1e-36
+    X[2] = dic["D"][rng.integers(0, dic["K"], 8)] * 1e35
+    X[3] = dic["D"][rng.integers(0, dic["K"], 8)] * (1 + 1j)
+    X[4, 2, 3] = np.inf
+    e = engine_mod.Engine(0)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    g = e.dict_match(X)
+    e.dict_filter(False)
+    g0 = e.dict_match(X)
+    o = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"])
+    fin = np.ones((8, 8), bool); fin[4, 2] = False
+    assert np.array_equal(g["dm"], g0["dm"])
+    assert np.array_equal(g["dm"][fin], o["dm"][fin]) and np.array_equal(g["mt"][fin], o["mt"][fin])
+    assert np.all(g["dm"][0] == 1)
+    e.close()
