@@ -659,6 +659,7 @@ void qmri_free_dict(qmri_ctx* ctx) {
     DictHost& d = ctx->dict;
     if (d.d_pack) (void)hipFree(d.d_pack);
     if (d.d_pack16) (void)hipFree(d.d_pack16);
+    if (d.d_gmax) (void)hipFree(d.d_gmax);
     if (d.d_normD) (void)hipFree(d.d_normD);
     if (d.d_lut) (void)hipFree(d.d_lut);
     if (d.d_part) (void)hipFree(d.d_part);
@@ -714,7 +715,7 @@ extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const flo
             for (int t = 0; t < d.ntiles; ++t)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int atom = t * 32 + (lane & 31);
-                    _Float16* hi = &p16[((size_t)t * 64 + lane) * 16], *lo = hi + 8;
+                    _Float16* hi = &p16[((size_t)t * 128 + lane) * 8], *lo = hi + 64 * 8;     // [tile][hi | lo][lane][8]
                     for (int jj = 0; jj < 8; ++jj) {
                         const int c = 8 * (lane >> 5) + jj;
                         if (atom >= K || c >= s) continue;

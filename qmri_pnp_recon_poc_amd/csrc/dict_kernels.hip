@@ -1,4 +1,6 @@
-// dict_kernels.hip -- MRF dictionary template match on the f32 MFMA (gfx950).
+// dict_kernels.hip -- MRF dictionary template match on the matrix cores (gfx950): exact single-precision products (f32 MFMA) behind an f16
+// filter that decides which 32-atom tiles can hold the winner (k_dict_match_f, the default); k_dict_match is the exact products alone
+// (dictionaries with non-finite entries, qmri_debug_dict_filter(ctx, 0, ..)).  Both give the oracle's bits.
 //
 // Reference semantics: main_files/dictionary_matching/mrf_dtm_cpu.m
 //   :54      x = single(x)
@@ -15,11 +17,12 @@
 // max(abs(ip)) compares single-precision MAGNITUDES: two atoms whose |ip|^2 differ in the last bits but whose
 // sqrtf rounds to the same single tie, and the first index wins (:92).  The loop keeps that semantics without a
 // square root per candidate: beside the best magnitude it holds `thr`, the largest |ip|^2 whose correctly rounded
-// square root is still that magnitude; a candidate beats the incumbent iff its |ip|^2 exceeds thr (checked once per
-// 32-atom tile on the tile's maximum).  The square root and the bounds of its pre-image are evaluated only when the
-// incumbent changes.
+// square root is still that magnitude; a candidate can replace the incumbent iff its |ip|^2 reaches the pre-image (checked once per
+// 32-atom tile on the tile's maximum; thr sits just below the pre-image and an atom of EQUAL magnitude wins only with the lower
+// index, so the tiles may be visited in any order).  The square root and the bounds of its pre-image are evaluated only when a tile
+// gets that far.
 //
-// Work split: a workgroup (4 waves) takes one 32-pixel tile and one of P contiguous parts of the atom tiles; wave w takes the part's
+// Work split of k_dict_match: a workgroup (4 waves) takes one 32-pixel tile and one of P contiguous parts of the atom tiles; wave w takes the part's
 // tiles w, w+4, ...; the four (max, argmax) candidates per pixel are merged through LDS preferring the lower index on ties.  P > 1
 // when the pixel tiles alone do not fill the device evenly: a workgroup walks ALL its atoms (1.1 ms at K = 98 304), so 1568 pixel
 // tiles on 1280 resident workgroups took two rounds, the second at 22 % occupancy -- the matrix pipe idled 40 % of the launch.  The
@@ -57,22 +60,64 @@ __device__ __forceinline__ void sqrt_preimage(float s, float m2, float& lo, floa
     if ((double)lo <= bl) lo = __uint_as_float(__float_as_uint(lo) + 1u);
 }
 
+// One 32-atom tile through the exact products and the incumbent rule.  The incumbent of a lane: best = abs(ip), thr (see the header),
+// (cre, cim) = ip, bidx = atom.
+struct Inc { float best, thr, cre, cim; int bidx; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NPAIR, int NV>
+__device__ __forceinline__ void exact_tile(int t, int h, const f32x4 (&av)[NV], const float (&bre)[NPAIR], const float (&bim)[NPAIR], Inc& I) {
+    float &best = I.best, &thr = I.thr, &cre = I.cre, &cim = I.cim;
+    int& bidx = I.bidx;
+    f32x16 are = {0}, aim = {0};
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) {
+        are = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bre[q], are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bim[q], aim, 0, 0, 0);
+    }
+    // |ip|^2 = fma(im, im, re * re), the bits the oracle computes -- one v_mul_f32 and one v_fma_f32 per row, NOT the packed forms (the file
+    // is compiled with -fno-slp-vectorize): beside MFMAs a v_pk_fma_f32 costs the wave ~22 cycles more than the two plain instructions it
+    // replaces (MI355X_MICROARCH.md, constants table).  The file is also compiled with -amdgpu-mfma-vgpr-form (Makefile): the products
+    // land in VGPRs and the epilogue reads them in place -- with AGPR accumulators 32 of its 80 vector instructions per tile
+    // were v_accvgpr_read, and the epilogue's issue slots, not the matrix pipe, set the pace (10 MFMAs per 32 x 32 outputs).
+    float m2[16], tmax;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m2[r] = __builtin_fmaf(aim[r], aim[r], are[r] * are[r]);
+    tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
+                 fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
+    if (tmax > thr) {          // some atom of this tile reaches the incumbent's magnitude (rare: see the visiting order below)
+        // the tile's magnitude is sqrtf of its largest |ip|^2; MATLAB's max keeps the FIRST atom with the largest magnitude, i.e. the
+        // lowest row of the tile whose |ip|^2 lies in the root's pre-image [lo, hi]: one square root per update, not per candidate.
+        // Tiles are not visited in ascending order, so thr sits just BELOW the incumbent's pre-image: a tile holding an atom of the
+        // same magnitude comes here too and wins only with the lower index.
+        float lo, hi;
+        const float mag = sqrtf(tmax);
+        sqrt_preimage(mag, tmax, lo, hi);
+        int rsel = 15;                                                  // (the tile's maximum itself is >= lo: some row qualifies)
+        float nre = are[15], nim = aim[15];
+#pragma unroll
+        for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; nre = are[r]; nim = aim[r]; }     // (ascending rows = ascending atoms)
+        const int nidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;    // C/D row of the 32x32 MFMA tile
+        if (mag > best || nidx < bidx) {                                // (mag >= best here: tmax > thr means tmax >= the incumbent's lo)
+            best = mag; bidx = nidx; cre = nre; cim = nim;
+            // (magnitude 0 -- an all-zero pixel -- has nothing below it: there the incumbent is row 0 of the wave's FIRST tile,
+            //  which is visited first and is the wave's lowest index, so only a non-zero product may come here again)
+            thr = (lo > 0.f) ? __uint_as_float(__float_as_uint(lo) - 1u) : 0.f;
+        }
+    }
+}
+
 // D packed as MFMA A-fragments, all pairs of a lane together: pack[tile][lane][q] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s;
 // NPL = 4 or 8 floats per lane, so a tile is one or two 16-byte requests per lane instead of one 4-byte request per pair)
-// FILT: the f16 filter in front of the exact products (see the header): pack16[tile][lane] = {hi, lo} pieces of g*D as A-fragments of
-// v_mfma_f32_32x32x16_f16 (row = lane & 31, k = channel = 8 (lane >> 5) + 0..7), marg_coef = 2^-14 (g R)^2.
-constexpr int LCAP = 128;       // tiles a wave collects for the exact products before it works them off
-template <int NPAIR, bool FILT>
+template <int NPAIR>
 __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X, int Npix, int s, const float* __restrict__ pack,
                                                     int ntiles_all, int K, const float* __restrict__ normD,
                                                     const float* __restrict__ lut, int Q, float* __restrict__ qmap,
                                                     float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm,
-                                                    float4* __restrict__ part, const uint4* __restrict__ pack16, float marg_coef) {
+                                                    float4* __restrict__ part) {
     __shared__ float s_best[4][32];
     __shared__ int s_idx[4][32];
     __shared__ float s_re[4][32];
     __shared__ float s_im[4][32];
-    __shared__ int s_list[FILT ? 4 : 1][FILT ? LCAP : 1];
     // (the wave number as a SCALAR: the tile counter, its bound checks and the fragment pointers of the loop below then live on the scalar
     //  unit -- round 3: a PMC pass showed the f32 MFMA and the vector ALU not to overlap (MFMA busy 0.67 + VALU 0.35 of the launch), so every
     //  vector instruction of the loop is paid in full; 8 of its ~43 were tile-address arithmetic)
@@ -89,57 +134,17 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
         bre[q] = (float)v.x;                   // single(x)  mrf_dtm_cpu.m:54
         bim[q] = -(float)v.y;                  // conj
     }
-    float best = -1.0f, thr = -1.0f, cre = 0.f, cim = 0.f;      // best = abs(ip) of the incumbent, thr: see the header
-    int bidx = 0;
+    Inc I = {-1.0f, -1.0f, 0.f, 0.f, 0};
+    float &best = I.best, &cre = I.cre, &cim = I.cim;
+    int& bidx = I.bidx;
     // this workgroup's part of the atom tiles: [tbeg, ntiles)
     const int tper = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
     const int tbeg = (int)blockIdx.y * tper, ntiles = min(ntiles_all, tbeg + tper);
     // The atom fragments of tile t + 4 are requested before the products of tile t (register double buffer): the loop used to
     // request a tile's fragments and wait for them at once, one L2 latency per tile hidden only by occupancy.
     constexpr int NPL = (NPAIR <= 4) ? 4 : 8, NV = NPL / 4;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 av[NV], avn[NV];
-    auto tile_body = [&](int t, const f32x4 (&av)[NV]) __attribute__((always_inline)) {
-        f32x16 are = {0}, aim = {0};
-#pragma unroll
-        for (int q = 0; q < NPAIR; ++q) {
-            are = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bre[q], are, 0, 0, 0);
-            aim = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bim[q], aim, 0, 0, 0);
-        }
-        // |ip|^2 = fma(im, im, re * re), two rows per packed instruction (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations as the
-        // scalar forms, so the bits the oracle computes).  The file is compiled with -amdgpu-mfma-vgpr-form (Makefile): the products
-        // land in VGPRs and the epilogue reads them in place -- with AGPR accumulators 32 of its 80 vector instructions per tile
-        // were v_accvgpr_read, and the epilogue's issue slots, not the matrix pipe, set the pace (10 MFMAs per 32 x 32 outputs).
-        float m2[16], tmax;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2 re = {are[r], are[r + 1]}, im = {aim[r], aim[r + 1]};
-            const f32x2 v = __builtin_elementwise_fma(im, im, re * re);
-            m2[r] = v[0]; m2[r + 1] = v[1];
-        }
-        tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
-                     fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
-        if (tmax > thr) {          // some atom of this tile reaches the incumbent's magnitude (rare: see the visiting order below)
-            // the tile's magnitude is sqrtf of its largest |ip|^2; MATLAB's max keeps the FIRST atom with the largest magnitude, i.e. the
-            // lowest row of the tile whose |ip|^2 lies in the root's pre-image [lo, hi]: one square root per update, not per candidate.
-            // Tiles are not visited in ascending order, so thr sits just BELOW the incumbent's pre-image: a tile holding an atom of the
-            // same magnitude comes here too and wins only with the lower index.
-            float lo, hi;
-            const float mag = sqrtf(tmax);
-            sqrt_preimage(mag, tmax, lo, hi);
-            int rsel = 15;                                                  // (the tile's maximum itself is >= lo: some row qualifies)
-            float nre = are[15], nim = aim[15];
-#pragma unroll
-            for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; nre = are[r]; nim = aim[r]; }     // (ascending rows = ascending atoms)
-            const int nidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;    // C/D row of the 32x32 MFMA tile
-            if (mag > best || nidx < bidx) {                                // (mag >= best here: tmax > thr means tmax >= the incumbent's lo)
-                best = mag; bidx = nidx; cre = nre; cim = nim;
-                // (magnitude 0 -- an all-zero pixel -- has nothing below it: there the incumbent is row 0 of the wave's FIRST tile,
-                //  which is visited first and is the wave's lowest index, so only a non-zero product may come here again)
-                thr = (lo > 0.f) ? __uint_as_float(__float_as_uint(lo) - 1u) : 0.f;
-            }
-        }
-    };
+    auto tile_body = [&](int t, const f32x4 (&av)[NV]) __attribute__((always_inline)) { exact_tile<NPAIR, NV>(t, h, av, bre, bim, I); };
     // Visiting order.  Atoms lie on a (T1, T2) grid and neighbouring pixels have neighbouring matches: in ascending order the scan climbs
     // towards the match row by row and 28 % of the tiles brought a new incumbent for some lane of the wave (measured on the bench slice;
     // the update path costs three times the plain tile).  A wave therefore walks its tiles i = 0 .. n-1 (tile tbeg + wave + 4 i) in
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
 #pragma unroll
         for (int v = 0; v < NV; ++v) dst[v] = ap[v];
     };
-    if constexpr (!FILT) {
+    {
         unsigned k = 0;
         int i0 = (n > 0) ? next_i(k) : n;
         if (i0 < n) request(i0, av);
@@ -174,107 +179,6 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             i0 = next_i(k);
             if (i0 < n) request(i0, av);
             tile_body(tbeg + wave + 4 * i1, avn);
-        }
-    } else {
-        // ---- the f16 filter.  Per pixel the channels are scaled by a power of two to max |component| in [0.5, 1) and cut into f16 pieces
-        // hi + lo (22 bits); D likewise on the host with one power of two g for the whole dictionary.  Three f16 products
-        // (lo hi, hi lo, hi hi; K = 16 >= s in ONE instruction each) give ip to |error| <= 2^-19 B, B = g R |x| >= |ip| (R the largest row
-        // norm of D) -- the pieces' rounding, the dropped lo lo term and the accumulation, see DESIGN.md section 5.4 -- the exact chain
-        // itself is within 2^-20 B of the real product.  So |ip|^2 of the atom MATLAB's max picks (and of every atom of the same
-        // magnitude) is, as the filter sees it, within 2^-15.8 B^2 of the largest filtered |ip|^2 seen so far; a tile goes to the exact
-        // products iff some lane's filtered maximum comes within marg = 2^-14 B^2 of its running maximum.  Nothing else depends on
-        // the filter: the exact pass applies the rule above to the listed tiles, in any order.
-        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-        f16x8 brh, brl, bih, bil;
-        float marg;
-        {
-            float xr[8], xi[8], mx = 0.f, n2 = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int c = 8 * h + jj;
-                double2 v = make_double2(0.0, 0.0);
-                if (p < Npix && c < s) v = X[(size_t)p + (size_t)Npix * c];
-                xr[jj] = (float)v.x; xi[jj] = -(float)v.y;
-                mx = fmaxf(mx, fmaxf(fabsf(xr[jj]), fabsf(xi[jj])));
-                n2 = fmaf(xr[jj], xr[jj], fmaf(xi[jj], xi[jj], n2));
-            }
-            mx = fmaxf(mx, __shfl(mx, lane ^ 32, 64));
-            n2 += __shfl(n2, lane ^ 32, 64);
-            const bool zero = (mx == 0.f) && (n2 == 0.f);
-            const bool ok = zero || (mx > 1e-30f && mx < 1e30f && n2 == n2);
-            int e = 0;
-            if (ok && !zero) (void)frexpf(mx, &e);
-            const float sc = ldexpf(1.f, -e);                               // max |component| * sc in [0.5, 1)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float a = ok ? xr[jj] * sc : 0.f, b = ok ? xi[jj] * sc : 0.f;
-                const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-                brh[jj] = ah; brl[jj] = (_Float16)(a - (float)ah);
-                bih[jj] = bh; bil[jj] = (_Float16)(b - (float)bh);
-            }
-            // (a pixel with a non-finite, tiny or huge channel is not filtered: marg = +inf sends every tile to the exact products)
-            marg = ok ? marg_coef * (n2 * sc * sc) * 1.001f : __builtin_inff();
-        }
-        float runa = -1.f, cut = -1.f - marg;
-        uint4 a16[2], a16n[2];
-        auto request16 = [&](int i, uint4 (&dst)[2]) __attribute__((always_inline)) {
-            const uint4* ap = pack16 + ((size_t)(tbeg + wave + 4 * i) * 64 + lane) * 2;
-            dst[0] = ap[0]; dst[1] = ap[1];
-        };
-        int cnt = 0;                                                        // listed tiles (scalar)
-        auto filter_body = [&](int i, const uint4 (&a)[2]) __attribute__((always_inline)) {
-            const f16x8 dh = __builtin_bit_cast(f16x8, a[0]), dl = __builtin_bit_cast(f16x8, a[1]);
-            f32x16 fr = {0}, fi = {0};
-            fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, brh, fr, 0, 0, 0);
-            fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, bih, fi, 0, 0, 0);
-            fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, brl, fr, 0, 0, 0);
-            fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, bil, fi, 0, 0, 0);
-            fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, brh, fr, 0, 0, 0);
-            fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, bih, fi, 0, 0, 0);
-            float m2[16];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 re = {fr[r], fr[r + 1]}, im = {fi[r], fi[r + 1]};
-                const f32x2 v = __builtin_elementwise_fma(im, im, re * re);
-                m2[r] = v[0]; m2[r + 1] = v[1];
-            }
-            const float tm = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
-                                   fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
-            const bool tr = !(tm <= cut);
-            if (__builtin_amdgcn_ballot_w64(tr)) {                          // (uniform)
-                if (tr) { runa = fmaxf(runa, tm); cut = runa - marg; }
-                if (lane == 0) s_list[wave][cnt] = i;
-                ++cnt;
-            }
-        };
-        auto exact_pass = [&]() __attribute__((always_inline)) {            // the listed tiles through the exact products
-            if (cnt == 0) return;
-            int i0 = __builtin_amdgcn_readfirstlane(s_list[wave][0]);
-            request(i0, av);
-            for (int l = 0; l < cnt; l += 2) {
-                int i1 = 0;
-                if (l + 1 < cnt) { i1 = __builtin_amdgcn_readfirstlane(s_list[wave][l + 1]); request(i1, avn); }
-                tile_body(tbeg + wave + 4 * i0, av);
-                if (l + 1 >= cnt) break;
-                if (l + 2 < cnt) { i0 = __builtin_amdgcn_readfirstlane(s_list[wave][l + 2]); request(i0, av); }
-                tile_body(tbeg + wave + 4 * i1, avn);
-            }
-            cnt = 0;
-        };
-        unsigned k = 0;
-        int i0 = (n > 0) ? next_i(k) : n;
-        if (i0 < n) request16(i0, a16);
-        while (i0 < n) {
-            while (i0 < n && cnt < LCAP - 2) {
-                const int i1 = next_i(k);
-                if (i1 < n) request16(i1, a16n);
-                filter_body(i0, a16);
-                if (i1 >= n) { i0 = n; break; }
-                i0 = next_i(k);
-                if (i0 < n) request16(i0, a16);
-                filter_body(i1, a16n);
-            }
-            exact_pass();                                                   // (the list is full or the scan is over)
         }
     }
     // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
@@ -302,6 +206,219 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
         if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
         if (mt) mt[p] = best;                                        // :150-154
         if (pd) { pd[2 * (size_t)p] = cre / nd; pd[2 * (size_t)p + 1] = cim / nd; }     // :96,:144-148
+        if (qmap)
+            for (int q = 0; q < Q; ++q) {
+                const float v = lut[(size_t)bidx + (size_t)K * q];
+                qmap[(size_t)p + (size_t)Npix * q] = (v != v) ? 0.f : v;                  // NaN -> 0  :138
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The match with the f16 filter in front of the exact products (the default; k_dict_match above when D cannot be cut into f16 pieces).
+//
+// Per pixel the channels are scaled by a power of two to max |component| in [0.5, 1) and cut into f16 pieces hi + lo (22 bits); D likewise
+// on the host with one power of two g for the whole dictionary (pack16).  Three f16 products (lo hi, hi lo, hi hi; K = 16 >= s in ONE
+// v_mfma_f32_32x32x16_f16 each) give ip to |error| <= 2^-19 B, B = g R |x| >= |ip| (R the largest row norm of D) -- the pieces' rounding
+// 5 * 2^-22 B, the accumulation <= 2^-20 B -- and the exact chain itself is within 2^-20 B of the real product.
+// So |ip|^2 of the atom MATLAB's max picks (and of every atom of the same magnitude) is, as the filter sees it, within 2^-15.8 B^2 of
+// the largest filtered |ip|^2 seen so far, and a tile goes to the exact products iff some lane's filtered maximum comes within
+// marg = 2^-14 B^2 of its running maximum.  Nothing else depends on the filter: the listed tiles go through exact_tile(), whose rule
+// does not depend on the order.  192 matrix-core cycles per tile instead of 640, and ~5 % of the tiles listed (bench slice).
+//
+// Work split: a workgroup takes FOUR 32-pixel tiles (one per wave) and one of P parts of the atom tiles; every wave walks all tiles of
+// the part.  The f16 fragments pass through LDS in steps of FSTEP tiles, loaded once per workgroup (each wave fetching its own copy, as
+// the exact kernel does, asked the L2 for 94 GB/s per CU at the matrix cores' pace -- more than a CU gets).  Steps are visited in
+// bit-reversed order (see k_dict_match).
+constexpr int LCAP = 128;       // tiles a wave collects for the exact products before it works them off
+constexpr int FSTEP = 8;        // tiles per LDS step: 16 KB of f16 pieces, [tile][hi | lo][lane] of 16 bytes
+template <int NPAIR, bool SEED>
+__global__ __launch_bounds__(NT) void k_dict_match_f(const double2* __restrict__ X, int Npix, int s, const float* __restrict__ pack,
+                                                      int ntiles_all, int tper, int K, const float* __restrict__ normD,
+                                                      const float* __restrict__ lut, int Q, float* __restrict__ qmap,
+                                                      float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm,
+                                                      float4* __restrict__ part, const uint4* __restrict__ pack16, float marg_coef,
+                                                      int* __restrict__ gmax, int seed_stride) {
+    __shared__ uint4 s_a[2][FSTEP * 128];
+    __shared__ int s_list[4][LCAP];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int p = ((int)blockIdx.x * 4 + wave) * 32 + j;
+    constexpr int NPL = (NPAIR <= 4) ? 4 : 8, NV = NPL / 4;
+    // exact products: B[k = 2q + h][j] = x(p, c = 2q + h) (real chain) and -imag (conjugate) for the imaginary chain
+    float bre[NPAIR], bim[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) {
+        const int c = 2 * q + h;
+        double2 v = make_double2(0.0, 0.0);
+        if (p < Npix && c < s) v = X[(size_t)p + (size_t)Npix * c];
+        bre[q] = (float)v.x;                   // single(x)  mrf_dtm_cpu.m:54
+        bim[q] = -(float)v.y;                  // conj
+    }
+    // filter: B[k = 8 h + jj][j], pieces of the scaled pixel
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    f16x8 brh, brl, bih, bil;
+    float marg;
+    {
+        float xr[8], xi[8], mx = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int c = 8 * h + jj;
+            double2 v = make_double2(0.0, 0.0);
+            if (p < Npix && c < s) v = X[(size_t)p + (size_t)Npix * c];
+            xr[jj] = (float)v.x; xi[jj] = -(float)v.y;
+            mx = fmaxf(mx, fmaxf(fabsf(xr[jj]), fabsf(xi[jj])));
+            n2 = fmaf(xr[jj], xr[jj], fmaf(xi[jj], xi[jj], n2));
+        }
+        mx = fmaxf(mx, __shfl(mx, lane ^ 32, 64));
+        n2 += __shfl(n2, lane ^ 32, 64);
+        const bool zero = (mx == 0.f) && (n2 == 0.f);
+        const bool ok = zero || (mx > 1e-30f && mx < 1e30f && n2 == n2);
+        int e = 0;
+        if (ok && !zero) (void)frexpf(mx, &e);
+        const float sc = ldexpf(1.f, -e);                               // max |component| * sc in [0.5, 1)
+        float n2s = 0.f;                                                // |x|^2 of the scaled pixel (this lane's channels)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float a = ok ? xr[jj] * sc : 0.f, b = ok ? xi[jj] * sc : 0.f;
+            const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+            brh[jj] = ah; brl[jj] = (_Float16)(a - (float)ah);
+            bih[jj] = bh; bil[jj] = (_Float16)(b - (float)bh);
+            n2s = fmaf(a, a, fmaf(b, b, n2s));
+        }
+        n2s += __shfl(n2s, lane ^ 32, 64);
+        // (a pixel with a non-finite, tiny or huge channel is not filtered: marg = +inf sends every tile to the exact products)
+        marg = ok ? marg_coef * n2s * 1.001f : __builtin_inff();
+    }
+    // The running maximum starts from a SEED: gmax[p] holds the largest filtered |ip|^2 of pixel p over a coarse sample of the whole
+    // dictionary (every seed_stride-th step), left there by a first launch of this kernel with SEED = true (3 % of the filter's work; -1
+    // when the dictionary is small and that launch is skipped).  Any value found there belongs to an atom of the dictionary, so the
+    // argument above holds with it.  What it buys: without it every wave climbs from -1 in each of the P atom parts and 7 % of the tiles
+    // went to the exact products (21 parts of 152 tiles on the bench slice); within the margin of the final maximum are ~0.5 %.
+    const bool pub = (marg < __builtin_inff()) && p < Npix;
+    Inc I = {-1.0f, -1.0f, 0.f, 0.f, 0};
+    float runa = (!SEED && pub) ? __int_as_float(gmax[p]) : -1.f, cut = runa - marg;
+    int cnt = 0;                                                        // listed tiles (scalar)
+    // this workgroup's part of the atom tiles: [tbeg, tbeg + n), local index i
+    // (SEED: the whole dictionary, steps (blockIdx.y + gridDim.y k) seed_stride)
+    const int tbeg = SEED ? 0 : (int)blockIdx.y * tper, n = SEED ? ntiles_all : min(ntiles_all - tbeg, tper);
+    const int nsteps = (n + FSTEP - 1) / FSTEP;
+    int nb = 0;
+    while ((1 << nb) < nsteps) ++nb;
+    const unsigned kend = 1u << nb;
+    auto next_step = [&](unsigned& k) __attribute__((always_inline)) -> int {       // next valid step at or after counter k (nsteps when exhausted)
+        if constexpr (SEED) {
+            const long i = ((long)blockIdx.y + (long)gridDim.y * k) * seed_stride;
+            ++k;
+            return i < nsteps ? (int)i : nsteps;
+        }
+        while (k < kend) {
+            const int i = nb ? (int)(__builtin_bitreverse32(k) >> (32 - nb)) : 0;
+            ++k;
+            if (i < nsteps) return i;
+        }
+        return nsteps;
+    };
+    auto stage_load = [&](int st, uint4 (&r)[4]) __attribute__((always_inline)) {
+        const int t0 = tbeg + st * FSTEP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            r[q] = (t0 + idx / 128 < ntiles_all) ? pack16[(size_t)t0 * 128 + idx] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_store = [&](int b, const uint4 (&r)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_a[b][tid + 256 * q] = r[q];
+    };
+    auto filter_tile = [&](int i, uint4 a_hi, uint4 a_lo) __attribute__((always_inline)) {
+        const f16x8 dh = __builtin_bit_cast(f16x8, a_hi), dl = __builtin_bit_cast(f16x8, a_lo);
+        f32x16 fr = {0}, fi = {0};
+        fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, brh, fr, 0, 0, 0);     // (smallest terms first)
+        fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, bih, fi, 0, 0, 0);
+        fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, brl, fr, 0, 0, 0);
+        fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, bil, fi, 0, 0, 0);
+        fr = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, brh, fr, 0, 0, 0);
+        fi = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, bih, fi, 0, 0, 0);
+        float m2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m2[r] = __builtin_fmaf(fi[r], fi[r], fr[r] * fr[r]);
+        auto max3 = [](float a, float b, float c) __attribute__((always_inline)) { return fmaxf(fmaxf(a, b), c); };     // (v_max3_f32: 8 instead of 10 instructions)
+        const float tm = fmaxf(max3(max3(m2[0], m2[1], m2[2]), max3(m2[3], m2[4], m2[5]), m2[15]),
+                               max3(max3(m2[6], m2[7], m2[8]), max3(m2[9], m2[10], m2[11]), max3(m2[12], m2[13], m2[14])));
+        const bool tr = !(tm <= cut);
+        if constexpr (SEED) { runa = fmaxf(runa, tm); return; }
+        if (__builtin_amdgcn_ballot_w64(tr)) {                          // (uniform)
+            if (tr) { runa = fmaxf(runa, tm); cut = runa - marg; }
+            if (lane == 0) s_list[wave][cnt] = i;
+            ++cnt;
+        }
+    };
+    f32x4 av[NV], avn[NV];
+    auto request = [&](int i, f32x4 (&dst)[NV]) __attribute__((always_inline)) {
+        const f32x4* ap = (const f32x4*)(pack + ((size_t)(tbeg + i) * 64 + lane) * NPL);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = ap[v];
+    };
+    auto exact_pass = [&]() __attribute__((always_inline)) {            // the listed tiles through the exact products
+        if (cnt == 0) return;
+        int i0 = __builtin_amdgcn_readfirstlane(s_list[wave][0]);
+        request(i0, av);
+        for (int l = 0; l < cnt; l += 2) {
+            int i1 = 0;
+            if (l + 1 < cnt) { i1 = __builtin_amdgcn_readfirstlane(s_list[wave][l + 1]); request(i1, avn); }
+            exact_tile<NPAIR, NV>(tbeg + i0, h, av, bre, bim, I);
+            if (l + 1 >= cnt) break;
+            if (l + 2 < cnt) { i0 = __builtin_amdgcn_readfirstlane(s_list[wave][l + 2]); request(i0, av); }
+            exact_tile<NPAIR, NV>(tbeg + i1, h, avn, bre, bim, I);
+        }
+        cnt = 0;
+    };
+    {
+        // Tile 0 of the dictionary is listed whatever the filter says: for a pixel whose products are all zero MATLAB's max keeps atom 1,
+        // and exact_tile() gives that answer when the dictionary's first tile is the first one it sees (its note on magnitude 0).
+        if (!SEED && blockIdx.y == 0 && n > 0) { if (lane == 0) s_list[wave][0] = 0; cnt = 1; }
+        unsigned k = 0;
+        uint4 r[4];
+        int st = (nsteps > 0) ? next_step(k) : nsteps, cur = 0;
+        if (st < nsteps) { stage_load(st, r); stage_store(0, r); }
+        __syncthreads();
+        while (st < nsteps) {
+            while (st < nsteps && cnt <= LCAP - FSTEP) {                // (room for one more step; every wave passes one barrier per step)
+                const int stn = next_step(k);
+                if (stn < nsteps) stage_load(stn, r);
+                const int ntl = min(FSTEP, n - st * FSTEP);
+                const uint4* ab = s_a[cur] + lane;
+#pragma unroll 2
+                for (int tt = 0; tt < ntl; ++tt) filter_tile(st * FSTEP + tt, ab[tt * 128], ab[tt * 128 + 64]);
+                if (stn < nsteps) stage_store(cur ^ 1, r);
+                __syncthreads();
+                cur ^= 1; st = stn;
+            }
+            if constexpr (!SEED) exact_pass();
+        }
+    }
+    if constexpr (SEED) {
+        if (pub && runa >= 0.f) (void)__hip_atomic_fetch_max(gmax + p, __float_as_int(runa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // merge the two lane halves (same pixel, interleaved atom rows): larger value, then lower index
+    {
+        const float ob = __shfl(I.best, lane ^ 32, 64), ore = __shfl(I.cre, lane ^ 32, 64), oim = __shfl(I.cim, lane ^ 32, 64);
+        const int oi = __shfl(I.bidx, lane ^ 32, 64);
+        if (ob > I.best || (ob == I.best && oi < I.bidx)) { I.best = ob; I.bidx = oi; I.cre = ore; I.cim = oim; }
+    }
+    if (h == 0 && p < Npix) {
+        int bidx = I.bidx;
+        if (bidx >= K) bidx = 0;       // cannot happen: padded atoms are all-zero and never beat a real one
+        if (part) {                    // atoms split over workgroups: k_dict_merge finishes the pixel
+            part[(size_t)blockIdx.y * Npix + p] = make_float4(I.best, __int_as_float(bidx), I.cre, I.cim);
+            return;
+        }
+        const float nd = normD[bidx];
+        if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
+        if (mt) mt[p] = I.best;                                      // :150-154
+        if (pd) { pd[2 * (size_t)p] = I.cre / nd; pd[2 * (size_t)p + 1] = I.cim / nd; }     // :96,:144-148
         if (qmap)
             for (int q = 0; q < Q; ++q) {
                 const float v = lut[(size_t)bidx + (size_t)K * q];
@@ -343,22 +460,28 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
         qmri_set_error(ctx, "dictionary match supports s <= %d channels (got %d)", 2 * MAXPAIR, D.s);
         return QMRI_ERR_UNSUPPORTED;
     }
-    const int ptiles = (Npix + 31) / 32;
-    // atom parts: none if the pixel tiles fill the device's resident workgroups at least four times over (a ragged last round then
-    // costs little), else as many as give ~8 rounds, each part keeping >= 64 atom tiles per wave
     const bool filt = D.d_pack16 && D.filter_on;
     if (!D.slots) {
         int per_cu = 0, per_cu_f = 0;
         hipDeviceProp_t prop;
         QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        QMRI_HIP(ctx, (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dict_match<5, false>, NT, 0)));
-        QMRI_HIP(ctx, (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, k_dict_match<5, true>, NT, 0)));
-        D.slots = std::max(1, std::min(per_cu, per_cu_f)) * prop.multiProcessorCount;
+        QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dict_match<5>, NT, 0));
+        QMRI_HIP(ctx, (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, k_dict_match_f<5, false>, NT, 0)));
+        D.slots = std::max(1, per_cu) * prop.multiProcessorCount;
+        D.slots_f = std::max(1, per_cu_f) * prop.multiProcessorCount;
     }
-    int P = 1;
-    if (ptiles < 4 * D.slots) {
-        P = (8 * D.slots + ptiles - 1) / ptiles;
-        P = std::max(1, std::min(P, D.ntiles / (4 * 64)));
+    // atom parts: none if the pixel tiles fill the device's resident workgroups at least four times over (a ragged last round then
+    // costs little), else as many as give ~8 rounds, each part keeping >= 64 atom tiles per wave
+    const int ptiles = filt ? (Npix + 127) / 128 : (Npix + 31) / 32;
+    const int slots = filt ? D.slots_f : D.slots;
+    int P = 1, tper = D.ntiles;
+    if (ptiles < 4 * slots) {
+        P = (8 * slots + ptiles - 1) / ptiles;
+        P = std::max(1, std::min(P, D.ntiles / (filt ? 64 : 4 * 64)));
+    }
+    if (filt) {                                                         // whole LDS steps per part, no empty part
+        tper = ((D.ntiles + P - 1) / P + FSTEP - 1) / FSTEP * FSTEP;
+        P = (D.ntiles + tper - 1) / tper;
     }
     float4* part = nullptr;
     if (P > 1) {
@@ -372,12 +495,27 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
     }
     dim3 grid(ptiles, P), blk(NT);
     const float mc = D.marg_coef * D.margin_scale;
+    if (filt) {
+        if (D.gmax_cap < (size_t)Npix) {
+            if (D.d_gmax) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); QMRI_HIP(ctx, hipFree(D.d_gmax)); D.d_gmax = nullptr; D.gmax_cap = 0; }
+            QMRI_HIP(ctx, hipMalloc((void**)&D.d_gmax, (size_t)Npix * sizeof(int)));
+            D.gmax_cap = (size_t)Npix;
+        }
+        QMRI_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)D.d_gmax, (int)0xBF800000u /* -1.0f */, (size_t)Npix, ctx->stream));
+    }
+    // seed launch: ~12 steps of the whole dictionary per pixel, spread over as many workgroups as give one round of the device
+    const int nsteps_all = (D.ntiles + FSTEP - 1) / FSTEP;
+    const int seed_stride = std::max(1, nsteps_all / 12), nseed = (nsteps_all + seed_stride - 1) / seed_stride;
+    const bool seed = filt && P > 1 && nsteps_all >= 48;
+    const int Ps = seed ? std::max(1, std::min(nseed, (slots + ptiles - 1) / ptiles)) : 0;
 #define LAUNCH(NP)                                                                                                              \
     do {                                                                                                                        \
-        if (filt) k_dict_match<NP, true><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q, \
-                                                                        d_qmap, d_pd, d_mt, d_dm, part, D.d_pack16, mc);        \
-        else k_dict_match<NP, false><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q,     \
-                                                                    d_qmap, d_pd, d_mt, d_dm, part, nullptr, 0.f);              \
+        if (seed) k_dict_match_f<NP, true><<<dim3(ptiles, Ps), blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, tper, D.K, D.d_normD, D.d_lut, \
+                                                                    D.Q, nullptr, nullptr, nullptr, nullptr, nullptr, D.d_pack16, mc, D.d_gmax, seed_stride); \
+        if (filt) k_dict_match_f<NP, false><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, tper, D.K, D.d_normD, D.d_lut, D.Q, \
+                                                                    d_qmap, d_pd, d_mt, d_dm, part, D.d_pack16, mc, D.d_gmax, 0); \
+        else k_dict_match<NP><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q,  \
+                                                             d_qmap, d_pd, d_mt, d_dm, part);                                   \
     } while (0)
     switch (npair) {
         case 1: LAUNCH(1); break;

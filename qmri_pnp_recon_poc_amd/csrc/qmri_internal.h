@@ -229,10 +229,11 @@ struct DictHost {
     float* d_pack = nullptr;            // [ntiles][npair][64] MFMA A-fragments
     float* d_normD = nullptr; float* d_lut = nullptr;
     float4* d_part = nullptr; size_t part_cap = 0;        // (|ip|, atom index, re, im) per (atom part, pixel) when the atoms are split over workgroups
-    int slots = 0;                                        // workgroups of k_dict_match the device holds at once (occupancy query, first launch)
-    // f16 filter in front of the exact products (dict_kernels.hip): hi / lo pieces of g D as A-fragments, [ntiles][64 lanes][2] of 16 bytes;
+    int slots = 0, slots_f = 0;                           // workgroups of k_dict_match / k_dict_match_f the device holds at once (occupancy query, first launch)
+    // f16 filter in front of the exact products (dict_kernels.hip): hi / lo pieces of g D as A-fragments, [ntiles][hi | lo][64 lanes] of 16 bytes;
     // nullptr when D holds a non-finite entry (no filter then).  marg_coef = 2^-14 (g R)^2, R = largest row 2-norm of D.
     uint4* d_pack16 = nullptr;
+    int* d_gmax = nullptr; size_t gmax_cap = 0;           // per pixel: largest filtered |ip|^2 seen by any wave (float bits), -1 at launch
     float marg_coef = 0.f;
     int filter_on = 1; float margin_scale = 1.f;          // qmri_debug_dict_filter
 };

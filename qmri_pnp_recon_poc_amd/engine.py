@@ -349,6 +349,12 @@ class Engine:
             out["dm"] = dm.reshape(lead, order="F")
         return out
 
+    def dict_match_dev(self, d_X: int, npix: int, d_qmap: int = 0, d_pd: int = 0, d_mt: int = 0, d_dm: int = 0):
+        """qmri_dict_match_dev: device pointers (X Npix x s complex double column-major; outputs as qmri.h lays them out), asynchronous on
+        the engine's stream."""
+        self._check(self.L.qmri_dict_match_dev(self.h, C.c_void_p(d_X), int(npix), C.c_void_p(d_qmap or None), C.c_void_p(d_pd or None),
+                                               C.c_void_p(d_mt or None), C.c_void_p(d_dm or None)))
+
     # -- profiling -----------------------------------------------------------------------------------
     def profile_enable(self, level: int):
         self._check(self.L.qmri_profile_enable(self.h, int(level)))
