@@ -117,6 +117,9 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     if (p.sp6 != 2 || !p.d_range_flag) return QMRI_OK;
     unsigned f = 0;
     QMRI_HIP(ctx, hipMemcpy(&f, p.d_range_flag, sizeof f, hipMemcpyDeviceToHost));
+#ifdef QMRI_TIMING_ONLY
+    f = 0;
+#endif
     if (!f) return QMRI_OK;
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
     if (p.h_range_flag) std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
@@ -128,6 +131,9 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
 
 // any bit in the pinned host words of the range guards (k_act_check, conv6_kernels.hip)
 static bool host_range_tripped(const NetPlan& p) {
+#ifdef QMRI_TIMING_ONLY
+    return false;
+#endif
     if (!p.h_range_flag) return false;
     const int n = std::min(p.h_range_words, (int)p.layers.size() + 1);
     for (int i = 0; i < n; ++i) if (p.h_range_flag[i]) return true;
@@ -181,7 +187,11 @@ static int net_calibrate_scheme(qmri_ctx* ctx) {
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = QMRI_ERR_HIP; break; }
         float ref_max, diff_max;
         std::memcpy(&ref_max, &m[0], 4); std::memcpy(&diff_max, &m[1], 4);
+#ifdef QMRI_TIMING_ONLY   // builds with parts of a kernel removed (tools/ab_*.sh): wrong results by design -- without this the probe would put them on the bf16 scheme
+        const bool ok = true;
+#else
         const bool ok = flag == 0 && std::isfinite(ref_max) && std::isfinite(diff_max) && diff_max <= 2e-5f * ref_max;
+#endif
         if (getenv("QMRI_CALIB_VERBOSE"))
             fprintf(stderr, "libqmri: calibration probe: max |out| %.3g, max |f16 - f32| %.3g, overflow flag %u -> %s scheme\n", ref_max, diff_max, flag,
                     ok ? "f16 x 3" : "bf16 x 6");

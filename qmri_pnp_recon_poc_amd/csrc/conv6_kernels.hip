@@ -125,6 +125,10 @@ __device__ __forceinline__ f32x16 mfma_b(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef C6_NO_MFMA       // (timing only, with -DQMRI_TIMING_ONLY: the fragments are still read -- the operands stay live)
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
@@ -244,6 +248,9 @@ __device__ __forceinline__ void split_pair(float xa, float xb, unsigned& p0, uns
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, unsigned& p1) {
+#ifdef C6_NO_SPLIT
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){xa, xb}, f16x2)); p1 = 0u; return;      // (timing only: one instruction instead of the split; finite values -- garbage trips the range guard and the run repeats with bf16 pieces)
+#endif
     const f16x2 hi = __builtin_convertvector((f32x2){xa, xb}, f16x2);
     const float ra = __builtin_fmaf((float)hi[0], -1.0f, xa), rb = __builtin_fmaf((float)hi[1], -1.0f, xb);
     const f16x2 lo = __builtin_convertvector((f32x2){ra * LO_SCALE, rb * LO_SCALE}, f16x2);
@@ -962,6 +969,9 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
         // part k_ of B(c0+1); in steps 0..7 of every tile but the first runs epilogue slice g+k_ of the previous tile with the
         // residual operands of set rs.  Residual requests: steps 0..5 ask for slices 2..7 of the previous tile, the tile's last
         // two steps for slices 0 and 1 of the tile itself (consumed by steps 0 and 1 of the next tile).
+#ifdef C6P_LOADER_IDLE  // (timing only: the matrix waves alone -- operands of the first steps stay in LDS, the loaders only keep the barriers)
+#define PITER(k_, rs_a, rs_b, rs_r, rq_a, rq_b, rq_r) { lds_barrier6(); }
+#else
 #define PITER(k_, rs_a, rs_b, rs_r, rq_a, rq_b, rq_r)                                                            \
         {                                                                                                        \
             constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
@@ -990,6 +1000,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             P_STAMP(6, sidx);                                                                                    \
             if constexpr (STAMP) ++sidx;                                                                         \
         }
+#endif
         // ONE loop over the chunks of all tiles of this workgroup (no alternative code paths around in-flight registers)
         bool have_prev = false;
         int sidx = 0;                                               // (STAMP builds: running step number)
