@@ -389,8 +389,13 @@ __global__ __launch_bounds__(NT) void k_dict_match_f(const double2* __restrict__
                 if (stn < nsteps) stage_load(stn, r);
                 const int ntl = min(FSTEP, n - st * FSTEP);
                 const uint4* ab = s_a[cur] + lane;
-#pragma unroll 2
-                for (int tt = 0; tt < ntl; ++tt) filter_tile(st * FSTEP + tt, ab[tt * 128], ab[tt * 128 + 64]);
+                uint4 fh = ab[0], fl = ab[64];                          // (the next tile's fragments are read before this tile's products)
+                for (int tt = 0; tt < ntl; ++tt) {
+                    const int tn = (tt + 1 < ntl) ? tt + 1 : tt;
+                    const uint4 nh = ab[tn * 128], nl = ab[tn * 128 + 64];
+                    filter_tile(st * FSTEP + tt, fh, fl);
+                    fh = nh; fl = nl;
+                }
                 if (stn < nsteps) stage_store(cur ^ 1, r);
                 __syncthreads();
                 cur ^= 1; st = stn;
