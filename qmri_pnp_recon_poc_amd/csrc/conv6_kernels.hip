@@ -215,6 +215,9 @@ template <int N> __device__ __forceinline__ void gwait(u32x4 (&a)[3], BRegs<true
 // of the 1.7-1.9 us of a boundary with nothing dirty (MI355X_MICROARCH.md, price list row "boundary").  Write-through (sc1) stores
 // send the bytes to memory as they are issued -- while other workgroups still compute -- and leave nothing for the boundary.
 __device__ __forceinline__ void store4(float* p, f32x4 x, int wt) {
+#ifdef C6_NO_STORES     // (timing only: k_conv6's output stores dropped)
+    asm volatile("" :: "v"(x), "v"(p)); return;
+#endif
     if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
     else *(f32x4*)p = x;
 }
@@ -472,6 +475,9 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
         // iteration g stores A(g+2) and part g%3 of B(g/3+1) from set (g+1)%3 and requests what iteration g+2 stores,
         // A(g+4) and part (g+2)%3 of B((g+2)/3+1), into set g%3 (whose content iteration g-1 stored).  At the wait the
         // requests of this and of the previous iteration may stay in flight: vmcnt(2*NLOAD).
+#ifdef C6_LOADER_IDLE   // (timing only: k_conv6's matrix waves alone after the prologue)
+#define ITER(k_, rs_a, rs_b, rq_a, rq_b) { lds_barrier6(); }
+#else
 #define ITER(k_, rs_a, rs_b, rq_a, rq_b)   /* iteration g + k_, g = 3*c0 */                                       \
         {                                                                                                        \
             constexpr int part_ = (k_), part2_ = ((k_) + 2) % 3, dc2_ = ((k_) + 2) / 3;                         \
@@ -485,6 +491,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             C6_STAMP(1, g + (k_) + 1);                                                                           \
             lds_barrier6();                                                                                      \
         }
+#endif
         for (int g = 0, c0 = 0; g < nsteps; g += 3, ++c0) {
             ITER(0, ra1, rb1, ra0, rb0)
             ITER(1, ra2, rb2, ra1, rb1)
