@@ -8,7 +8,10 @@ import csv, glob, collections
 acc=collections.defaultdict(list)
 for f in glob.glob('/tmp/pd1/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_dict_match' in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
-for k,v in acc.items(): print(k, sum(v)/len(v), len(v))
+        n = r['Kernel_Name']
+        if 'k_dict_match' in n:
+            kind = 'filter+exact (k_dict_match_f, main)' if 'k_dict_match_f<5, false>' in n or 'Lb0E' in n else 'seed (k_dict_match_f, SEED)' if 'k_dict_match_f' in n else 'exact products only (k_dict_match)'
+            acc[(kind, r['Counter_Name'])].append(float(r['Counter_Value']))
+for k,v in sorted(acc.items()): print('%-40s %-28s %.4g  (%d launches)' % (k[0], k[1], sum(v)/len(v), len(v)))
 PY
 tail -3 /tmp/pd1.log
