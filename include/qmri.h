@@ -181,7 +181,10 @@ int qmri_norm_tv(qmri_ctx* ctx, const double* I, int R, int C, double* out);
 /* D: K x s column-major unit-norm atoms, normD: K, lut: K x Q column-major (dict.D / .normD / .lut, :8-12). */
 int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const float* D, const float* normD, const float* lut);
 /* X: Npix x s complex double column-major (data.X reshaped, :50).  qmap: Npix x Q (NaN->0, :136-141);
- * pd: Npix complex single interleaved (:144-148); mt: Npix or NULL (:150-154); dm: Npix 1-based or NULL (:156-160). */
+ * pd: Npix complex single interleaved (:144-148); mt: Npix or NULL (:150-154); dm: Npix 1-based or NULL (:156-160).
+ * The outputs are those of the single-precision products ip = D x^H (:91) and max(abs(ip)) with the first index winning (:92), bit for bit;
+ * which 32-atom tiles need those products is decided by a filter on f16 pieces with a proven margin (qmri_debug_dict_filter switches it
+ * off; dictionaries with non-finite entries are matched without it). */
 int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm);
 int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt,
                         int32_t* d_dm);
