@@ -252,7 +252,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, unsigned& p1) {
 #ifdef C6_NO_SPLIT
-    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){xa, xb}, f16x2)); p1 = 0u; return;      // (timing only: one instruction instead of the split; finite values -- garbage trips the range guard and the run repeats with bf16 pieces)
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){xa, xb}, f16x2)); p1 = p0 ^ 0x03ff03ffu; return;   // (a lo piece that toggles like a real one: zeros would let the matrix cores run cooler and clock higher)      // (timing only: one instruction instead of the split; finite values -- garbage trips the range guard and the run repeats with bf16 pieces)
 #endif
     const f16x2 hi = __builtin_convertvector((f32x2){xa, xb}, f16x2);
     const float ra = __builtin_fmaf((float)hi[0], -1.0f, xa), rb = __builtin_fmaf((float)hi[1], -1.0f, xb);
