@@ -105,7 +105,7 @@ def audit(lines, name):
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'c6.s')
-        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-S', '--cuda-device-only', SRC, '-o', out])
+        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-fno-slp-vectorize', '-S', '--cuda-device-only', SRC, '-o', out])   # (flags of csrc/Makefile)
         text = open(out).read().split('\n')
     total = 0
     cur, name = [], None
