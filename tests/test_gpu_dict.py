@@ -205,3 +205,37 @@ def test_dict_match_filter_leaves_non_finite_and_extreme_pixels_to_the_exact_pro
     assert np.array_equal(g["dm"][fin], o["dm"][fin]) and np.array_equal(g["mt"][fin], o["mt"][fin])
     assert np.all(g["dm"][0] == 1)
     e.close()
+
+
+def test_dict_match_filter_random_shapes(engine_mod, oracle):
+    """Random channel counts (1 .. 16), dictionary sizes (not multiples of a tile or of an LDS step), pixel counts (not multiples of the
+    128-pixel workgroup), magnitudes and phases: with and without the f16 filter the same bits, and every fourth case against the oracle."""
+    rng = np.random.default_rng(2024)
+    e = engine_mod.Engine(0)
+    for case in range(32):
+        s = int(rng.integers(1, 17))
+        K = int(rng.choice([33, 97, 255, 256, 257, 1000, 2049, 5000]))
+        npix = int(rng.choice([1, 31, 32, 127, 129, 300, 1000]))
+        D = rng.standard_normal((K, s)).astype(np.float32)
+        if case % 3 == 0:                                          # near-duplicate atoms: ties and near-ties across tiles
+            D[K // 2:] = D[:K - K // 2] * (1 + 1e-7 * rng.standard_normal((K - K // 2, 1))).astype(np.float32)
+        D /= np.maximum(np.linalg.norm(D, axis=1, keepdims=True), 1e-20)
+        D = (D * np.float32(10.0 ** rng.integers(-3, 4))).astype(np.float32)
+        nd = np.linalg.norm(D, axis=1).astype(np.float32)
+        lut = rng.standard_normal((K, 2)).astype(np.float32)
+        X = (rng.standard_normal((npix, s)) + 1j * rng.standard_normal((npix, s))) * 10.0 ** rng.integers(-6, 7)
+        if case % 5 == 0:
+            X[rng.integers(0, npix)] = 0
+        if case % 2 == 0:                                          # pixels that ARE atoms (scaled, rotated): exact matches among near-duplicates
+            idx = rng.integers(0, K, npix)
+            X = D[idx].astype(np.complex128) * np.exp(1j * rng.random((npix, 1)) * 6.28) * 10.0 ** rng.integers(-3, 4)
+        e.set_dictionary(D, nd, lut)
+        e.dict_filter(True)
+        g1 = e.dict_match(X)
+        e.dict_filter(False)
+        g0 = e.dict_match(X)
+        assert _same(g0, g1), f"case {case}: s={s} K={K} npix={npix}"
+        if case % 4 == 0:
+            assert _same(g1, oracle.dict_match(X, D, nd, lut)), f"case {case} vs oracle: s={s} K={K} npix={npix}"
+    e.dict_filter(True)
+    e.close()
