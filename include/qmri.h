@@ -178,7 +178,9 @@ int qmri_prox_tv(qmri_ctx* ctx, const double* b, int R, int C, double gamma, dou
 int qmri_norm_tv(qmri_ctx* ctx, const double* I, int R, int C, double* out);
 
 /* ---- dictionary match: out = mrf_dtm_cpu(dict, data, par), mrf_dtm_cpu.m:1 --------------------------- */
-/* D: K x s column-major unit-norm atoms, normD: K, lut: K x Q column-major (dict.D / .normD / .lut, :8-12). */
+/* D: K x s column-major unit-norm atoms, normD: K, lut: K x Q column-major (dict.D / .normD / .lut, :8-12).  s <= 1024: the compressed
+ * atoms of the shipped script (s = 10; s <= 16 keeps a pixel tile in registers) or uncompressed fingerprints (s = T; mrf_dtm_cpu.m:41-50 takes T
+ * from size(data.X)), matched by a channel-blocked GEMM. */
 int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const float* D, const float* normD, const float* lut);
 /* X: Npix x s complex double column-major (data.X reshaped, :50).  qmap: Npix x Q (NaN->0, :136-141);
  * pd: Npix complex single interleaved (:144-148); mt: Npix or NULL (:150-154); dm: Npix 1-based or NULL (:156-160).
@@ -188,6 +190,11 @@ int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const float* D, cons
 int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm);
 int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt,
                         int32_t* d_dm);
+/* The same with out.Xfit (par.f.Xout, mrf_dtm_cpu.m:95,129-134): xfit (nullable) = Npix x s complex single interleaved, column-major,
+ * Xfit(p,:) = ip(dm(p)) .* D(dm(p),:) -- the matched atom scaled by the unnormalised inner product, before the division by normD (:96). */
+int qmri_dict_match_xfit(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm, float* xfit);
+int qmri_dict_match_xfit_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt,
+                             int32_t* d_dm, float* d_xfit);
 
 /* ---- TSMI synthesis from quantitative maps: main_synthesize_tsmis.m:54,82-100 (mode 'real') ------------ */
 /* I = knnsearch(KDTreeSearcher(dict.lut), qm(:,1:2)); X = real(dict.D(I,:)) .* dict.normD(I) .* abs(qm(:,3)); X .* sign(X(:,:,1)).

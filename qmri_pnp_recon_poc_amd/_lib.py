@@ -20,7 +20,7 @@ SYMBOLS = [
     "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
     "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
-    "qmri_dict_match_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
+    "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_onnx_read_unetres",
     "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi", "qmri_synthesize_tsmi_complex",
 ]
@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
     L.qmri_set_dictionary.argtypes = [vp, i, i, i, fp, fp, fp]
     L.qmri_dict_match.argtypes = [vp, vp, i, fp, fp, fp, ip]
     L.qmri_dict_match_dev.argtypes = [vp, vp, i, vp, vp, vp, vp]
+    L.qmri_dict_match_xfit.argtypes = [vp, vp, i, fp, fp, fp, ip, fp]
+    L.qmri_dict_match_xfit_dev.argtypes = [vp, vp, i, vp, vp, vp, vp, vp]
     L.qmri_recon_batch.argtypes = [i, C.POINTER(i), i, C.POINTER(Problem), vp, vp, fp, fp, C.c_char_p, C.c_size_t]
     L.qmri_profile_enable.argtypes = [vp, i]
     L.qmri_profile_get.argtypes = [vp, C.POINTER(Profile), i]

@@ -673,6 +673,8 @@ void qmri_free_dict(qmri_ctx* ctx) {
     if (d.d_normD) (void)hipFree(d.d_normD);
     if (d.d_lut) (void)hipFree(d.d_lut);
     if (d.d_part) (void)hipFree(d.d_part);
+    if (d.d_xp) (void)hipFree(d.d_xp);
+    if (d.d_win) (void)hipFree(d.d_win);
     const int filter_on = d.filter_on; const float margin_scale = d.margin_scale;
     d = DictHost();
     d.filter_on = filter_on; d.margin_scale = margin_scale;
@@ -683,11 +685,23 @@ extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const flo
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
     QMRI_CHECK_ARG(ctx, D && normD && lut, "D / normD / lut must not be NULL");
     QMRI_CHECK_ARG(ctx, K > 0 && s > 0 && Q > 0, "K, s, Q must be positive");
-    if (s > 16) { qmri_set_error(ctx, "dictionary match supports s <= 16 channels (got %d)", s); return QMRI_ERR_UNSUPPORTED; }
+    if (s > 1024) { qmri_set_error(ctx, "dictionary match supports s <= 1024 channels (got %d)", s); return QMRI_ERR_UNSUPPORTED; }
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     qmri_free_dict(ctx);
     DictHost& d = ctx->dict;
     d.K = K; d.s = s; d.Q = Q;
+    if (s > 16) {
+        // wide dictionaries (uncompressed fingerprints, s = T; mrf_dtm_cpu.m:41-50 is T-generic): channel-blocked GEMM, dictw_kernels.hip
+        d.wide = 1;
+        int st = dictw_pack_dictionary(ctx, D, K, s);
+        if (st == QMRI_OK) st = dev_alloc(ctx, &d.d_normD, (size_t)K);
+        if (st == QMRI_OK) st = dev_alloc(ctx, &d.d_lut, (size_t)K * Q);
+        if (st != QMRI_OK) { qmri_free_dict(ctx); return st; }
+        QMRI_HIP(ctx, hipMemcpy(d.d_normD, normD, (size_t)K * sizeof(float), hipMemcpyHostToDevice));
+        QMRI_HIP(ctx, hipMemcpy(d.d_lut, lut, (size_t)K * Q * sizeof(float), hipMemcpyHostToDevice));
+        d.ready = true;
+        return QMRI_OK;
+    }
     d.ntiles = (K + 31) / 32;
     const int npair = (s + 1) / 2;
     // [tile][lane][NPL] with NPL = 4 or 8 floats per lane (its A-fragment value of every channel pair, zero padded): a lane fetches its
@@ -750,23 +764,26 @@ extern "C" int qmri_debug_dict_filter(qmri_ctx* ctx, int on, float margin_scale)
     return QMRI_OK;
 }
 
-extern "C" int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm) {
+extern "C" int qmri_dict_match_xfit_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float* d_xfit) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->dict.ready) { qmri_set_error(ctx, "dictionary not set: call qmri_set_dictionary first"); return QMRI_ERR_STATE; }
     QMRI_CHECK_ARG(ctx, d_X && Npix > 0, "X must not be NULL and Npix > 0");
-    ctx->prof.ms_match += 0.0;
-    return dict_launch(ctx, (const double2*)d_X, Npix, d_qmap, d_pd, d_mt, d_dm);
+    return dict_launch(ctx, (const double2*)d_X, Npix, d_qmap, d_pd, d_mt, d_dm, (float2*)d_xfit);
 }
 
-extern "C" int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm) {
+extern "C" int qmri_dict_match_dev(qmri_ctx* ctx, const void* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm) {
+    return qmri_dict_match_xfit_dev(ctx, d_X, Npix, d_qmap, d_pd, d_mt, d_dm, nullptr);
+}
+
+extern "C" int qmri_dict_match_xfit(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm, float* xfit) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->dict.ready) { qmri_set_error(ctx, "dictionary not set: call qmri_set_dictionary first"); return QMRI_ERR_STATE; }
     QMRI_CHECK_ARG(ctx, X && Npix > 0, "X must not be NULL and Npix > 0");
     const DictHost& d = ctx->dict;
     const size_t nx = (size_t)Npix * d.s;
-    double2* dX = nullptr; float* dq = nullptr; float* dp = nullptr; float* dmt = nullptr; int32_t* ddm = nullptr;
+    double2* dX = nullptr; float* dq = nullptr; float* dp = nullptr; float* dmt = nullptr; int32_t* ddm = nullptr; float2* dxf = nullptr;
     int st = QMRI_OK;
     auto fail = [&](const char* what) { qmri_set_error(ctx, "%s failed in qmri_dict_match", what); st = QMRI_ERR_HIP; };
     do {
@@ -775,17 +792,23 @@ extern "C" int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qm
         if (pd && hipMalloc((void**)&dp, (size_t)Npix * 2 * sizeof(float)) != hipSuccess) { fail("hipMalloc"); break; }
         if (mt && hipMalloc((void**)&dmt, (size_t)Npix * sizeof(float)) != hipSuccess) { fail("hipMalloc"); break; }
         if (dm && hipMalloc((void**)&ddm, (size_t)Npix * sizeof(int32_t)) != hipSuccess) { fail("hipMalloc"); break; }
+        if (xfit && hipMalloc((void**)&dxf, nx * sizeof(float2)) != hipSuccess) { fail("hipMalloc"); break; }
         if (hipMemcpyAsync(dX, X, nx * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
-        if ((st = dict_launch(ctx, dX, Npix, dq, dp, dmt, ddm)) != QMRI_OK) break;
+        if ((st = dict_launch(ctx, dX, Npix, dq, dp, dmt, ddm, dxf)) != QMRI_OK) break;
         if (qmap && hipMemcpyAsync(qmap, dq, (size_t)Npix * d.Q * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (pd && hipMemcpyAsync(pd, dp, (size_t)Npix * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (mt && hipMemcpyAsync(mt, dmt, (size_t)Npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (dm && hipMemcpyAsync(dm, ddm, (size_t)Npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        if (xfit && hipMemcpyAsync(xfit, dxf, nx * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { fail("synchronize"); break; }
     } while (0);
-    void* ptrs[] = { dX, dq, dp, dmt, ddm };
+    void* ptrs[] = { dX, dq, dp, dmt, ddm, dxf };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     return st;
+}
+
+extern "C" int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qmap, float* pd, float* mt, int32_t* dm) {
+    return qmri_dict_match_xfit(ctx, X, Npix, qmap, pd, mt, dm, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -30,80 +30,26 @@
 // so max(abs(ip)) with the first index winning ties (mrf_dtm_cpu.m:92) whatever the split.
 #include <algorithm>
 #include "qmri_internal.h"
+#include "dict_device.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NT = 256;
-constexpr int MAXPAIR = 8;      // s <= 16
+constexpr int MAXPAIR = 8;      // s <= 16 here; more channels: dictw_kernels.hip
 
-// The floats whose correctly rounded square root is s: lo .. hi (two or three consecutive floats share one root).
-// sqrtf() is the correctly rounded square root under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt (the __fsqrt_rn
-// intrinsic is NOT: without OCML_BASIC_ROUNDED_OPERATIONS it is the 1-ulp native instruction) -- bit-identical to glibc's sqrtf.
-// x rounds to s iff (prev(s) + s)/2 < sqrt(x) < (s + next(s))/2 (a tie is impossible: a midpoint has 25 significant bits, its square
-// an odd 50th one, x only 24), i.e. iff mid_lo^2 < x < mid_hi^2 with both squares exact in double precision.
-__device__ __forceinline__ void sqrt_preimage(float s, float m2, float& lo, float& hi) {
-    if (!(s >= 1e-30f && s <= 1e30f)) {                                 // zero, tiny, infinite or NaN: walk (never in practice)
-        lo = hi = m2;
-        for (int it = 0; it < 4; ++it) { const float n = __uint_as_float(__float_as_uint(hi) + 1u); if (sqrtf(n) == s) hi = n; else break; }
-        for (int it = 0; it < 4 && lo > 0.f; ++it) { const float n = __uint_as_float(__float_as_uint(lo) - 1u); if (sqrtf(n) == s) lo = n; else break; }
-        return;
-    }
-    const double sd = (double)s;
-    const double mid_hi = 0.5 * (sd + (double)__uint_as_float(__float_as_uint(s) + 1u));
-    const double mid_lo = 0.5 * (sd + (double)__uint_as_float(__float_as_uint(s) - 1u));
-    const double bh = mid_hi * mid_hi, bl = mid_lo * mid_lo;            // exact
-    hi = (float)bh;                                                     // nearest float; step down if it did not land below bh
-    if ((double)hi >= bh) hi = __uint_as_float(__float_as_uint(hi) - 1u);
-    lo = (float)bl;                                                     // ... step up if it did not land above bl
-    if ((double)lo <= bl) lo = __uint_as_float(__float_as_uint(lo) + 1u);
-}
-
-// One 32-atom tile through the exact products and the incumbent rule.  The incumbent of a lane: best = abs(ip), thr (see the header),
-// (cre, cim) = ip, bidx = atom.
-struct Inc { float best, thr, cre, cim; int bidx; };
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// One 32-atom tile through the exact products and the incumbent rule (dict_device.h).  The file is compiled with -amdgpu-mfma-vgpr-form
+// (Makefile): the products land in VGPRs and the epilogue reads them in place -- with AGPR accumulators 32 of its 80 vector instructions
+// per tile were v_accvgpr_read, and the epilogue's issue slots, not the matrix pipe, set the pace (10 MFMAs per 32 x 32 outputs).
 template <int NPAIR, int NV>
 __device__ __forceinline__ void exact_tile(int t, int h, const f32x4 (&av)[NV], const float (&bre)[NPAIR], const float (&bim)[NPAIR], Inc& I) {
-    float &best = I.best, &thr = I.thr, &cre = I.cre, &cim = I.cim;
-    int& bidx = I.bidx;
     f32x16 are = {0}, aim = {0};
 #pragma unroll
     for (int q = 0; q < NPAIR; ++q) {
         are = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bre[q], are, 0, 0, 0);
         aim = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bim[q], aim, 0, 0, 0);
     }
-    // |ip|^2 = fma(im, im, re * re), the bits the oracle computes -- one v_mul_f32 and one v_fma_f32 per row, NOT the packed forms (the file
-    // is compiled with -fno-slp-vectorize): beside MFMAs a v_pk_fma_f32 costs the wave ~22 cycles more than the two plain instructions it
-    // replaces (MI355X_MICROARCH.md, constants table).  The file is also compiled with -amdgpu-mfma-vgpr-form (Makefile): the products
-    // land in VGPRs and the epilogue reads them in place -- with AGPR accumulators 32 of its 80 vector instructions per tile
-    // were v_accvgpr_read, and the epilogue's issue slots, not the matrix pipe, set the pace (10 MFMAs per 32 x 32 outputs).
-    float m2[16], tmax;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m2[r] = __builtin_fmaf(aim[r], aim[r], are[r] * are[r]);
-    tmax = fmaxf(fmaxf(fmaxf(fmaxf(m2[0], m2[1]), fmaxf(m2[2], m2[3])), fmaxf(fmaxf(m2[4], m2[5]), fmaxf(m2[6], m2[7]))),
-                 fmaxf(fmaxf(fmaxf(m2[8], m2[9]), fmaxf(m2[10], m2[11])), fmaxf(fmaxf(m2[12], m2[13]), fmaxf(m2[14], m2[15]))));
-    if (tmax > thr) {          // some atom of this tile reaches the incumbent's magnitude (rare: see the visiting order below)
-        // the tile's magnitude is sqrtf of its largest |ip|^2; MATLAB's max keeps the FIRST atom with the largest magnitude, i.e. the
-        // lowest row of the tile whose |ip|^2 lies in the root's pre-image [lo, hi]: one square root per update, not per candidate.
-        // Tiles are not visited in ascending order, so thr sits just BELOW the incumbent's pre-image: a tile holding an atom of the
-        // same magnitude comes here too and wins only with the lower index.
-        float lo, hi;
-        const float mag = sqrtf(tmax);
-        sqrt_preimage(mag, tmax, lo, hi);
-        int rsel = 15;                                                  // (the tile's maximum itself is >= lo: some row qualifies)
-        float nre = are[15], nim = aim[15];
-#pragma unroll
-        for (int r = 14; r >= 0; --r) if (m2[r] >= lo) { rsel = r; nre = are[r]; nim = aim[r]; }     // (ascending rows = ascending atoms)
-        const int nidx = t * 32 + (rsel & 3) + 8 * (rsel >> 2) + 4 * h;    // C/D row of the 32x32 MFMA tile
-        if (mag > best || nidx < bidx) {                                // (mag >= best here: tmax > thr means tmax >= the incumbent's lo)
-            best = mag; bidx = nidx; cre = nre; cim = nim;
-            // (magnitude 0 -- an all-zero pixel -- has nothing below it: there the incumbent is row 0 of the wave's FIRST tile,
-            //  which is visited first and is the wave's lowest index, so only a non-zero product may come here again)
-            thr = (lo > 0.f) ? __uint_as_float(__float_as_uint(lo) - 1u) : 0.f;
-        }
-    }
+    inc_update(t, h, are, aim, I);
 }
 
 // D packed as MFMA A-fragments, all pairs of a lane together: pack[tile][lane][q] = D[tile*32 + (lane&31)][2q + (lane>>5)]  (0 beyond K or s;
@@ -113,7 +59,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
                                                     int ntiles_all, int K, const float* __restrict__ normD,
                                                     const float* __restrict__ lut, int Q, float* __restrict__ qmap,
                                                     float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm,
-                                                    float4* __restrict__ part) {
+                                                    float4* __restrict__ part, float4* __restrict__ win) {
     __shared__ float s_best[4][32];
     __shared__ int s_idx[4][32];
     __shared__ float s_re[4][32];
@@ -202,15 +148,7 @@ __global__ __launch_bounds__(NT) void k_dict_match(const double2* __restrict__ X
             part[(size_t)blockIdx.y * Npix + p] = make_float4(best, __int_as_float(bidx), cre, cim);
             return;
         }
-        const float nd = normD[bidx];
-        if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
-        if (mt) mt[p] = best;                                        // :150-154
-        if (pd) { pd[2 * (size_t)p] = cre / nd; pd[2 * (size_t)p + 1] = cim / nd; }     // :96,:144-148
-        if (qmap)
-            for (int q = 0; q < Q; ++q) {
-                const float v = lut[(size_t)bidx + (size_t)K * q];
-                qmap[(size_t)p + (size_t)Npix * q] = (v != v) ? 0.f : v;                  // NaN -> 0  :138
-            }
+        finish_pixel(p, Npix, K, best, bidx, cre, cim, normD, lut, Q, qmap, pd, mt, dm, win);
     }
 }
 
@@ -238,7 +176,7 @@ __global__ __launch_bounds__(NT) void k_dict_match_f(const double2* __restrict__
                                                       const float* __restrict__ lut, int Q, float* __restrict__ qmap,
                                                       float* __restrict__ pd, float* __restrict__ mt, int32_t* __restrict__ dm,
                                                       float4* __restrict__ part, const uint4* __restrict__ pack16, float marg_coef,
-                                                      int* __restrict__ gmax, int seed_stride) {
+                                                      int* __restrict__ gmax, int seed_stride, float4* __restrict__ win) {
     __shared__ uint4 s_a[2][FSTEP * 128];
     __shared__ int s_list[4][LCAP];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -420,45 +358,77 @@ __global__ __launch_bounds__(NT) void k_dict_match_f(const double2* __restrict__
             part[(size_t)blockIdx.y * Npix + p] = make_float4(I.best, __int_as_float(bidx), I.cre, I.cim);
             return;
         }
-        const float nd = normD[bidx];
-        if (dm) dm[p] = bidx + 1;                                    // 1-based  :92,:156-160
-        if (mt) mt[p] = I.best;                                      // :150-154
-        if (pd) { pd[2 * (size_t)p] = I.cre / nd; pd[2 * (size_t)p + 1] = I.cim / nd; }     // :96,:144-148
-        if (qmap)
-            for (int q = 0; q < Q; ++q) {
-                const float v = lut[(size_t)bidx + (size_t)K * q];
-                qmap[(size_t)p + (size_t)Npix * q] = (v != v) ? 0.f : v;                  // NaN -> 0  :138
-            }
+        finish_pixel(p, Npix, K, I.best, bidx, I.cre, I.cim, normD, lut, Q, qmap, pd, mt, dm, win);
     }
 }
 
 // per pixel: the best candidate of the P atom parts (larger magnitude, then lower index), then the outputs as in k_dict_match
 __global__ __launch_bounds__(256) void k_dict_merge(const float4* __restrict__ part, int P, int Npix, int K, const float* __restrict__ normD,
                                                      const float* __restrict__ lut, int Q, float* __restrict__ qmap, float* __restrict__ pd,
-                                                     float* __restrict__ mt, int32_t* __restrict__ dm) {
+                                                     float* __restrict__ mt, int32_t* __restrict__ dm, float4* __restrict__ win) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= Npix) return;
     float4 b = part[p];
     for (int k = 1; k < P; ++k) {
         const float4 o = part[(size_t)k * Npix + p];
-        if (o.x > b.x || (o.x == b.x && __float_as_int(o.y) < __float_as_int(b.y))) b = o;
+        if (cand_better(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
     }
-    int bidx = __float_as_int(b.y);
-    if (bidx >= K || bidx < 0) bidx = 0;   // (cannot happen, as in k_dict_match)
-    const float nd = normD[bidx];
-    if (dm) dm[p] = bidx + 1;
-    if (mt) mt[p] = b.x;
-    if (pd) { pd[2 * (size_t)p] = b.z / nd; pd[2 * (size_t)p + 1] = b.w / nd; }
-    if (qmap)
-        for (int q = 0; q < Q; ++q) {
-            const float v = lut[(size_t)bidx + (size_t)K * q];
-            qmap[(size_t)p + (size_t)Npix * q] = (v != v) ? 0.f : v;
-        }
+    finish_pixel(p, Npix, K, b.x, __float_as_int(b.y), b.z, b.w, normD, lut, Q, qmap, pd, mt, dm, win);
+}
+
+// Xfit(p, :) = ip(dm(p)) .* D(dm(p), :)  (mrf_dtm_cpu.m:95,129-134; single complex, interleaved, Npix x s column-major): the product of two
+// singles rounded once, which is what MATLAB's double product of the two (exact) followed by single() gives.
+__global__ __launch_bounds__(256) void k_dict_xfit(const float4* __restrict__ win, int Npix, int s, DictView dv, float2* __restrict__ xfit) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Npix) return;
+    const float4 w = win[p];
+    const int a = __float_as_int(w.z);
+    for (int c = blockIdx.y; c < s; c += gridDim.y) {
+        const float d = dict_atom(dv, a, c);
+        xfit[(size_t)p + (size_t)Npix * c] = make_float2(w.x * d, w.y * d);
+    }
 }
 
 }  // namespace
 
-int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm) {
+// grow-only device scratch of the dictionary match (the stream is drained before a buffer in use is replaced)
+int dict_scratch(qmri_ctx* ctx, void** buf, size_t* cap, size_t need_bytes) {
+    if (*cap >= need_bytes) return QMRI_OK;
+    if (*buf) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); QMRI_HIP(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    QMRI_HIP(ctx, hipMalloc(buf, need_bytes));
+    *cap = need_bytes;
+    return QMRI_OK;
+}
+
+int dict_launch_merge(qmri_ctx* ctx, const float4* part, int P, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float4* win) {
+    const DictHost& D = ctx->dict;
+    k_dict_merge<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(part, P, Npix, D.K, D.d_normD, D.d_lut, D.Q, d_qmap, d_pd, d_mt, d_dm, win);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
+static int dict_launch_narrow(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float4* win);
+
+// d_xfit (nullable): Npix x s complex single (mrf_dtm_cpu.m:95,129-134, par.f.Xout)
+int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float2* d_xfit) {
+    DictHost& D = ctx->dict;
+    float4* win = nullptr;
+    if (d_xfit) {
+        QMRI_TRY(dict_scratch(ctx, (void**)&D.d_win, &D.win_cap, (size_t)Npix * sizeof(float4)));
+        win = D.d_win;
+    }
+    if (D.wide) QMRI_TRY(dictw_launch(ctx, d_X, Npix, d_qmap, d_pd, d_mt, d_dm, win));
+    else QMRI_TRY(dict_launch_narrow(ctx, d_X, Npix, d_qmap, d_pd, d_mt, d_dm, win));
+    if (d_xfit) {
+        const int npair = (D.s + 1) / 2;
+        const DictView dv = {D.d_pack, D.wide, (npair <= 4) ? 4 : 8, D.G8};
+        k_dict_xfit<<<dim3((Npix + 255) / 256, std::min(D.s, 64)), dim3(256), 0, ctx->stream>>>(win, Npix, D.s, dv, d_xfit);
+        QMRI_HIP(ctx, hipGetLastError());
+    }
+    return QMRI_OK;
+}
+
+static int dict_launch_narrow(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float4* win) {
     DictHost& D = ctx->dict;
     const int npair = (D.s + 1) / 2;
     if (npair < 1 || npair > MAXPAIR) {
@@ -490,22 +460,13 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
     }
     float4* part = nullptr;
     if (P > 1) {
-        const size_t need = (size_t)P * Npix;
-        if (D.part_cap < need) {
-            if (D.d_part) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); QMRI_HIP(ctx, hipFree(D.d_part)); D.d_part = nullptr; D.part_cap = 0; }
-            QMRI_HIP(ctx, hipMalloc((void**)&D.d_part, need * sizeof(float4)));
-            D.part_cap = need;
-        }
+        QMRI_TRY(dict_scratch(ctx, (void**)&D.d_part, &D.part_cap, (size_t)P * Npix * sizeof(float4)));
         part = D.d_part;
     }
     dim3 grid(ptiles, P), blk(NT);
     const float mc = D.marg_coef * D.margin_scale;
     if (filt) {
-        if (D.gmax_cap < (size_t)Npix) {
-            if (D.d_gmax) { QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream)); QMRI_HIP(ctx, hipFree(D.d_gmax)); D.d_gmax = nullptr; D.gmax_cap = 0; }
-            QMRI_HIP(ctx, hipMalloc((void**)&D.d_gmax, (size_t)Npix * sizeof(int)));
-            D.gmax_cap = (size_t)Npix;
-        }
+        QMRI_TRY(dict_scratch(ctx, (void**)&D.d_gmax, &D.gmax_cap, (size_t)Npix * sizeof(int)));
         QMRI_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)D.d_gmax, (int)0xBF800000u /* -1.0f */, (size_t)Npix, ctx->stream));
     }
     // seed launch: ~12 steps of the whole dictionary per pixel, spread over as many workgroups as give one round of the device
@@ -516,11 +477,11 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
 #define LAUNCH(NP)                                                                                                              \
     do {                                                                                                                        \
         if (seed) k_dict_match_f<NP, true><<<dim3(ptiles, Ps), blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, tper, D.K, D.d_normD, D.d_lut, \
-                                                                    D.Q, nullptr, nullptr, nullptr, nullptr, nullptr, D.d_pack16, mc, D.d_gmax, seed_stride); \
+                                                                    D.Q, nullptr, nullptr, nullptr, nullptr, nullptr, D.d_pack16, mc, D.d_gmax, seed_stride, nullptr); \
         if (filt) k_dict_match_f<NP, false><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, tper, D.K, D.d_normD, D.d_lut, D.Q, \
-                                                                    d_qmap, d_pd, d_mt, d_dm, part, D.d_pack16, mc, D.d_gmax, 0); \
+                                                                    d_qmap, d_pd, d_mt, d_dm, part, D.d_pack16, mc, D.d_gmax, 0, win); \
         else k_dict_match<NP><<<grid, blk, 0, ctx->stream>>>(d_X, Npix, D.s, D.d_pack, D.ntiles, D.K, D.d_normD, D.d_lut, D.Q,  \
-                                                             d_qmap, d_pd, d_mt, d_dm, part);                                   \
+                                                             d_qmap, d_pd, d_mt, d_dm, part, win);                              \
     } while (0)
     switch (npair) {
         case 1: LAUNCH(1); break;
@@ -534,9 +495,6 @@ int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, floa
     }
 #undef LAUNCH
     QMRI_HIP(ctx, hipGetLastError());
-    if (P > 1) {
-        k_dict_merge<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(part, P, Npix, D.K, D.d_normD, D.d_lut, D.Q, d_qmap, d_pd, d_mt, d_dm);
-        QMRI_HIP(ctx, hipGetLastError());
-    }
+    if (P > 1) QMRI_TRY(dict_launch_merge(ctx, part, P, Npix, d_qmap, d_pd, d_mt, d_dm, win));
     return QMRI_OK;
 }

@@ -226,14 +226,20 @@ struct OpHost {
 struct DictHost {
     bool ready = false;
     int K = 0, s = 0, Q = 0, ntiles = 0;
-    float* d_pack = nullptr;            // [ntiles][npair][64] MFMA A-fragments
+    // s <= 16 (dict_kernels.hip): d_pack = [ntiles][lane][4 | 8] MFMA A-fragments.
+    // s  > 16 (wide = 1, dictw_kernels.hip): d_pack = [ntiles (padded to 128-atom tiles)][G8][lane][4], G8 = groups of 8 channels (s padded to 16)
+    int wide = 0, G8 = 0;
+    float* d_pack = nullptr;
+    float* d_xp = nullptr; size_t xp_cap = 0;             // wide: the pixels as single-precision B-fragments, [tile32][G8][re | -im][lane][4]  (bytes)
+    float4* d_win = nullptr; size_t win_cap = 0;          // per pixel (re ip, im ip, atom, |ip|) of the winner, kept when Xfit is asked for (bytes)
+    int slots_w = 0;                                      // workgroups of k_dictw_match the device holds at once
     float* d_normD = nullptr; float* d_lut = nullptr;
-    float4* d_part = nullptr; size_t part_cap = 0;        // (|ip|, atom index, re, im) per (atom part, pixel) when the atoms are split over workgroups
+    float4* d_part = nullptr; size_t part_cap = 0;        // (|ip|, atom index, re, im) per (atom part, pixel) when the atoms are split over workgroups (bytes)
     int slots = 0, slots_f = 0;                           // workgroups of k_dict_match / k_dict_match_f the device holds at once (occupancy query, first launch)
     // f16 filter in front of the exact products (dict_kernels.hip): hi / lo pieces of g D as A-fragments, [ntiles][hi | lo][64 lanes] of 16 bytes;
     // nullptr when D holds a non-finite entry (no filter then).  marg_coef = 2^-14 (g R)^2, R = largest row 2-norm of D.
     uint4* d_pack16 = nullptr;
-    int* d_gmax = nullptr; size_t gmax_cap = 0;           // per pixel: largest filtered |ip|^2 seen by any wave (float bits), -1 at launch
+    int* d_gmax = nullptr; size_t gmax_cap = 0;           // per pixel: largest filtered |ip|^2 seen by any wave (float bits), -1 at launch (bytes)
     float marg_coef = 0.f;
     int filter_on = 1; float margin_scale = 1.f;          // qmri_debug_dict_filter
 };
@@ -328,4 +334,9 @@ size_t conv_pack_weights(const ConvLayer& L, const float* w_src, std::vector<flo
 void conv_plan_layer(ConvLayer& L, ConvKind kind, int Cin, int Cout);
 
 // dictionary match (dict_kernels.hip)
-int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm);
+int dict_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float2* d_xfit);
+int dict_scratch(qmri_ctx* ctx, void** buf, size_t* cap, size_t need_bytes);
+int dict_launch_merge(qmri_ctx* ctx, const float4* part, int P, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float4* win);
+// wide dictionaries (16 < s <= 1024; dictw_kernels.hip)
+int dictw_pack_dictionary(qmri_ctx* ctx, const float* D_host, int K, int s);    // fills ctx->dict.d_pack / G8 / ntiles
+int dictw_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, float* d_pd, float* d_mt, int32_t* d_dm, float4* win);

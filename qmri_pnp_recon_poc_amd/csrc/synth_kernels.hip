@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <vector>
 #include "qmri_internal.h"
+#include "dict_device.h"
 
 #pragma clang fp contract(off)      // d1*d1 + d2*d2 unfused, as in the oracle: equal distances must compare equal (first index wins)
 
@@ -66,15 +67,13 @@ __global__ __launch_bounds__(256) void k_nn_combine(const double* __restrict__ p
 }
 
 // X(p, c) = D(I, c) * normD(I) * |PD(p)|, then times sign(X(p, 1))  -- single precision, as the reference's arrays are
-__global__ __launch_bounds__(256) void k_synth_tsmi(const double* __restrict__ qmap, int Npix, const int32_t* __restrict__ idx, const float* __restrict__ pack,
+__global__ __launch_bounds__(256) void k_synth_tsmi(const double* __restrict__ qmap, int Npix, const int32_t* __restrict__ idx, DictView dv,
                                                      const float* __restrict__ normD, int s, float* __restrict__ X) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= Npix) return;
     const int a = idx[p] - 1;
-    const int npair = (s + 1) / 2, t = a >> 5;
     const float nd = normD[a], pd = (float)fabs(qmap[(size_t)2 * Npix + p]);
-    const int npl = (npair <= 4) ? 4 : 8;                                  // (qmri_set_dictionary's fragment order: [tile][lane][npl])
-    auto atom = [&](int c) { return pack[((size_t)t * 64 + (a & 31) + 32 * (c & 1)) * npl + (c >> 1)]; };
+    auto atom = [&](int c) { return dict_atom(dv, a, c); };               // (qmri_set_dictionary's fragment order: dict_device.h)
     const float x0 = atom(0) * nd * pd;
     const float sg = (x0 > 0.f) ? 1.f : ((x0 < 0.f) ? -1.f : 0.f);        // MATLAB sign(): 0 at 0
     for (int c = 0; c < s; ++c) X[(size_t)c * Npix + p] = atom(c) * nd * pd * sg;
@@ -83,15 +82,14 @@ __global__ __launch_bounds__(256) void k_synth_tsmi(const double* __restrict__ q
 // mode 'complex' (main_synthesize_tsmis.m:100-103): X = (D .* normD) .* PD with PD complex, no abs and no sign alignment;
 // the output stacks the real parts of the s channels and then their imaginary parts (cat(3, real(X), imag(X)): 2s channels)
 __global__ __launch_bounds__(256) void k_synth_tsmi_complex(const double* __restrict__ qmap, const double* __restrict__ pd_imag, int Npix,
-                                                             const int32_t* __restrict__ idx, const float* __restrict__ pack,
+                                                             const int32_t* __restrict__ idx, DictView dv,
                                                              const float* __restrict__ normD, int s, float* __restrict__ X) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= Npix) return;
     const int a = idx[p] - 1;
-    const int npair = (s + 1) / 2, t = a >> 5;
     const float nd = normD[a], pr = (float)qmap[(size_t)2 * Npix + p], pi = pd_imag ? (float)pd_imag[p] : 0.f;
     for (int c = 0; c < s; ++c) {
-        const float base = pack[((size_t)t * 64 + (a & 31) + 32 * (c & 1)) * ((npair <= 4) ? 4 : 8) + (c >> 1)] * nd;
+        const float base = dict_atom(dv, a, c) * nd;
         X[(size_t)c * Npix + p] = base * pr;
         X[(size_t)(s + c) * Npix + p] = base * pi;
     }
@@ -134,8 +132,9 @@ static int synthesize_impl(qmri_ctx* ctx, const double* qmap, const double* pd_i
         if (pd_imag && hipMemcpyAsync(d_im, pd_imag, (size_t)Npix * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
         k_nn_lut<<<dim3(nbx, nslice), dim3(NNT), 0, ctx->stream>>>(d_q, Npix, d.d_lut, d.K, kslice, d_pd, d_pi);
         k_nn_combine<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_pd, d_pi, Npix, nslice, d_i);
-        if (complex_mode) k_synth_tsmi_complex<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, d_im, Npix, d_i, d.d_pack, d.d_normD, d.s, d_X);
-        else k_synth_tsmi<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, Npix, d_i, d.d_pack, d.d_normD, d.s, d_X);
+        const DictView dv = {d.d_pack, d.wide, ((d.s + 1) / 2 <= 4) ? 4 : 8, d.G8};
+        if (complex_mode) k_synth_tsmi_complex<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, d_im, Npix, d_i, dv, d.d_normD, d.s, d_X);
+        else k_synth_tsmi<<<dim3((Npix + 255) / 256), dim3(256), 0, ctx->stream>>>(d_q, Npix, d_i, dv, d.d_normD, d.s, d_X);
         if (hipGetLastError() != hipSuccess) { fail("kernel launch"); break; }
         if (hipMemcpyAsync(X_out, d_X, (size_t)nch * Npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
         if (idx_out && hipMemcpyAsync(idx_out, d_i, (size_t)Npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { fail("D2H copy"); break; }

@@ -325,8 +325,9 @@ class Engine:
         self._check(self.L.qmri_norm_tv(self.h, I.ctypes.data_as(C.POINTER(C.c_double)), I.shape[0], I.shape[1], C.byref(out)))
         return float(out.value)
 
-    def dict_match(self, X, want_mt=True, want_dm=True):
-        """out = mrf_dtm_cpu(dict, data, par)  (mrf_dtm_cpu.m:1).  X [..., s] complex -> dict of arrays."""
+    def dict_match(self, X, want_mt=True, want_dm=True, want_xfit=False):
+        """out = mrf_dtm_cpu(dict, data, par)  (mrf_dtm_cpu.m:1).  X [..., s] complex -> dict of arrays; want_xfit adds Xfit [..., s]
+        complex64 (par.f.Xout, :95,129-134)."""
         X = np.asarray(X, dtype=np.complex128)
         K, s, Q = self.dict_shape
         if X.shape[-1] != s:
@@ -338,22 +339,26 @@ class Engine:
         pd = np.empty(2 * npix, np.float32)
         mt = np.empty(npix, np.float32) if want_mt else None
         dm = np.empty(npix, np.int32) if want_dm else None
+        xfit = np.empty(2 * npix * s, np.float32) if want_xfit else None
         f = C.POINTER(C.c_float)
-        self._check(self.L.qmri_dict_match(self.h, _vp(xb), npix, qmap.ctypes.data_as(f), pd.ctypes.data_as(f),
-                                           mt.ctypes.data_as(f) if mt is not None else None,
-                                           dm.ctypes.data_as(C.POINTER(C.c_int32)) if dm is not None else None))
+        self._check(self.L.qmri_dict_match_xfit(self.h, _vp(xb), npix, qmap.ctypes.data_as(f), pd.ctypes.data_as(f),
+                                                mt.ctypes.data_as(f) if mt is not None else None,
+                                                dm.ctypes.data_as(C.POINTER(C.c_int32)) if dm is not None else None,
+                                                xfit.ctypes.data_as(f) if xfit is not None else None))
         out = {"qmap": qmap.reshape(lead + (Q,), order="F"), "pd": pd.view(np.complex64).reshape(lead, order="F")}
+        if xfit is not None:
+            out["Xfit"] = xfit.view(np.complex64).reshape(lead + (s,), order="F")
         if mt is not None:
             out["mt"] = mt.reshape(lead, order="F")
         if dm is not None:
             out["dm"] = dm.reshape(lead, order="F")
         return out
 
-    def dict_match_dev(self, d_X: int, npix: int, d_qmap: int = 0, d_pd: int = 0, d_mt: int = 0, d_dm: int = 0):
-        """qmri_dict_match_dev: device pointers (X Npix x s complex double column-major; outputs as qmri.h lays them out), asynchronous on
+    def dict_match_dev(self, d_X: int, npix: int, d_qmap: int = 0, d_pd: int = 0, d_mt: int = 0, d_dm: int = 0, d_xfit: int = 0):
+        """qmri_dict_match_xfit_dev: device pointers (X Npix x s complex double column-major; outputs as qmri.h lays them out), asynchronous on
         the engine's stream."""
-        self._check(self.L.qmri_dict_match_dev(self.h, C.c_void_p(d_X), int(npix), C.c_void_p(d_qmap or None), C.c_void_p(d_pd or None),
-                                               C.c_void_p(d_mt or None), C.c_void_p(d_dm or None)))
+        self._check(self.L.qmri_dict_match_xfit_dev(self.h, C.c_void_p(d_X), int(npix), C.c_void_p(d_qmap or None), C.c_void_p(d_pd or None),
+                                                    C.c_void_p(d_mt or None), C.c_void_p(d_dm or None), C.c_void_p(d_xfit or None)))
 
     # -- profiling -----------------------------------------------------------------------------------
     def profile_enable(self, level: int):

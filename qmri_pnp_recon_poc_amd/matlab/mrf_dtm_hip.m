@@ -14,11 +14,15 @@ if ~isreal(D)   % mrf_dtm_cpu.m:91 multiplies by dict.D as stored; the GPU match
     D = real(D);
 end
 qmri_mex('set_dictionary', single(D), single(real(dict.normD(:))), single(real(dict.lut)));
-[qmap, pd, mt, dm] = qmri_mex('dict_match', complex(double(reshape(data.X, [Npix, T]))), Q);
+if par.f.Xout   % mrf_dtm_cpu.m:95,129-134: Xfit = ip(dm) .* D(dm,:)
+    [qmap, pd, mt, dm, xfit] = qmri_mex('dict_match', complex(double(reshape(data.X, [Npix, T]))), Q);
+else
+    [qmap, pd, mt, dm] = qmri_mex('dict_match', complex(double(reshape(data.X, [Npix, T]))), Q);
+end
 if par.f.qout,  out.qmap = reshape(qmap, [datadims(1:end-1), Q]);  out.mask = true(datadims(1:end-1)); end
 if par.f.pdout, out.pd = reshape(pd, [datadims(1:end-1), 1]); end
 if par.f.mtout, out.mt = reshape(mt, [datadims(1:end-1), 1]); end
 if par.f.dmout, out.dm = reshape(single(dm), [datadims(1:end-1), 1]); end
-if par.f.Xout,  out.X = data.X; end
+if par.f.Xout,  out.Xfit = reshape(xfit, [datadims(1:end-1), T]);  out.X = data.X; end
 if par.f.Yout && isfield(data, 'Y'), out.Y = data.Y; end
 end

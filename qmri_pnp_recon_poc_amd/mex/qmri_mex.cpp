@@ -166,17 +166,19 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             mexErrMsgIdAndTxt("qmri:set_dictionary:size", "normD must have K elements and lut K rows (K = rows of D)");
         check(qmri_set_dictionary(ctx(), (int)mxGetM(prhs[1]), (int)mxGetN(prhs[1]), (int)mxGetN(prhs[3]),
                                   (const float*)mxGetData(prhs[1]), (const float*)mxGetData(prhs[2]), (const float*)mxGetData(prhs[3])));
-    } else if (c == "dict_match") {                  // [qmap, pd, mt, dm] = qmri_mex('dict_match', X(Npix x s complex double), Q)
+    } else if (c == "dict_match") {                  // [qmap, pd, mt, dm, xfit] = qmri_mex('dict_match', X(Npix x s complex double), Q)
         const int npix = (int)mxGetM(prhs[1]), Q = (int)mxGetScalar(prhs[2]);
+        mxArray* xfit = (nlhs > 4) ? mxCreateNumericMatrix(npix, mxGetN(prhs[1]), mxSINGLE_CLASS, mxCOMPLEX) : nullptr;   // out.Xfit, mrf_dtm_cpu.m:129-134
         plhs[0] = mxCreateNumericMatrix(npix, Q, mxSINGLE_CLASS, mxREAL);
         mxArray* pd = mxCreateNumericMatrix(npix, 1, mxSINGLE_CLASS, mxCOMPLEX);
         mxArray* mt = mxCreateNumericMatrix(npix, 1, mxSINGLE_CLASS, mxREAL);
         mxArray* dm = mxCreateNumericMatrix(npix, 1, mxINT32_CLASS, mxREAL);
-        check(qmri_dict_match(ctx(), mxGetComplexDoubles(prhs[1]), npix, (float*)mxGetData(plhs[0]), (float*)mxGetData(pd),
-                              (float*)mxGetData(mt), (int32_t*)mxGetData(dm)));
+        check(qmri_dict_match_xfit(ctx(), mxGetComplexDoubles(prhs[1]), npix, (float*)mxGetData(plhs[0]), (float*)mxGetData(pd),
+                                   (float*)mxGetData(mt), (int32_t*)mxGetData(dm), xfit ? (float*)mxGetData(xfit) : nullptr));
         if (nlhs > 1) plhs[1] = pd; else mxDestroyArray(pd);
         if (nlhs > 2) plhs[2] = mt; else mxDestroyArray(mt);
         if (nlhs > 3) plhs[3] = dm; else mxDestroyArray(dm);
+        if (nlhs > 4) plhs[4] = xfit;
     } else if (c == "release") {
         cleanup();
         if (mexIsLocked()) mexUnlock();

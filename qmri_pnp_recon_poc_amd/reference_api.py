@@ -150,8 +150,8 @@ def mrf_dtm_cpu(dict_, data, par, device=0):
     """out = mrf_dtm_cpu(dict, data, par)  (mrf_dtm_cpu.m:1): dict.{D,normD,lut}, data.X, par.f.{qout,pdout,mtout,dmout,Xout}."""
     eng = _engine(device)
     eng.set_dictionary(dict_["D"], dict_["normD"], dict_["lut"])
-    r = eng.dict_match(data["X"], want_mt=True, want_dm=True)
     f = par.get("f", {})
+    r = eng.dict_match(data["X"], want_mt=True, want_dm=True, want_xfit=bool(f.get("Xout", 0)))
     out = {}
     if f.get("qout", 1):
         out["qmap"], out["mask"] = r["qmap"], np.ones(np.asarray(data["X"]).shape[:-1], bool)
@@ -161,6 +161,6 @@ def mrf_dtm_cpu(dict_, data, par, device=0):
         out["mt"] = r["mt"]
     if f.get("dmout", 0):
         out["dm"] = r["dm"].astype(np.float32)
-    if f.get("Xout", 0):
-        out["X"] = data["X"]
+    if f.get("Xout", 0):                                      # mrf_dtm_cpu.m:129-134: the scaled matched atoms and the input
+        out["Xfit"], out["X"] = r["Xfit"], data["X"]
     return out

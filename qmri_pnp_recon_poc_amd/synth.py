@@ -56,8 +56,11 @@ def flip_angle_train(T: int, seed: int = 0) -> np.ndarray:
     return np.deg2rad(5.0 + lobes + jitter)
 
 
-def make_dictionary(T: int = 200, n_t1: int = 128, n_t2: int = 64, s: int = 10, seed: int = 0) -> dict:
+def make_dictionary(T: int = 200, n_t1: int = 128, n_t2: int = 64, s: int = 10, seed: int = 0, uncompressed: bool = False) -> dict:
     """Synthetic MRF dictionary with K = n_t1*n_t2 atoms.
+
+    uncompressed=True: D holds the unit-norm fingerprints themselves, [K, T] (the s = T case of mrf_dtm_cpu.m:41-50, V = identity);
+    `s` is ignored and V is None.
 
     Returns dict(D [K,s] f32 unit-norm, normD [K] f32, lut [K,2] f32 = (T1,T2) seconds, V [T,s] f64 with
     orthonormal columns) -- the fields `main_recon_tsmis_FFT.m:127-129` loads and `mrf_dtm_cpu.m:91-96` uses.
@@ -85,6 +88,10 @@ def make_dictionary(T: int = 200, n_t1: int = 128, n_t2: int = 64, s: int = 10, 
         F[:, t] = mx * ete
         mx = mx * e2
         mz = 1.0 + (mz - 1.0) * e1
+    if uncompressed:
+        normD = np.linalg.norm(F, axis=1)
+        return {"D": np.ascontiguousarray((F / normD[:, None]).astype(np.float32)), "normD": normD.astype(np.float32),
+                "lut": np.ascontiguousarray(np.stack([T1, T2], axis=1).astype(np.float32)), "V": None, "t1_grid": t1, "t2_grid": t2, "K": K}
     # temporal subspace: top-s eigenvectors of F'F (== right singular vectors of F)
     G = F.T @ F
     evals, evecs = np.linalg.eigh(G)

@@ -239,3 +239,124 @@ def test_dict_match_filter_random_shapes(engine_mod, oracle):
             assert _same(g1, oracle.dict_match(X, D, nd, lut)), f"case {case} vs oracle: s={s} K={K} npix={npix}"
     e.dict_filter(True)
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# wide dictionaries: 16 < s <= 1024 channels (uncompressed fingerprints, s = T; mrf_dtm_cpu.m:41-50 takes T from size(data.X)) -- the
+# channel-blocked f32-MFMA GEMM of dictw_kernels.hip against the oracle's sequential fmaf chain, bit for bit
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _assert_same(g, o, keys=("dm", "mt", "pd", "qmap")):
+    for k in keys:
+        assert np.array_equal(g[k], o[k]), f"{k} differs: {int(np.sum(g[k] != o[k]))} of {g[k].size}"
+
+
+@pytest.mark.parametrize("T", [17, 64, 200, 1000])
+def test_wide_dict_match_bit_exact(engine_mod, oracle, synth, T):
+    """K = 4096 atoms x T channels against 64 x 64 noisy complex pixels (some of them all-zero, some an exact atom): indices, magnitudes, PD
+    and maps equal the oracle's bits.  T = 17 and 1000 are not multiples of the 16-channel stage (zero padding adds fma(0, 0, acc))."""
+    dic = synth.make_dictionary(T=T, n_t1=64, n_t2=64, uncompressed=True)
+    assert dic["D"].shape == (4096, T)
+    q = synth.make_phantom_qmaps(64, seed=1)
+    X = synth.synthesize_tsmi(q, dic)
+    rng = np.random.default_rng(T)
+    X = X * np.exp(1j * rng.random((64, 64, 1)) * 6.28) + 0.02 * X.std() * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape))
+    X[0, :8] = 0.0                                                  # all-zero pixels: every |ip| ties at 0 -> atom 1
+    X[5, 5] = 3.0 * dic["D"][1234]
+    X[6, 6] = -2.0j * dic["D"][4095]
+    e = engine_mod.Engine(0)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    g = e.dict_match(X, want_xfit=True)
+    o = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"], want_xfit=True)
+    _assert_same(g, o, ("dm", "mt", "pd", "qmap", "Xfit"))
+    assert g["dm"][0, 0] == 1 and g["dm"][5, 5] == 1235 and g["dm"][6, 6] == 4096
+    assert len(np.unique(g["dm"])) > 50                            # (the match is not degenerate)
+    e.close()
+
+
+def test_wide_dict_match_ragged_sizes_and_ties(engine_mod, oracle):
+    """Atom and pixel counts that are not multiples of the 128 x 128 tile, an odd channel count, and thousands of atoms within +-3 ulp of
+    each other spread over several atom parts: max(abs(ip)) with the first index winning (mrf_dtm_cpu.m:92) survives the split and the merge."""
+    rng = np.random.default_rng(77)
+    e = engine_mod.Engine(0)
+    for K, s, shape in ((185, 23, (5, 7)), (6000, 40, (40, 40)), (1300, 129, (31, 9))):
+        base = rng.standard_normal(s).astype(np.float32)
+        base /= np.linalg.norm(base)
+        D = np.repeat(base[None, :], K, axis=0)
+        D = (D.view(np.int32) + rng.integers(-3, 4, size=D.shape, dtype=np.int32)).view(np.float32).copy()
+        nd = (1.0 + rng.random(K)).astype(np.float32)
+        lut = np.stack([np.arange(K), -np.arange(K)], axis=1).astype(np.float32)
+        lut[K // 2, 1] = np.nan                                    # NaN -> 0 (mrf_dtm_cpu.m:138)
+        X = (base[None, None, :] * (1.0 + rng.random(shape + (1,)))) * np.exp(1j * rng.random(shape + (1,)) * 6.28)
+        X = X + 1e-7 * rng.standard_normal(X.shape)
+        X[0, 0] = 0.0
+        e.set_dictionary(D, nd, lut)
+        g = e.dict_match(X, want_xfit=True)
+        o = oracle.dict_match(X, D, nd, lut, want_xfit=True)
+        _assert_same(g, o, ("dm", "mt", "pd", "qmap", "Xfit"))
+        assert g["dm"][0, 0] == 1
+        print(f"K={K} s={s}: distinct winning atoms {len(np.unique(g['dm']))}, largest index {int(g['dm'].max())}")
+    e.close()
+
+
+def test_wide_dict_match_full_slice_round_trip(engine_mod, synth):
+    """BASELINE configs[4] at its pixel count: 224 x 224 pixels x T = 1000 uncompressed channels against K = 4096 atoms (size-independent
+    property: maps -> TSMI -> match returns the atoms the synthesis used, PD included), and the device entry point."""
+    T = 1000
+    dic = synth.make_dictionary(T=T, n_t1=64, n_t2=64, uncompressed=True)
+    q = synth.make_phantom_qmaps(224, seed=0)
+    X = synth.synthesize_tsmi(q, dic)
+    t1g, t2g = dic["t1_grid"], dic["t2_grid"]
+    e = engine_mod.Engine(0)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    g = e.dict_match(X)
+    fg = q[:, :, 2] > 0
+    want = dic["lut"][g["dm"] - 1]
+    assert np.array_equal(g["qmap"][fg], want[fg])
+    # the matched atom is the nearest grid atom of the phantom's (T1, T2), as the synthesis chose it
+    i1 = np.abs(np.log(t1g)[None, :] - np.log(np.maximum(q[:, :, 0][fg], 1e-9))[:, None]).argmin(1)
+    near = np.abs(g["qmap"][:, :, 0][fg] - t1g[i1].astype(np.float32))
+    assert np.mean(near < 1e-6) > 0.98                             # (nearest in linear, not log, distance differs for a few)
+    # PD: a single-precision chain of 1000 fmaf (<= 1000 x 2^-24 relative); where a neighbouring, nearly parallel atom wins within that
+    # rounding, PD moves by the ratio of the two normD
+    rel = np.abs(np.abs(g["pd"][fg]) - q[:, :, 2][fg]) / q[:, :, 2][fg]
+    assert np.mean(rel < 2e-4) > 0.98 and np.median(rel) < 2e-5
+    # device-resident entry point (buffers from the HIP runtime libqmri itself uses): same bits as the host-buffer call
+    import ctypes as C
+    path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+    hip = C.CDLL(path)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    npix = 224 * 224
+    xb = np.ascontiguousarray(X.astype(np.complex128).reshape((npix, T), order="F").ravel(order="F"))
+    dm, pd = np.empty(npix, np.int32), np.empty(2 * npix, np.float32)
+    d_x, d_dm, d_pd = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_x), xb.nbytes) == 0 and hip.hipMalloc(C.byref(d_dm), dm.nbytes) == 0 and hip.hipMalloc(C.byref(d_pd), pd.nbytes) == 0
+    assert hip.hipMemcpy(d_x, xb.ctypes.data_as(C.c_void_p), xb.nbytes, 1) == 0
+    e.dict_match_dev(d_x.value, npix, d_pd=d_pd.value, d_dm=d_dm.value)
+    e.synchronize()
+    assert hip.hipMemcpy(dm.ctypes.data_as(C.c_void_p), d_dm, dm.nbytes, 2) == 0 and hip.hipMemcpy(pd.ctypes.data_as(C.c_void_p), d_pd, pd.nbytes, 2) == 0
+    assert np.array_equal(dm.reshape((224, 224), order="F"), g["dm"])
+    assert np.array_equal(pd.view(np.complex64).reshape((224, 224), order="F"), g["pd"])
+    for d in (d_x, d_dm, d_pd):
+        hip.hipFree(d)
+    e.close()
+
+
+def test_xfit_narrow_dictionary(engine_mod, oracle, synth, case224):
+    """out.Xfit = ip(dm) .* D(dm,:) (par.f.Xout, mrf_dtm_cpu.m:95,129-134) for the compressed s = 10 dictionary, filter on and off,
+    atoms split over workgroups and not."""
+    rng = np.random.default_rng(5)
+    e = engine_mod.Engine(0)
+    for n1, n2 in ((37, 5), (256, 128)):
+        dic = synth.make_dictionary(T=200, n_t1=n1, n_t2=n2)
+        X = synth.synthesize_tsmi(case224["q"], dic)
+        X = X + 0.01 * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape))
+        e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+        o = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"], want_xfit=True)
+        for filt in (True, False):
+            e.dict_filter(filt)
+            g = e.dict_match(X, want_xfit=True)
+            _assert_same(g, o, ("dm", "mt", "pd", "qmap", "Xfit"))
+    e.dict_filter(True)
+    e.close()
