@@ -582,20 +582,15 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
                 o.xhat_valid = true;
                 return QMRI_OK;
             }
-            // the kernel's last act is a system-scope release of this solve's tag into the pinned state (no event packet in the stream: one
-            // costs 5.7 us of idle GPU): spin on it, with the stream's own end as the bound
-            {
-                bool seen = false;
-                for (long spin = 0; !seen; ++spin) {
-                    seen = true;
-                    for (int b = 0; b < B; ++b) seen = seen && (unsigned)__atomic_load_n(&hs[b].pad, __ATOMIC_ACQUIRE) == tag0;
-                    if (!seen && (spin & 1023) == 1023 && hipStreamQuery(ctx->stream) == hipSuccess) {      // everything has run: the word must be there
-                        seen = true;
-                        for (int b = 0; b < B; ++b) seen = seen && (unsigned)__atomic_load_n(&hs[b].pad, __ATOMIC_ACQUIRE) == tag0;
-                        if (!seen) { qmri_set_error(ctx, "the one-launch LSQR kernel ended without reporting its state"); return QMRI_ERR_HIP; }
-                    }
+            // Not deferred (qmri_xupdate): wait for the stream -- the kernels above are a few tens of microseconds, any HIP error ends the wait,
+            // and k_ks_final_w has then overridden the state if a workgroup of the one-launch kernel gave up.  (The ADMM loop never waits here:
+            // it reads its pinned slots after its own final synchronisation.)
+            QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int b = 0; b < B; ++b)
+                if ((unsigned)__atomic_load_n(&hs[b].pad, __ATOMIC_ACQUIRE) != tag0) {
+                    qmri_set_error(ctx, "the one-launch LSQR kernel ended without reporting its state");
+                    return QMRI_ERR_HIP;
                 }
-            }
             bool timed_out = false;
             for (int b = 0; b < B; ++b) timed_out = timed_out || hs[b].flag == 77;
             if (timed_out) {                                       // repeat with the two-launch iteration, from the untouched inputs
@@ -609,7 +604,9 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     int launched = 0;
     int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
     bool all_done = persisted;
-    while (!persisted && launched < maxit && !all_done) {
+    // (do ... while: with maxit == 0 the final kernels still run once and return x0 -- the assembled spectrum and the diagnostics' partial
+    //  sums must exist whatever the iteration count)
+    if (!persisted) do {
         const int nthis = std::min(chunk, maxit - launched);
         for (int k = 0; k < nthis; ++k) {
             ks.ii = launched + k + 1;
@@ -624,7 +621,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         all_done = true;
         for (int b = 0; b < B; ++b) all_done = all_done && hs[b].done;
         chunk = 2;
-    }
+    } while (launched < maxit && !all_done);
     std::swap(o.ks.xhat, o.ks.xhat_out);                                  // the assembled spectrum is the next solve's xhat0
     o.xhat_valid = true;
     int worst = 0;
@@ -676,6 +673,10 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
 extern "C" int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
     ctx->ks_persist = (on == 2) ? 2 : (on ? 1 : 0);               // (2: test hook -- one partial sum is withheld, the time-out path must take over)
+    if (ctx->d_ks_gran && ctx->op.ready) {                         // a fresh start: forget an earlier time-out (the sticky word behind the granules)
+        QMRI_HIP(ctx, hipSetDevice(ctx->device));
+        QMRI_HIP(ctx, hipMemsetAsync((char*)ctx->d_ks_gran + ks_gran_bytes(ctx->op.ks.G, ctx->op.maxB) - 64, 0, 64, ctx->stream));
+    }
     return QMRI_OK;
 }
 

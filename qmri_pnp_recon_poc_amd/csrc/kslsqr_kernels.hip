@@ -305,6 +305,7 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
             st->iter = fin ? 0 : ks.maxit;
             st->flag = fin ? 0 : 1;
             st->done = fin ? 1 : 0;
+            st->pad = 0;                                  // (77: a workgroup of k_ks_persist gave up on this solve)
             if (ks.hst) { LsqrState* h = ks.hst + b; h->iter = st->iter; h->flag = st->flag; h->done = st->done; }     // (visible to the host when the launch is over)
         }
         if (fin) return;
@@ -490,7 +491,7 @@ __device__ __forceinline__ void ks_tell_host(LsqrState* h, unsigned seq) {
     if (h) __hip_atomic_store(&h->pad, (int32_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop) {
+__global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop, int* sticky) {
     __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]   (k_ks_a)
     __shared__ double2 ulds[KS_ECAP];                      // u(1:m) of the unit's samples        (k_ks_b)
     __shared__ cd part[KS_GCAPB * DC_MAXS];
@@ -503,6 +504,9 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     constexpr int s = DC_MAXS;                             // (the launcher requires op.s == DC_MAXS, the reference's 10 channels: row pitches become constants)
     const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, G = ks.G;
     LsqrState* st = ks.st + b;
+    // (a spin of an EARLIER launch of this context timed out: nothing of this launch can be trusted to complete either -- requested here with
+    //  the other operands, looked at below)
+    const int stuck = __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const KsUnit un = ks.unit[g];
     const int s0 = un.s0, s1 = un.s1, nsl = s1 - s0, ne = nsl * s;
     const int e0 = un.e0, nsamp = un.e1 - e0;
@@ -534,6 +538,10 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     const double R = st->R, tolb = st->tolb, sr = ks.sr;
     if (st->done) {                                                 // x0 already exact, or b = 0 (uniform over the grid)
         if (g == 0 && tid == 0 && ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = st->flag; h->iter = st->iter; ks_tell_host(h, tag0); }
+        return;
+    }
+    if (stuck) {                                                    // (uniform over the grid: the word was set before this launch began)
+        if (g == 0 && tid == 0) { st->pad = 77; st->flag = 77; if (ks.hst) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; ks_tell_host(h, tag0); } }
         return;
     }
     if (tid < 64) {
@@ -717,6 +725,13 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
         PS(8);
     }
     if (aborted) {
+        // EVERY workgroup that gives up says so (device words: st->pad for k_ks_final_w, which runs after the whole grid and overrides whatever
+        // workgroup 0 told the host -- it may have seen the late partial sum and finished; `sticky` for this context's later launches): the
+        // unit's x was not stored, so a "done" from workgroup 0 alone would be a silent wrong answer
+        if (tid == 0) {
+            __hip_atomic_store(&st->pad, 77, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (writer) { st->flag = 77; if (ks.hst) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; ks_tell_host(h, tag0); } }
         return;
     }
@@ -750,6 +765,8 @@ __global__ __launch_bounds__(KT) void k_ks_final_w(OpDev op, KsDev ks, double2* 
     const int tid = threadIdx.x, kh = blockIdx.x, b = blockIdx.y, s = op.s, sM = s * M;
     const size_t n = (size_t)s * N * M;
     const double ue = ks.st[b].ue_final;
+    // a workgroup of the one-launch iteration gave up on this solve (k_ks_persist, `aborted`): the host must not believe any "done"
+    if (kh == 0 && tid == 0 && ks.hst && ks.st[b].pad == 77) { LsqrState* h = ks.hst + b; h->flag = 77; h->done = 0; h->iter = 0; }
     double rv[NVQ];
     load_v(op, rv);
     // ---- request everything (clamped, not predicated): the slots first, then the compact x / the two spectra
@@ -924,12 +941,13 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, vo
     if ((long)ks.G * B > ctx->ks_persist_cap) return QMRI_OK;
     KsGran* gu = (KsGran*)gran;
     KsGran* gv = gu + (size_t)B * 4 * ks.G;
-    k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0);
+    int* sticky = (int*)(gu + (size_t)ctx->op.maxB * 6 * ks.G);                         // (the word behind the granules: ks_gran_bytes)
+    k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0, sticky);
     QMRI_HIP(ctx, hipGetLastError());
     *ran = true;
     return QMRI_OK;
 }
-size_t ks_gran_bytes(int G, int B) { return (size_t)B * 6 * G * sizeof(KsGran); }
+size_t ks_gran_bytes(int G, int B) { return (size_t)B * 6 * G * sizeof(KsGran) + 64; }     // + the sticky time-out word
 
 int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp) {
     switch (op.N) {

@@ -119,6 +119,37 @@ def test_lsqr_one_launch_time_out_falls_back_to_two_launch_iteration(engine_mod,
     e.close()
 
 
+def test_admm_recovers_from_a_one_launch_time_out(engine_mod, synth, case224, capfd):
+    """The same recovery on the route the reconstruction takes: qmri_pnp_admm never waits inside its loop and reads the LSQR state of all
+    iterations after its final synchronisation.  With the test hook the first x-update's kernel times out (every workgroup that gives up says
+    so on the device, k_ks_final_w tells the host whatever workgroup 0 believed, and the later launches of the call return at once instead of
+    spinning to their own time-outs); the call then repeats itself on the two-launch iteration: same x and LSQR counts as a run that never
+    used the one-launch kernel, the message once, and a call that is not slow."""
+    import time
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, case224["dic"]["V"], case224["fp"], case224["k"])
+    e.set_denoiser(synth.structured_weights(seed=2, eps=0.02), 224, 224)
+    y = case224["y"]
+    e.lsqr_persist(False)
+    xb, _, lb = e.pnp_admm(y, iters=6)
+    e.lsqr_persist(2)
+    t0 = time.perf_counter()
+    xa, _, la = e.pnp_admm(y, iters=6)
+    dt = time.perf_counter() - t0
+    err = capfd.readouterr().err
+    assert err.count("timed out") == 1
+    assert np.array_equal(la, lb) and np.array_equal(xa, xb)
+    assert dt < 3.0, dt                                               # (one time-out of 0.1-0.3 s, not one per ADMM iteration)
+    # maxit = 0 (accepted by the argument checks): no LSQR iteration, the final kernels still run, x = x0
+    op = case224["op"]
+    x0 = op.adjoint(y)
+    for persist in (True, False):
+        e.lsqr_persist(persist)
+        x1, it1, fl1 = e.xupdate(y, 0.9 * x0, 0.05, 1e-4, 0, x0, solver="lsqr")
+        assert it1 == 0 and fl1 == 1 and rel_err(x1, x0) < 1e-12
+    e.close()
+
+
 def test_lsqr_xupdate_vs_oracle(eng, case224):
     op, y = case224["op"], case224["y"]
     x0 = op.adjoint(y)
