@@ -61,3 +61,25 @@ def atom_tolerance(K: int) -> float:
     The match itself is bit-exact for equal X; near-ties between neighbouring atoms grow with the density of the (T1, T2) grid, so the
     bound is K-aware: 0.99 at K = 8 192 (measured 0.997), 0.88 at K = 98 304 (measured 0.963).  Same formula as bench.py's."""
     return max(0.85, 1.0 - 0.01 * K / 8192.0)
+
+
+def assert_atoms_close(mg, mo, dic, what=""):
+    """Two reconstructions that agree to ~2e-5 (GPU vs oracle) through the same bit-exact match: at least atom_tolerance(K) of the pixels on
+    the identical atom, and a differing pixel sits on a NEIGHBOUR of the (T1, T2) grid (atom index = i_t1 * n_t2 + i_t2) -- every one at most
+    2 grid steps away in either direction, one step or less on average (T1 / T2 mean absolute error on the differing pixels <= one grid step)."""
+    import numpy as np
+    K, n2 = int(dic["K"]), int(dic["t2_grid"].size)
+    same = mg["dm"] == mo["dm"]
+    frac = float(np.mean(same))
+    msg = f"{what}: identical atoms {frac:.4f} at K = {K}"
+    if not same.all():
+        ig, ic = mg["dm"][~same].astype(np.int64) - 1, mo["dm"][~same].astype(np.int64) - 1
+        d1, d2 = np.abs(ig // n2 - ic // n2), np.abs(ig % n2 - ic % n2)
+        msg += f"; differing pixels: T1 steps mean {d1.mean():.2f} max {int(d1.max())}, T2 steps mean {d2.mean():.2f} max {int(d2.max())}"
+        print(msg)
+        assert max(int(d1.max()), int(d2.max())) <= 2, msg
+        assert d1.mean() <= 1.0 and d2.mean() <= 1.0, msg
+    else:
+        print(msg)
+    assert frac > atom_tolerance(K), msg
+    return frac

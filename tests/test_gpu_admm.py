@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import atom_tolerance, rel_err
+from conftest import assert_atoms_close, atom_tolerance, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -244,9 +244,7 @@ def test_cut0_T1000_admm_and_match_at_bench_K(engine_mod, oracle, synth):
     mx = oracle.dict_match(xg, dic["D"], dic["normD"], dic["lut"])
     assert np.array_equal(mg["dm"], mx["dm"]) and np.array_equal(mg["qmap"], mx["qmap"]) and np.array_equal(mg["pd"], mx["pd"])
     mo = oracle.dict_match(xo, dic["D"], dic["normD"], dic["lut"])
-    same = float(np.mean(mg["dm"] == mo["dm"]))
-    print(f"cut0: identical atoms between the two reconstructions {same:.4f} at K = {dic['K']}")
-    assert same > atom_tolerance(dic["K"])
+    assert_atoms_close(mg, mo, dic, "cut0")                           # fraction AND distance of the differing pixels on the (T1, T2) grid
     e.close()
 
 
@@ -304,6 +302,7 @@ def test_admm_224_full_length_100_iterations(engine_mod, oracle, synth, case224,
     assert err < 1e-3
     assert psnr > 70.0
     assert same > atom_tolerance(dic["K"])                              # K-aware (0.99 at this K = 8 192; see conftest.atom_tolerance)
+    assert_atoms_close(mg, mo, dic, config)                             # ... and every differing pixel on a neighbouring atom of the grid
     assert pd_err < 1e-3
     assert frac_counts > 0.7 and maxdiff <= 2
     # same X in -> bit-exact maps out (the match itself is bit-exact; the differences above come from x)

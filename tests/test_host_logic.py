@@ -165,3 +165,50 @@ def test_oracle_under_address_and_ub_sanitizer(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ASAN_RUN_OK True" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_product_host_code_under_address_and_ub_sanitizer(tmp_path):
+    """The PRODUCT's host code under AddressSanitizer + UBSan: `make asan-host` compiles every source file of libqmri host-only (no device
+    code, so it runs here) with -fsanitize=address,undefined, and tests/cpp/host_asan_driver.cpp drives the mask builders, the weight
+    packers of every layer kind in both splitting schemes, qmri_net_nparams, the refusals of every entry point without a context or device,
+    and the ONNX reader -- an untrusted file -- on a well-formed export and on ~150 truncated / bit-flipped / spliced ones.  Any report
+    fails the test.  (Kernels are covered by the parity tests on the GPU; device sanitizers are not available on the pool.)"""
+    import onnx_writer as ow
+    from qmri_pnp_recon_poc_amd import synth
+    csrc = os.path.join(ROOT, "qmri_pnp_recon_poc_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-s", "-j4", "asan-host"], check=True)
+    rt_dirs = [d for d in sorted(os.listdir("/opt/rocm/lib/llvm/lib/clang")) if os.path.isdir(os.path.join("/opt/rocm/lib/llvm/lib/clang", d, "lib", "linux"))]
+    if not rt_dirs:
+        pytest.skip("clang sanitizer runtime not found")
+    rt = os.path.join("/opt/rocm/lib/llvm/lib/clang", rt_dirs[-1], "lib", "linux")
+    in_nc, out_nc, nc, nb = 10, 10, (8, 16, 16, 32), 2
+    blob = synth.random_weights(in_nc=in_nc, out_nc=out_nc, nc=nc, nb=nb, seed=5)
+    good = ow.unetres_model(ow.split_blob(blob, in_nc, out_nc, nc, nb), in_nc, out_nc, nc, nb)
+    files = [tmp_path / "good.onnx"]
+    files[0].write_bytes(good)
+    rng = np.random.default_rng(4)
+    n = len(good)
+    variants = []
+    for cut in sorted(set([0, 1, 2, 3, 7, 8, 15, 16, 31, 64, 100, n // 4, n // 2, n - 100, n - 9, n - 2, n - 1] + [int(v) for v in rng.integers(1, n, 40)])):
+        variants.append(good[:cut])                                            # truncations, also inside varints and length prefixes
+    header = min(n, 4096)                                                       # (field tags, lengths, dims live near the front and around the nodes)
+    for _ in range(60):
+        b = bytearray(good)
+        for pos in rng.integers(0, header if rng.random() < 0.7 else n, int(rng.integers(1, 4))):
+            b[int(pos)] ^= 1 << int(rng.integers(0, 8))
+        variants.append(bytes(b))
+    for _ in range(30):                                                         # lengths blown up, pieces spliced and repeated
+        a, c = sorted(int(v) for v in rng.integers(0, n, 2))
+        variants.append(good[:a] + bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x0F]) + good[c:])
+        variants.append(good[:c] + good[a:])
+    for i, v in enumerate(variants):
+        p = tmp_path / f"bad_{i:03d}.onnx"
+        p.write_bytes(v)
+        files.append(p)
+    env = dict(os.environ, LD_LIBRARY_PATH=rt + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=77:allocator_may_return_null=1:max_allocation_size_mb=4096",
+               UBSAN_OPTIONS="halt_on_error=1:exitcode=78:print_stacktrace=1")
+    r = subprocess.run([os.path.join(csrc, "_build_asan", "host_asan_driver")] + [str(f) for f in files], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "HOST_ASAN_DRIVER_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-6000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
+    print(r.stdout.strip().splitlines()[-2:])
