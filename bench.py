@@ -50,6 +50,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 / f16 ma
 # tile, every fragment read from LDS, one wave per SIMD on all 256 CUs): 1325-1345 TFLOP/s at 1.75-1.92 GHz (tools/ubench/mfma_shape_f16.hip,
 # profiles/r03_h_ubench_mfma_shape_f16.txt; bare MFMAs without LDS reads: 22.1 ns each = 1518, profiles/r01_g_ubench_mfma_f16x3_loop.txt)
 SUSTAINED_MFMA_TFLOPS = 1335.0
+SUSTAINED_MFMA_TFLOPS_BARE = 1518.3   # ... bare MFMAs, no LDS reads (the figure `frac_of_sustained` used up to round 2; both are reported so rounds stay comparable)
 BF16X6 = os.environ.get("QMRI_CONV_SCHEME", "") == "bf16x6"
 SPLIT_PRODUCTS = 6 if BF16X6 else 3   # MFMA products per fp32-equivalent product (conv6_kernels.hip: bf16 x 6 / f16 x 3)
 SCHEME_TEXT = ("v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate" if BF16X6 else
@@ -77,6 +78,10 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=0, help="ADMM iterations of the CPU sample (0: as many of --steps as fit --cpu-budget-s)")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="wall-clock bound of the all-threads CPU sample")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-slices", action="store_true", help="workload=admm: skip the `slices` object (north_star's second metric: a fixed 120-slice batch, "
+                    "100 ADMM iterations + dictionary match at K = 98 304 per slice, sharded over the ranks; ~10 s on one GPU)")
+    ap.add_argument("--slices-total", type=int, default=120, help="... its slice count")
+    ap.add_argument("--slices-iters", type=int, default=100, help="... ADMM iterations per slice (PnP_ADMM.m: param.iter = 100)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo + --one-device: rehearsal of the "
                     "multi-rank path on a single-GPU box; the ranks then share device 0, so the value is not a scaling result)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
@@ -194,6 +199,128 @@ def atom_tolerance(K: int) -> float:
     return max(0.85, 1.0 - 0.01 * K / 8192.0)
 
 
+def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, iters, warmup_iters, dict_grid=(384, 256)):
+    """north_star metric 2: a FIXED batch of `total` slices (120 = 8 subjects x 15, BASELINE configs[3]) sharded over the ranks in contiguous
+    blocks; each rank walks its block in launches of `batch` slices (k_conv6p, batched LSQR), every slice = `iters` PnP-ADMM iterations + the
+    dictionary match at K = dict_grid product.  Inputs resident in HBM, barrier + synchronize on both sides, max over ranks.  Returns the
+    object that goes into the JSON line (rank 0: with the roofline of the batched conv kernel and of the dictionary match)."""
+    import ctypes as C
+    from qmri_pnp_recon_poc_amd import engine as E, synth
+    from qmri_pnp_recon_poc_amd._lib import AdmmParams
+    from qmri_pnp_recon_poc_amd.batch import shard_slices
+    N, T, s, S = 224, 200, 10, 771
+    B = batch
+    dic = synth.make_dictionary(T=T, n_t1=dict_grid[0], n_t2=dict_grid[1], s=s)
+    fp, k = E.build_spiral(N, S, T)
+    weights = synth.structured_weights(seed=2, eps=0.02)
+    eng = E.Engine(local_rank)
+    eng.set_operator(N, N, dic["V"], fp, k, max_batch=B)
+    eng.set_denoiser(weights, N, N, max_batch=B)
+    eng.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    stream = torch.cuda.Stream()                               # a torch stream the engine launches on: torch events then see its kernels
+    eng.set_stream(stream.cuda_stream)
+    mine = shard_slices(total, world, rank)
+    nsl = len(mine)
+    n, m = N * N * s, eng.m
+
+    def make_y(seed):
+        X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=seed), dic)
+        return synth.awgn_measured(eng.forward(X0), 30.0, seed=seed)
+
+    ys = np.stack([make_y(i) for i in mine]) if nsl else np.zeros((0, m), np.complex128)
+    d_y = torch.from_numpy(np.ascontiguousarray(ys).view(np.float64)).to(dev)
+    d_x = torch.empty((B, 2 * n), dtype=torch.float64, device=dev)
+    d_q = torch.empty(N * N * 2, dtype=torch.float32, device=dev)
+    d_pd = torch.empty(N * N * 2, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def params(it):
+        return AdmmParams(0.05, it, 1e-4, 100, 0 if args.solver == "lsqr" else 1, 0, 0.01, 0)
+
+    def match(i):
+        eng._check(eng.L.qmri_dict_match_dev(eng.h, C.c_void_p(d_x.data_ptr() + i * n * 16), N * N, C.c_void_p(d_q.data_ptr()),
+                                             C.c_void_p(d_pd.data_ptr()), None, None))
+
+    def run(count, it):
+        p = params(it)
+        for s0 in range(0, count, B):
+            cnt = min(B, count - s0)
+            eng._check(eng.L.qmri_pnp_admm_dev(eng.h, cnt, C.c_void_p(d_y.data_ptr() + s0 * m * 16), C.byref(p), None, None,
+                                               C.c_void_p(d_x.data_ptr()), None, None))
+            for i in range(cnt):
+                match(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    if nsl:
+        run(min(B, nsl), max(warmup_iters, 1))
+    barrier()
+    t0 = time.perf_counter()
+    run(nsl, iters)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = None
+    if rank == 0:
+        K = int(dic["K"])
+        out = {"metric": f"slices/sec ({total}-slice synthetic batch: {iters} ADMM iterations + dictionary match per slice)", "value": round(total / dt, 4),
+               "unit": "slices/s", "n_gpus": world, "scaling": "strong", "seconds": round(dt, 3), "ms_per_slice": round(dt / max(nsl, 1) * 1e3, 3),
+               "slices_on_rank0": nsl, "total_slices": total, "batch": B, "admm_iters_per_slice": iters, "dict_K": K,
+               "sharding": "fixed total, contiguous blocks (batch.shard_slices), no collective in the data path",
+               "workload": f"cut3 {total}-slice batch over {world} GPU(s), {B} slices advanced together, spiral mask, PnP-ADMM + UNetRes + dictionary match K={K}"}
+        if not args.no_roofline and nsl:
+            # the batched conv kernel (k_conv6p): live dispatch durations of three forwards of B slices
+            eng.profile_get(reset=True)
+            eng.profile_enable(2)
+            d_in = torch.rand(B * s * N * N, dtype=torch.float32, device=dev)
+            d_out = torch.empty(B * s * N * N, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                eng._check(eng.L.qmri_net_forward_dev(eng.h, C.c_void_p(d_in.data_ptr()), B, C.c_void_p(d_out.data_ptr())))
+            eng.synchronize()
+            pr = eng.profile_get(reset=True)
+            eng.profile_enable(0)
+            if pr["n_conv3x3"] > 0:
+                avg_s = pr["ms_conv3x3"] / pr["n_conv3x3"] * 1e-3
+                ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
+                traffic, tsrc = load_traffic(B)
+                out["roofline"] = {"kernel": f"k_conv6p (persistent implicit-GEMM conv3x3, {B} slices per launch, on {SCHEME_TEXT})", "bound": "mfma",
+                                   "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                                   "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
+                                   "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B, "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3),
+                                   "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4)}
+            # the dictionary match of one reconstructed slice (d_x[0] holds the last batch's first slice), HIP events on the engine's stream
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    match(0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(20):
+                    match(0)
+                e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            pairs = ((K + 31) // 32) * ((N * N + 31) // 32)
+            exec_f16 = pairs * 6 * 32 * 32 * 16 * 2               # filter: 6 x v_mfma_f32_32x32x16_f16 per (32-atom, 32-pixel) tile pair
+            alg = 2 * 2 * N * N * K * s
+            out["dict_match"] = {"ms_per_slice": round(ms, 4), "K": K,
+                                 "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TFLOPS, "achieved": round(exec_f16 / (ms * 1e-3) / 1e12, 1),
+                                              "frac": round(exec_f16 / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "executed_flop": exec_f16, "traffic": None,
+                                              "note": "against the pipe it uses: executed f16-MFMA flops of the filter (K-padding 10 -> 16 included; the exact f32 products "
+                                                      "of the ~1 % listed tiles not counted) / time; maps bit-identical to the oracle's",
+                                              "algorithmic_f32_tflops": round(alg / (ms * 1e-3) / 1e12, 1),
+                                              "algorithmic_over_f32_mfma_peak": round(alg / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3)}}
+    eng.close()
+    return out
+
+
 def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,6 +343,8 @@ def worker(args):
             dist.barrier()
         dt = time.perf_counter() - t0
         from qmri_pnp_recon_poc_amd.batch import shard_slices
+        if args.workload == "admm" and not args.no_slices:          # the default line's `slices` object shards args.slices_total the same way
+            args.total_slices = args.slices_total
         mine = shard_slices(args.total_slices, world, rank) if args.total_slices > 0 else list(range(rank * args.slices_per_gpu, (rank + 1) * args.slices_per_gpu))
         cover = torch.zeros(max(args.total_slices, args.slices_per_gpu * world), dtype=torch.int64)
         cover[mine] += 1                                          # every slice id must be owned by exactly one rank
@@ -410,7 +539,9 @@ def worker(args):
                         "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3), "fp32_equivalent_flop_per_launch": CONV3X3_FLOP * B,
                         # what the chip sustains on toggling operands at its power limit (see SUSTAINED_MFMA_TFLOPS) -- not the roofline peak,
                         # reported beside it
-                        "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4)}
+                        "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4),
+                        "sustained_mfma_tflops_bare_mfma_loop": SUSTAINED_MFMA_TFLOPS_BARE,
+                        "frac_of_sustained_bare_mfma_loop": round(ach / SUSTAINED_MFMA_TFLOPS_BARE, 4)}
         # stage split of one more run of the SAME workload (profile level 1 synchronises per stage; not part of the timed region): all
         # args.steps iterations, because the x-update is not uniform over a reconstruction -- LSQR needs 16 iterations in the first
         # x-updates and 5-8 in the later ones (lsqr_iters_mean)
@@ -480,6 +611,10 @@ def worker(args):
         if args.workload == "admm" and n_cpu <= len(li):
             parity["lsqr_iteration_counts_identical"] = bool(np.array_equal(li[:n_cpu], lio[:n_cpu]))
 
+    # ---- north_star's second metric in the same line: the fixed 120-slice batch over all ranks -----------------------------
+    slices_obj = None
+    if args.workload == "admm" and not args.no_slices and args.slices_total > 0:
+        slices_obj = slices_phase(args, rank, local_rank, world, dev, torch, dist, args.slices_total, args.batch, args.slices_iters, 2)
     if rank == 0:
         strong = args.workload == "slices" and args.total_slices > 0
         if args.workload == "admm":
@@ -501,6 +636,8 @@ def worker(args):
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu, "parity": parity}
         out.update(result_extra)
+        if slices_obj is not None:
+            out["slices"] = slices_obj
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -65,20 +65,24 @@ def atom_tolerance(K: int) -> float:
 
 def assert_atoms_close(mg, mo, dic, what=""):
     """Two reconstructions that agree to ~2e-5 (GPU vs oracle) through the same bit-exact match: at least atom_tolerance(K) of the pixels on
-    the identical atom, and a differing pixel sits on a NEIGHBOUR of the (T1, T2) grid (atom index = i_t1 * n_t2 + i_t2) -- every one at most
-    2 grid steps away in either direction, one step or less on average (T1 / T2 mean absolute error on the differing pixels <= one grid step)."""
+    the identical atom, and a differing pixel sits on a NEIGHBOUR of the (T1, T2) grid (atom index = i_t1 * n_t2 + i_t2).  The distance is
+    stated in steps of the 128 x 64 grid of the K = 8 192 test dictionary (log-spaced over the same T1 / T2 ranges at every K): every differing
+    pixel at most 2 such steps away in either direction and at most one on average -- i.e. 2 (1) x n_t1 / 128 steps in T1 and x n_t2 / 64 in
+    T2 on a denser grid (K = 98 304 = 384 x 256: 6 and 8), where neighbouring atoms are that much closer in correlation."""
     import numpy as np
-    K, n2 = int(dic["K"]), int(dic["t2_grid"].size)
+    K, n1, n2 = int(dic["K"]), int(dic["t1_grid"].size), int(dic["t2_grid"].size)
+    s1, s2 = max(1.0, n1 / 128.0), max(1.0, n2 / 64.0)
     same = mg["dm"] == mo["dm"]
     frac = float(np.mean(same))
     msg = f"{what}: identical atoms {frac:.4f} at K = {K}"
     if not same.all():
         ig, ic = mg["dm"][~same].astype(np.int64) - 1, mo["dm"][~same].astype(np.int64) - 1
         d1, d2 = np.abs(ig // n2 - ic // n2), np.abs(ig % n2 - ic % n2)
-        msg += f"; differing pixels: T1 steps mean {d1.mean():.2f} max {int(d1.max())}, T2 steps mean {d2.mean():.2f} max {int(d2.max())}"
+        msg += (f"; differing pixels: T1 steps mean {d1.mean():.2f} max {int(d1.max())} (bounds {s1:.0f}, {2 * s1:.0f}), "
+                f"T2 steps mean {d2.mean():.2f} max {int(d2.max())} (bounds {s2:.0f}, {2 * s2:.0f})")
         print(msg)
-        assert max(int(d1.max()), int(d2.max())) <= 2, msg
-        assert d1.mean() <= 1.0 and d2.mean() <= 1.0, msg
+        assert d1.max() <= 2 * s1 and d2.max() <= 2 * s2, msg
+        assert d1.mean() <= s1 and d2.mean() <= s2, msg
     else:
         print(msg)
     assert frac > atom_tolerance(K), msg

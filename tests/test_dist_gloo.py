@@ -57,7 +57,7 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     assert out["n_gpus"] == 2 and out["plumbing_only"] is True and out["steps"] == 3
     assert out["max_rank_seconds"] >= 0.02                 # the slower rank (rank 1 sleeps 20 ms) sets the time
     # north_star's slices workload: a FIXED total of 120 slices sharded over the ranks (the same job at every N), 15 at a time per GPU
-    for n, on0, batches in ((1, 120, 8), (2, 60, 4), (3, 40, 3)):
+    for n, on0, batches in ((1, 120, 8), (2, 60, 4), (3, 40, 3), (8, 15, 1)):     # (8: one batch of 15 per GPU, BASELINE configs[3])
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--plumbing-only", "--workload", "slices",
                             "--total-slices", "120", "--batch", "15"], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr

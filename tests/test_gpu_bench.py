@@ -21,14 +21,24 @@ def _run(args, timeout=900):
 
 def test_bench_two_ranks_without_a_launcher():
     """`bench.py --gpus 2` alone: two worker processes (here both on device 0 over gloo: one-GPU box), one line, n_gpus 2."""
-    out = _run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "4", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"])
+    out = _run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "4", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
+                "--slices-total", "5", "--slices-iters", "2", "--batch", "2"])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
     assert out["scaling"] == "weak" and out["config"]["parallelism"].startswith("slice-parallel x2")
+    sl = out["slices"]                                               # the fixed total sharded over the two ranks: 3 + 2
+    assert sl["n_gpus"] == 2 and sl["total_slices"] == 5 and sl["slices_on_rank0"] == 3 and sl["value"] > 0 and sl["scaling"] == "strong"
 
 
 def test_bench_line_has_roofline_cpu_baseline_and_parity():
-    out = _run(["--steps", "6", "--warmup", "2", "--cpu-iters", "6"])
+    out = _run(["--steps", "6", "--warmup", "2", "--cpu-iters", "6", "--slices-total", "6", "--slices-iters", "3", "--batch", "3"])
     assert out["n_gpus"] == 1 and out["unit"] == "ADMM iters/s" and out["dtype"] == "f32"
+    # north_star's second metric rides in the same line (default: 120 slices x 100 iterations; here 6 x 3): slices/s, the batched conv
+    # kernel's roofline and the dictionary match against the f16 pipe it runs on (a fraction <= 1)
+    sl = out["slices"]
+    assert sl["unit"] == "slices/s" and sl["value"] > 0 and sl["total_slices"] == 6 and sl["batch"] == 3 and sl["dict_K"] == 98304
+    assert sl["roofline"]["bound"] == "mfma" and 0 < sl["roofline"]["frac"] < 1 and "k_conv6p" in sl["roofline"]["kernel"]
+    dmr = sl["dict_match"]["roofline"]
+    assert 0 < dmr["frac"] < 1 and dmr["peak"] == 2500.0 and sl["dict_match"]["ms_per_slice"] > 0
     rf, cb, pa = out["roofline"], out["cpu_baseline"], out["parity"]
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["one_thread_value"] > 0 and cb["cpu_model"]
