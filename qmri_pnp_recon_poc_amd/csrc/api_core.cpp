@@ -542,8 +542,11 @@ int qmri_prepare_direct(qmri_ctx* ctx, double r) {
 // when the one-launch kernel runs, the call returns WITHOUT waiting (*deferred = true, iters_out / flag_out untouched): the kernel leaves
 // iter / done / flag in hslot, to be read after the caller's next synchronisation (state 77 there = the kernel timed out: the caller repeats
 // its work with ctx->ks_persist = 0).  The ADMM loop uses this so that the host never waits inside a reconstruction.
+// fuse (round 4, nullable): what the ADMM loop has already done in neighbouring launches, or wants done in this solve's last one --
+// z_hpass_nblk > 0: o.d_tmp holds the h-pass of z's transform and ls.pz that many partial sums of |z|^2 per slice (k_dual_fwd_h), d_z is not read;
+// mm_u / mm: the final h-pass also leaves the partial min / max of real(x + mm_u) per workgroup in mm (k_adj_h).
 int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
-                  int32_t* iters_out, int32_t* flag_out, double* pdiag, LsqrState* hslot, bool* deferred) {
+                  int32_t* iters_out, int32_t* flag_out, double* pdiag, LsqrState* hslot, bool* deferred, const LsqrFuse* fuse) {
     OpHost& o = ctx->op;
     const OpDev op = qmri_opdev(ctx);
     KsDev ks = o.ks;
@@ -551,9 +554,14 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     LsqrState* const hs = hslot ? hslot : o.h_state;
     ks.hst = hs;
     if (deferred) *deferred = false;
+    const bool z_fused = fuse && fuse->z_hpass_nblk > 0;
+    const double2* const mm_u = fuse ? fuse->mm_u : nullptr;
+    double* const mm = fuse ? fuse->mm : nullptr;
+    if (z_fused && !o.xhat_valid) { qmri_set_error(ctx, "qmri_lsqr_run: a transformed z needs the spectrum of x (internal)"); return QMRI_ERR_STATE; }
     if (!o.xhat_valid) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_x, o.d_tmp, ks.xhat, nullptr));
-    QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_z, o.d_tmp, ks.zhat, nullptr));
-    QMRI_TRY(ks_launch_init(ctx, op, ks, B));
+    if (z_fused) ks.nblk_z = fuse->z_hpass_nblk;
+    else QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_FWD_H_ONLY, B, d_z, o.d_tmp, nullptr, nullptr));
+    QMRI_TRY(ks_launch_init(ctx, op, ks, B, o.d_tmp));                  // w-pass of z (-> ks.zhat) + first Golub-Kahan vectors
     // The predicted number of iterations is launched, then -- speculatively -- the kernels that turn the solution back into
     // an image.  The host waits only for the copy of the LSQR state (an event between the two), so the device keeps working
     // while the host wakes up and enqueues the next stage.  If a slice was not done yet (rare: counts fall from one x-update
@@ -575,7 +583,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         if (persisted) {
             ctx->ks_tag += 2u * (unsigned)(maxit + 2);
             QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));
-            QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
+            QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x, mm_u, mm));
             if (deferred) {                                        // the caller reads hslot after its own synchronisation
                 *deferred = true;
                 std::swap(o.ks.xhat, o.ks.xhat_out);
@@ -616,7 +624,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
         // (no copy of the state: k_ks_b writes iter / done / flag of every slice to the pinned host array itself, ks.hst)
         QMRI_HIP(ctx, hipEventRecord(ctx->ev_state, ctx->stream));
         QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));              // reads ks.xhat (x0), writes ks.xhat_out
-        QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x));
+        QMRI_TRY(dc_launch_adj_h(ctx, op, B, o.d_tmp, d_x, mm_u, mm));
         QMRI_HIP(ctx, hipEventSynchronize(ctx->ev_state));
         all_done = true;
         for (int b = 0; b < B; ++b) all_done = all_done && hs[b].done;
@@ -652,7 +660,7 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
         QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, n * sizeof(double2), ctx->stream));
         QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, 1, o.d_z, o.d_u, o.d_vv));
         o.xhat_valid = false;
-        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out, nullptr, nullptr, nullptr));
+        QMRI_TRY(qmri_lsqr_run(ctx, 1, o.d_vv, r, tol, maxit, o.d_x, iters_out, flag_out, nullptr, nullptr, nullptr, nullptr));
     } else if (solver == QMRI_SOLVER_DIRECT) {
         QMRI_TRY(qmri_prepare_direct(ctx, r));
         QMRI_TRY(dc_launch_adj(ctx, op, 1, o.d_ya, o.d_tmp, o.d_xa));

@@ -14,7 +14,7 @@
 void qmri_free_operator(qmri_ctx* ctx);
 int qmri_prepare_direct(qmri_ctx* ctx, double r);
 int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol, int maxit, double2* d_x,
-                  int32_t* iters_out, int32_t* flag_out, double* pdiag, LsqrState* hslot, bool* deferred);
+                  int32_t* iters_out, int32_t* flag_out, double* pdiag, LsqrState* hslot, bool* deferred, const LsqrFuse* fuse);
 
 // ---------------------------------------------------------------------------------------------------
 // denoiser
@@ -548,15 +548,27 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         QMRI_HIP(ctx, hipHostMalloc((void**)&o.h_ring, cap * sizeof(LsqrState), hipHostMallocDefault));
         o.h_ring_cap = cap;
     }
+    // Round 4: the small launches around the network are folded into their neighbours (LSQR solver; QMRI_FUSE_EW=0 restores the separate kernels
+    // for A/Bs): un-normalise + dual update + z + the h-pass of z's transform + the forward pass's |output| report = ONE launch (k_dual_fwd_h);
+    // the w-pass of z rides in the solve's first kernel (k_ks_init_a<FWDW>); the min / max of real(x + u) come out of the solve's last h-pass.
+    static const bool fuse_ew = !(getenv("QMRI_FUSE_EW") && atoi(getenv("QMRI_FUSE_EW")) == 0);
+    static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;
+    const bool fused = fuse_ew && prm->solver == QMRI_SOLVER_LSQR;
+    const int hb = dc_hpass_blocks(op);
+    bool z_in_tmp = false;                                 // o.d_tmp holds the h-pass of z (and ls.pz hb partial sums per slice)
+    struct DeferGuard { NetPlan& n; ~DeferGuard() { n.act_defer = false; n.act_pending_valid = false; } } defer_guard{net};
+    net.act_defer = fused && !graph_replay;
     for (int it = 0; it < prm->iters; ++it) {
         // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
         tm.start();
         if (it == 0) QMRI_TRY(dc_launch_prepare_z(ctx, op, o.ls, B, o.d_vv, o.d_u, o.d_z));   // later: fused into the dual update
         if (prm->solver == QMRI_SOLVER_LSQR) {
             bool deferred = false;
+            LsqrFuse lf;
+            if (fused) { lf.z_hpass_nblk = z_in_tmp ? hb : 0; lf.mm_u = o.d_u; lf.mm = o.d_mm; }
             QMRI_TRY(qmri_lsqr_run(ctx, B, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, o.d_x, it_b.data(), nullptr,
                                    diag ? o.d_pd : nullptr,            // (the data-fidelity partials come with the solve)
-                                   o.h_ring + (size_t)it * B, &deferred));
+                                   o.h_ring + (size_t)it * B, &deferred, &lf));
             deferred_it[it] = deferred ? 1 : 0;
             if (!deferred && lsqr_iters_out) for (int b = 0; b < B; ++b) lsqr_iters_out[(size_t)b * prm->iters + it] = it_b[b];
             // The range guard of earlier forwards is on the host (pinned words written by k_act_check).  After a wait inside qmri_lsqr_run (the
@@ -577,7 +589,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         // Step 2 (PnP_ADMM.m:115-138): v = real(x+uold) -> [0,1] -> net -> undo
         tm.start();
         QMRI_TRY(ew_launch_minmax_normalise(ctx, B, n, (int)plane, o.N, o.s, multi, prm->noise_std, o.d_x, o.d_u, o.d_mm, o.d_norm,
-                                            o.ls.nblk_z, net.in32));
+                                            fused ? hb : o.ls.nblk_z, net.in32, fused /* the partial min / max came with the solve's last h-pass */));
         tm.stop(ctx->prof.ms_elementwise);
         tm.start();
         QMRI_TRY(net_forward(ctx, B));
@@ -588,8 +600,17 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         tm.stop(ctx->prof.ms_denoiser);
         // Step 3 (PnP_ADMM.m:138,144): v = I*range + min ; uold = uold + x - v
         tm.start();
-        QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u,
-                                            nullptr /* v itself is never read again: z = v - u goes to the next x-update */, o.d_z, o.ls.pz, o.ls.nblk_z));
+        if (fused) {
+            const DualArgs da = {net.out32.base1(), net.in32.base1(), net.out32.hp, (int)net.out32.plane(), net.out32.batch_stride(), net.in32.batch_stride(),
+                                 net.desc.residual_noise, o.d_norm, o.d_x, o.d_u, o.ls.pz};
+            ActCheckArgs ac{};
+            if (net.act_pending_valid) { ac = net.act_pending; net.act_pending_valid = false; }
+            QMRI_TRY(dc_launch_dual_fwd_h(ctx, op, B, da, ac, o.d_tmp));
+            z_in_tmp = true;
+        } else {
+            QMRI_TRY(ew_launch_unnormalise_dual(ctx, B, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, o.d_x, o.d_u,
+                                                nullptr /* v itself is never read again: z = v - u goes to the next x-update */, o.d_z, o.ls.pz, o.ls.nblk_z));
+        }
         tm.stop(ctx->prof.ms_elementwise);
         ctx->prof.admm_iters += 1;
     }

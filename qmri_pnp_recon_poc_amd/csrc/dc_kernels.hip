@@ -18,6 +18,7 @@
 //
 // Layouts: x [c][w][h] complex (MATLAB N x M x s); tmp [c][kh][w]; every per-slice array is slice-major.
 #include "dc_device.h"
+#include "conv6_act.h"
 
 using namespace dcdev;
 
@@ -46,6 +47,56 @@ __global__ __launch_bounds__(NT) void k_fwd_h(OpDev op, const double2* __restric
         double2* dst = tmp + (size_t)b * n + (size_t)c * N * op.M + w;
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + (size_t)(k1 + R1 * k2) * op.M, out[k2]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The step between the denoiser and the next x-update in ONE launch (PnP_ADMM.m:138,144 -> :102):
+//   v = double(I) * range + min ;  uold = uold + x - v ;  z = v - uold, with the partial sums of ||z||^2 -- and at once the h-pass of z's
+// transform (k_fwd_h): a workgroup's 16 lines of z go from registers to LDS instead of to memory and back.  z itself is never stored
+// (only the solve reads it, as a spectrum).  Its first workgroups also finish the per-layer |output| report of the forward pass that
+// has just ended (conv6_act.h) -- the launch of k_act_check saved.
+// ---------------------------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ __launch_bounds__(NT) void k_dual_fwd_h(OpDev op, DualArgs d, ActCheckArgs ac, double2* __restrict__ tmp) {
+    typedef Plan<R1, R2> P;
+    constexpr int N = P::N, L = Cfg<R1, R2>::L;
+    __shared__ cd lds[L * P::LINE];
+    __shared__ double red[NT / 64];
+    __shared__ float redf[4];
+    const int tid = threadIdx.x, b = blockIdx.y, M = op.M;
+    if (b == 0) for (int layer = blockIdx.x; layer < ac.nlayers; layer += gridDim.x) act_check_layer(ac, layer, redf);     // (uniform per workgroup)
+    const size_t n = (size_t)op.s * N * M;
+    const size_t base = (size_t)b * n + (size_t)blockIdx.x * L * N;
+    const double lo = d.norm[2 * b], range = d.norm[2 * b + 1];
+    double acc = 0.0;
+    for (int i = tid; i < L * N; i += NT) {
+        const int line = i / N, h = i - line * N;
+        const int l = blockIdx.x * L + line;
+        const int c = l / M, w = l - c * M;
+        const size_t pi = (size_t)c * d.pplane + (size_t)(w + 1) * d.php + h + 1;
+        float I = d.out32[(size_t)b * d.out_bs + pi];
+        if (d.residual_noise) I = d.in32[(size_t)b * d.in_bs + pi] - I;
+        const double vv = (double)I * range + lo;                   // undo_norm_zero_to_one  :138,187-192
+        const double2 xv = d.x[base + i];
+        double2 uv = d.u[base + i];
+        uv.x = uv.x + xv.x - vv;                                    // uold = uold + x - v  :144
+        uv.y = uv.y + xv.y - 0.0;
+        st_wt(d.u + base + i, uv);
+        const double2 zz = make_double2(vv - uv.x, 0.0 - uv.y);     // z = v - uold  :102
+        lds[line * P::LINE + h] = zz;
+        acc += zz.x * zz.x + zz.y * zz.y;
+    }
+    const double tot = block_sum(acc, red);
+    if (tid == 0) d.pz[(size_t)b * gridDim.x + blockIdx.x] = tot;
+    cd out[R2];
+    int line2, k1;
+    if (fft_lds<R1, R2, true>(lds, L, op.tw, out, line2, k1)) {
+        const int l = blockIdx.x * L + line2;
+        const int c = l / M, w = l - c * M;
+        double2* dst = tmp + (size_t)b * n + (size_t)c * N * M + w;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + (size_t)(k1 + R1 * k2) * M, out[k2]);
     }
 }
 
@@ -242,11 +293,15 @@ __global__ __launch_bounds__(NT) void k_adj_w(OpDev op, const double2* __restric
 // adjoint, pass 2: inverse FFT along h of L lines (c, w0..w0+L), un-conjugate, scale by 1/sqrt(NM)
 //   (= ifft2(.)*sqrt(NM)), and the fused LSQR updates of v, d, x.
 // ---------------------------------------------------------------------------------------------------
+// u / mm (nullable): the ADMM loop's next step needs min / max of real(x + uold) over the whole stack (PnP_ADMM.m:115-121,174-184); the
+// workgroup that produces x adds its lines' u and leaves its partial min / max in mm[b][blockIdx.x][2] -- the launch of k_minmax saved.
 template <int R1, int R2>
-__global__ __launch_bounds__(NT) void k_adj_h(OpDev op, const double2* __restrict__ tmp, double2* __restrict__ dst) {
+__global__ __launch_bounds__(NT) void k_adj_h(OpDev op, const double2* __restrict__ tmp, double2* __restrict__ dst,
+                                               const double2* __restrict__ u, double* __restrict__ mm) {
     typedef Plan<R1, R2> P;
     constexpr int N = P::N, L = Cfg<R1, R2>::L;
     __shared__ cd lds[L * P::LINE];
+    __shared__ double shm[2 * NT / 64];
     const int tid = threadIdx.x, b = blockIdx.y, M = op.M;
     const size_t n = (size_t)op.s * N * M;
     const int l0 = blockIdx.x * L;
@@ -258,11 +313,34 @@ __global__ __launch_bounds__(NT) void k_adj_h(OpDev op, const double2* __restric
     }
     cd out[R2];
     int line2, k1;
+    double lo = INFINITY, hi = -INFINITY;
     if (fft_lds<R1, R2, false>(lds, L, op.tw, out, line2, k1)) {
         const double sc = 1.0 / sqrt((double)N * (double)M);
         const size_t g0 = (size_t)b * n + (size_t)(l0 + line2) * N;
+        double ur[R2];
+        if (u) {
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) st_wt(dst + g0 + k1 + R1 * k2, make_double2(out[k2].x * sc, -out[k2].y * sc));
+            for (int k2 = 0; k2 < R2; ++k2) ur[k2] = u[g0 + k1 + R1 * k2].x;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const double2 xv = make_double2(out[k2].x * sc, -out[k2].y * sc);
+            st_wt(dst + g0 + k1 + R1 * k2, xv);
+            if (u) { const double v = xv.x + ur[k2]; lo = fmin(lo, v); hi = fmax(hi, v); }
+        }
+    }
+    if (u) {                                                        // (uniform)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off, 64)); hi = fmax(hi, __shfl_down(hi, off, 64)); }
+        const int wid = tid >> 6, lane = tid & 63;
+        if (lane == 0) { shm[2 * wid] = lo; shm[2 * wid + 1] = hi; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 1; i < NT / 64; ++i) { lo = fmin(lo, shm[2 * i]); hi = fmax(hi, shm[2 * i + 1]); }
+            mm[((size_t)b * gridDim.x + blockIdx.x) * 2] = lo;
+            mm[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = hi;
+        }
     }
 }
 
@@ -329,12 +407,13 @@ int launch_fwd_t(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, in
 }
 
 template <int R1, int R2>
-int launch_adj_t(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst, bool skip_w) {
+int launch_adj_t(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst, bool skip_w,
+                 const double2* u = nullptr, double* mm = nullptr) {
     constexpr int L = Cfg<R1, R2>::L;
     dim3 gh(op.s * op.M / L, B), gw(op.N, B), blk(NT);
     hipStream_t st = ctx->stream;
     if (!skip_w) k_adj_w<R1, R2><<<gw, blk, 0, st>>>(op, y_in, tmp);
-    k_adj_h<R1, R2><<<gh, blk, 0, st>>>(op, tmp, dst);
+    k_adj_h<R1, R2><<<gh, blk, 0, st>>>(op, tmp, dst, u, mm);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -367,10 +446,35 @@ int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, do
 #undef CALL_A
 }
 
-int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, double2* dst) {
-#define CALL_H(a, b) launch_adj_t<a, b>(ctx, op, B, nullptr, const_cast<double2*>(tmp), dst, true)
+int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, double2* dst, const double2* u, double* mm) {
+#define CALL_H(a, b) launch_adj_t<a, b>(ctx, op, B, nullptr, const_cast<double2*>(tmp), dst, true, u, mm)
     DC_DISPATCH(op.N, CALL_H)
 #undef CALL_H
+}
+
+// workgroups of the h-pass kernels per slice (= partial sums of |z|^2 of k_dual_fwd_h, partial min / max of k_adj_h)
+int dc_hpass_blocks(const OpDev& op) {
+    switch (op.N) {
+        case 224: return op.s * op.M / Cfg<16, 14>::L;
+        case 128: return op.s * op.M / Cfg<16, 8>::L;
+        case 64: return op.s * op.M / Cfg<8, 8>::L;
+        default: return op.s * op.M / Cfg<8, 4>::L;
+    }
+}
+
+template <int R1, int R2>
+static int launch_dual_t(qmri_ctx* ctx, const OpDev& op, int B, const DualArgs& d, const ActCheckArgs& ac, double2* tmp) {
+    constexpr int L = Cfg<R1, R2>::L;
+    k_dual_fwd_h<R1, R2><<<dim3(op.s * op.M / L, B), dim3(NT), 0, ctx->stream>>>(op, d, ac, tmp);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
+// unnormalise + dual update + z = v - u + h-pass of z's transform into tmp (+ the forward pass's |output| report): see k_dual_fwd_h
+int dc_launch_dual_fwd_h(qmri_ctx* ctx, const OpDev& op, int B, const DualArgs& d, const ActCheckArgs& ac, double2* tmp) {
+#define CALL_U(a, b) launch_dual_t<a, b>(ctx, op, B, d, ac, tmp)
+    DC_DISPATCH(op.N, CALL_U)
+#undef CALL_U
 }
 
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,

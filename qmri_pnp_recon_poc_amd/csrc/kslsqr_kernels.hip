@@ -60,14 +60,19 @@ __device__ __forceinline__ void store_v(const OpDev& op, const double* rv, doubl
 // ---------------------------------------------------------------------------------------------------------------
 // k_ks_init_a : one block per k-row kh.  xhat0 / zhat rows -> compact x, u(m+1:end) on the sampled k; R on the rest;
 // u(1:m) = y - P xhat0 for the row's samples.
+// FWDW: the row of zhat is not read but MADE here -- the w-pass of z's transform (k_fwd_w<DC_SPECTRUM>: FFT along w of the row's s channel
+// lines of tmp, the h-pass output) runs in the same launch, the row goes to registers and to ks.zhat (k_ks_final_w reads it): one launch and
+// one round trip of zhat less per x-update.  The FFT buffer and the xhat0 lines share one piece of LDS.
 // ---------------------------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks) {
+template <int R1, int R2, bool FWDW>
+__global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks, const double2* __restrict__ tmp) {
+    typedef Plan<R1, R2> P;
+    constexpr int N = P::N;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = N;                                   // square grids only (checked by qmri_set_operator)
     const int tid = threadIdx.x, kh = blockIdx.x, b = blockIdx.y, s = op.s, sM = s * M;
-    cd* lines = (cd*)smem;                                 // [c][kw] xhat0 of the row
-    double* vlds = (double*)(lines + sM);
+    cd* lines = (cd*)smem;                                 // [c][kw] xhat0 of the row  (FWDW: first the FFT buffer, [c][P::LINE])
+    double* vlds = (double*)(lines + (FWDW ? DC_MAXS * P::LINE : sM));
     __shared__ double red[3 * KT / 64];
     const size_t n = (size_t)s * N * M;
     const double sr = ks.sr;
@@ -80,7 +85,8 @@ __global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks) {
         const int i = (tid + KT * q < sM) ? tid + KT * q : sM - 1;
         const int c = i / M, kw = i - c * M;
         const size_t g = (size_t)b * n + ((size_t)c * N + kh) * M + kw;
-        xv[q] = ks.xhat[g]; zv[q] = ks.zhat[g];
+        xv[q] = ks.xhat[g];
+        zv[q] = FWDW ? tmp[g] : ks.zhat[g];                // (FWDW: the h-pass output, same [c][kh][w] layout)
         slot[q] = op.kslot[kh * M + kw];
     }
     const int r0 = op.kptr[kh * M], r1 = op.kptr[(kh + 1) * M];
@@ -94,6 +100,35 @@ __global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks) {
     }
     double rv[NVQ];
     load_v(op, rv);
+    if constexpr (FWDW) {
+        // w-pass of the row (k_fwd_w<DC_SPECTRUM>'s arithmetic: same codelets, same scaling), then this thread's elements back into zv
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + KT * q;
+            if (i < sM) { const int c = i / M; lines[c * P::LINE + (i - c * M)] = zv[q]; }
+        }
+        cd out[R2];
+        int line2, k1;
+        const bool act = fft_lds<R1, R2, false>(lines, s, op.tw, out, line2, k1);
+        lds_barrier();
+        if (act) {
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) lines[line2 * P::LINE + k1 + R1 * k2] = out[k2];
+        }
+        lds_barrier();
+        const double sc = 1.0 / sqrt((double)N * (double)M);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + KT * q;
+            if (i < sM) {
+                const int c = i / M, kw = i - c * M;
+                const cd z = lines[c * P::LINE + kw];
+                zv[q] = make_double2(z.x * sc, z.y * sc);
+                st_wt(ks.zhat + (size_t)b * n + ((size_t)c * N + kh) * M + kw, zv[q]);
+            }
+        }
+        lds_barrier();                                     // (the buffer becomes the xhat0 lines below)
+    }
     double accS = 0.0, accR = 0.0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -857,11 +892,11 @@ int launch_final_t(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, doubl
 template <int N, int R1, int R2>
 int lds_fits_t(qmri_ctx* ctx, int s, int M, int vcap, bool* ok) {
     const size_t vb = (size_t)vcap * 8;
-    const void* fns[5] = {(const void*)k_ks_init_a<N>, (const void*)k_ks_a, (const void*)k_ks_b<true>, (const void*)k_ks_b<false>,
-                          (const void*)k_ks_final_w<R1, R2>};
-    const size_t need[5] = {(size_t)s * M * 16 + vb, vb, vb, vb, vb};
+    const void* fns[6] = {(const void*)k_ks_init_a<R1, R2, false>, (const void*)k_ks_a, (const void*)k_ks_b<true>, (const void*)k_ks_b<false>,
+                          (const void*)k_ks_final_w<R1, R2>, (const void*)k_ks_init_a<R1, R2, true>};
+    const size_t need[6] = {(size_t)s * M * 16 + vb, vb, vb, vb, vb, (size_t)DC_MAXS * Plan<R1, R2>::LINE * 16 + vb};
     *ok = true;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         size_t dyn = 0;
         QMRI_TRY(allow_big_lds(ctx, fns[i], &dyn));
         if (need[i] > dyn) *ok = false;
@@ -883,10 +918,10 @@ int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok) {
 
 static int ks_attrs(qmri_ctx* ctx) {
     if (ctx->ks_lds_attr[0]) return QMRI_OK;
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<224>));
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<128>));
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<64>));
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<32>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 14, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 14, true>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 8, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 8, true>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 8, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 8, true>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 4, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 4, true>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_a));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<true>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<false>));
@@ -895,16 +930,22 @@ static int ks_attrs(qmri_ctx* ctx) {
 }
 
 // residual + first Golub-Kahan vectors; ks.xhat / ks.zhat hold the unitary spectra of x0 and z
-int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
+// hpass_tmp (nullable): the h-pass output of z's transform; the launch then also runs the w-pass and writes ks.zhat (k_ks_init_a<FWDW>)
+int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp) {
     QMRI_TRY(ks_attrs(ctx));
     const size_t vb = (size_t)ks.vcap * 8;
-    const size_t ib = (size_t)op.s * op.M * 16 + vb;
+#define KS_INIT(R1_, R2_)                                                                                                       \
+    do {                                                                                                                        \
+        if (hpass_tmp) k_ks_init_a<R1_, R2_, true><<<dim3(op.N, B), dim3(KT), (size_t)DC_MAXS * Plan<R1_, R2_>::LINE * 16 + vb, ctx->stream>>>(op, ks, hpass_tmp); \
+        else k_ks_init_a<R1_, R2_, false><<<dim3(op.N, B), dim3(KT), (size_t)op.s * op.M * 16 + vb, ctx->stream>>>(op, ks, nullptr);                              \
+    } while (0)
     switch (op.N) {
-        case 224: k_ks_init_a<224><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
-        case 128: k_ks_init_a<128><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
-        case 64: k_ks_init_a<64><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
-        default: k_ks_init_a<32><<<dim3(op.N, B), dim3(KT), ib, ctx->stream>>>(op, ks); break;
+        case 224: KS_INIT(16, 14); break;
+        case 128: KS_INIT(16, 8); break;
+        case 64: KS_INIT(8, 8); break;
+        default: KS_INIT(8, 4); break;
     }
+#undef KS_INIT
     k_ks_b<true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;

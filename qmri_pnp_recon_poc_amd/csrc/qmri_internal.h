@@ -157,6 +157,9 @@ struct PTensor {
     size_t batch_stride() const { return (size_t)Cal * plane(); }
 };
 
+// per-layer reduction of the |output| reports of a forward pass (conv6_act.h); nlayers = 0: nothing to do
+struct ActCheckArgs { const float* slots; int* count; float* ref; int record; unsigned* range_flag; unsigned* host_words; int nlayers; };
+
 struct NetPlan {
     qmri_net_desc desc{};
     int H = 0, W = 0, maxB = 0;
@@ -181,6 +184,9 @@ struct NetPlan {
     float* d_act_ref = nullptr;         // ... the magnitude of every layer under the set-up probe (calibrated reference)
     int act_cap = 0;                    // rows of the three arrays (= layers)
     bool act_on = false, act_record = false;   // a reporting forward pass is under way; it is the calibration probe
+    // the PnP-ADMM loop lets the kernel after the forward pass finish the per-layer |output| report (conv6_act.h) instead of launching k_act_check
+    bool act_defer = false, act_pending_valid = false;
+    ActCheckArgs act_pending{};
     int sp6 = 2;                     // scheme the layers are packed for
     bool blk_ok = false;             // the network's interior tensors may be BLOCKED (PTensor::blk): every layer runs on the conv6 kernels, channels % 8 == 0
     int interior_fmt = -1;           // format the interior tensors were last written in (-1: untouched zeros, 0 planar, 1 blocked): a change re-zeroes them (halo)
@@ -283,9 +289,19 @@ bool dc_size_supported(int N);
 int dc_launch_fwd(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int mode, int B, const double2* src, double2* tmp,
                   double2* y_out, double* pdiag);
 int dc_launch_adj(qmri_ctx* ctx, const OpDev& op, int B, const double2* y_in, double2* tmp, double2* dst);
-int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, double2* dst);   // inverse h-pass only
+int dc_launch_adj_h(qmri_ctx* ctx, const OpDev& op, int B, const double2* tmp, double2* dst, const double2* u = nullptr,
+                    double* mm = nullptr);   // inverse h-pass only (+ partial min / max of real(dst + u) per workgroup)
+// the step between the denoiser and the next x-update in one launch (dc_kernels.hip, k_dual_fwd_h)
+struct DualArgs {
+    const float* out32; const float* in32; int php, pplane; size_t out_bs, in_bs; int residual_noise;
+    const double* norm; const double2* x; double2* u; double* pz;
+};
+int dc_hpass_blocks(const OpDev& op);
+// what the ADMM loop fuses into the launches around a solve (qmri_lsqr_run)
+struct LsqrFuse { int z_hpass_nblk = 0; const double2* mm_u = nullptr; double* mm = nullptr; };
+int dc_launch_dual_fwd_h(qmri_ctx* ctx, const OpDev& op, int B, const DualArgs& d, const ActCheckArgs& ac, double2* tmp);
 // k-space LSQR (kslsqr_kernels.hip)
-int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
+int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp = nullptr);
 int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
 int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);
 int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran);   // all iterations in one launch
@@ -300,7 +316,7 @@ int dc_launch_prepare_z(qmri_ctx* ctx, const OpDev& op, const LsqrDev& ls, int B
                         double2* z);
 // elementwise ADMM stages (PnP_ADMM.m:115-121,138,144)
 int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H, int s, int multi_level, double noise_std,
-                               const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32);
+                               const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32, bool mm_ready = false);
 int ew_launch_unnormalise_dual(qmri_ctx* ctx, int B, size_t n, int plane, int H, const PTensor& out32, const PTensor& in32,
                                int residual_noise, const double* norm, const double2* x, double2* u, double2* v, double2* z,
                                double* pz, int nblk_z);   // also z = v - u and the partials of ||z||^2 for the next x-update

@@ -7,7 +7,7 @@ for spec in "$@"; do
   lib=${spec##* }; envs=${spec% *}; [ "$envs" = "$spec" ] && envs=""
   [ "$lib" = "-" ] && libenv="" || libenv="QMRI_LIBQMRI=$lib"
     echo "== $spec (run $rep)" >> $OUT
-    env $envs $libenv python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+    env $envs $libenv python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-slices 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
