@@ -71,13 +71,25 @@ __global__ __launch_bounds__(NT) void k_minmax(size_t n, const double2* __restri
     }
 }
 
-// pass 2: reduce the partials (min/max are order independent), normalise, cast to single, append noise map
+// pass 2: reduce the partials (min/max are order independent), normalise, cast to single, append noise map.
+// The workgroup's share of x and u is requested BEFORE the partials are reduced (the loads do not depend on min / max): one memory latency
+// for the launch instead of two plus one per loop iteration; shares beyond NRQ * NT elements per workgroup fall back to the plain loop.
+constexpr int NRQ = 16;
 __global__ __launch_bounds__(NT) void k_normalise(size_t n, int plane, int H, int s, int multi_level, double noise_std,
                                                    const double2* __restrict__ x, const double2* __restrict__ u,
                                                    const double* __restrict__ mm, int nblk, double* __restrict__ norm,
                                                    float* __restrict__ in32, int php, int pplane, size_t pbs) {
     __shared__ double sh[2 * NT / 64];
     const int b = blockIdx.y;
+    const size_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const size_t i0 = (size_t)blockIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    double xr[NRQ], ur[NRQ];
+#pragma unroll
+    for (int q = 0; q < NRQ; ++q) {
+        const size_t i = i0 + threadIdx.x + (size_t)NT * q;
+        const size_t ic = (i < i1) ? i : i0;
+        xr[q] = x[(size_t)b * n + ic].x; ur[q] = u[(size_t)b * n + ic].x;
+    }
     double lo = INFINITY, hi = -INFINITY;
     for (int i = threadIdx.x; i < nblk; i += NT) {
         lo = fmin(lo, mm[((size_t)b * nblk + i) * 2]);
@@ -86,15 +98,18 @@ __global__ __launch_bounds__(NT) void k_normalise(size_t n, int plane, int H, in
     block_minmax(lo, hi, sh);
     const double range = hi - lo;                       // no zero-range guard, as PnP_ADMM.m:174-184
     if (blockIdx.x == 0 && threadIdx.x == 0) { norm[2 * b] = lo; norm[2 * b + 1] = range; }
-    const size_t chunk = (n + gridDim.x - 1) / gridDim.x;
-    const size_t i0 = (size_t)blockIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
     float* dst = in32 + (size_t)b * pbs;                 // padded planes [c][w+1][h+1], zero halo untouched
-    for (size_t i = i0 + threadIdx.x; i < i1; i += NT) {
-        const double v = x[(size_t)b * n + i].x + u[(size_t)b * n + i].x;
+    auto put = [&](size_t i, double v) __attribute__((always_inline)) {
         const int c = (int)(i / plane), rem = (int)(i - (size_t)c * plane);
         const int w = rem / H, h = rem - w * H;
         dst[(size_t)c * pplane + (size_t)(w + 1) * php + h + 1] = (float)((v - lo) / range);
+    };
+#pragma unroll
+    for (int q = 0; q < NRQ; ++q) {
+        const size_t i = i0 + threadIdx.x + (size_t)NT * q;
+        if (i < i1) put(i, xr[q] + ur[q]);
     }
+    for (size_t i = i0 + threadIdx.x + (size_t)NT * NRQ; i < i1; i += NT) put(i, x[(size_t)b * n + i].x + u[(size_t)b * n + i].x);
     if (multi_level) {
         const int per = (plane + gridDim.x - 1) / gridDim.x;
         const int c0 = blockIdx.x * per, c1 = (c0 + per < plane) ? c0 + per : plane;
