@@ -23,6 +23,7 @@ ap.add_argument("--s", type=int, default=10)
 ap.add_argument("--n-t1", type=int, default=384)
 ap.add_argument("--n-t2", type=int, default=256)
 ap.add_argument("--reps", type=int, default=0)
+ap.add_argument("--dev-reps", type=int, default=0, help="device-resident matches timed (default 5 wide / 20 narrow)")
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--cpu-pixels", type=int, default=1024, help="s > 16: pixels of the slice the CPU oracle is timed on")
 args = ap.parse_args()
@@ -73,17 +74,26 @@ def dev_ms(reps):
     return e0.elapsed_time(e1) / reps
 
 
-ms_f = dev_ms(5 if wide else 20)
+ms_f = dev_ms(args.dev_reps or (5 if wide else 20))
 assert np.array_equal(o_dm.cpu().numpy(), m["dm"].ravel(order="C"))
 out = {"metric": f"dictionary match slices/sec (224x224x{s} TSMI, K atoms)", "value": round(1.0 / dt, 3), "unit": "slices/s", "K": K, "npix": npix, "s": s,
        "ms_per_slice": round(dt * 1e3, 3), "flop_per_slice": flop,
        "entry_point": f"qmri_dict_match (host buffers: {X.nbytes / 1e6:.0f} MB in, 1.4 MB out)",
        "f32_mfma_peak_tflops": F32_MFMA_PEAK_TFLOPS}
 if wide:
+    traffic, tsrc = None, None
+    try:                                                     # bytes leaving the L2s per launch, from the committed PMC passes of this size
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "dictw_traffic.json")) as f:
+            tj = json.load(f)
+        if (tj["s"], tj["K"], tj["npix"]) == (s, K, npix):
+            traffic, tsrc = tj["corrected_bytes_per_launch"], tj["source"] + "; " + tj["note"]
+    except (OSError, KeyError, ValueError):
+        pass
     out["device_resident"] = {"ms_per_slice": round(ms_f, 3),
                               "what": "qmri_dict_match_dev, HIP events over 5 matches: k_dictw_pack_x (single(x) into fragment order) + k_dictw_match + k_dict_merge"}
     out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS, "achieved": round(flop / (ms_f * 1e-3) / 1e12, 1),
-                       "frac": round(flop / (ms_f * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3), "traffic": None,
+                       "frac": round(flop / (ms_f * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3), "traffic": traffic, "traffic_source": tsrc,
+                       "algorithmic_bytes": 4 * (K * s + 2 * npix * s) + 16 * npix,
                        "note": "algorithmic = executed flops 2*2*Npix*K*s of the single-precision product mrf_dtm_cpu.m:91 on v_mfma_f32_32x32x2_f32 (channels "
                                "padded to 16: + 0.8 % executed at s = 1000) against the f32 MFMA peak; whole match incl. the X conversion and the merge"}
 else:

@@ -1,3 +1,4 @@
+#!/bin/bash
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
