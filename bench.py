@@ -229,26 +229,39 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
 
     ys = np.stack([make_y(i) for i in mine]) if nsl else np.zeros((0, m), np.complex128)
     d_y = torch.from_numpy(np.ascontiguousarray(ys).view(np.float64)).to(dev)
-    d_x = torch.empty((B, 2 * n), dtype=torch.float64, device=dev)
-    d_q = torch.empty(N * N * 2, dtype=torch.float32, device=dev)
-    d_pd = torch.empty(N * N * 2, dtype=torch.float32, device=dev)
+    # results of a launch (x and the maps of its B slices) are copied back to pinned host memory on a copy stream while the next launch
+    # computes ("results copied back per slice"; what qmri_recon_batch does): two sets of buffers in rotation
+    cstream = torch.cuda.Stream()
+    d_x = [torch.empty((B, 2 * n), dtype=torch.float64, device=dev) for _ in range(2)]
+    d_q = [torch.empty((B, N * N * 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_pd = [torch.empty((B, N * N * 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    h_x = [torch.empty((B, 2 * n), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+    h_q = [torch.empty((B, N * N * 2), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    h_pd = [torch.empty((B, N * N * 2), dtype=torch.float32, pin_memory=True) for _ in range(2)]
     torch.cuda.synchronize()
 
     def params(it):
         return AdmmParams(0.05, it, 1e-4, 100, 0 if args.solver == "lsqr" else 1, 0, 0.01, 0)
 
-    def match(i):
-        eng._check(eng.L.qmri_dict_match_dev(eng.h, C.c_void_p(d_x.data_ptr() + i * n * 16), N * N, C.c_void_p(d_q.data_ptr()),
-                                             C.c_void_p(d_pd.data_ptr()), None, None))
+    def match(j, i):
+        eng._check(eng.L.qmri_dict_match_dev(eng.h, C.c_void_p(d_x[j].data_ptr() + i * n * 16), N * N, C.c_void_p(d_q[j].data_ptr() + i * N * N * 8),
+                                             C.c_void_p(d_pd[j].data_ptr() + i * N * N * 8), None, None))
 
     def run(count, it):
         p = params(it)
-        for s0 in range(0, count, B):
-            cnt = min(B, count - s0)
+        for bi, s0 in enumerate(range(0, count, B)):
+            j, cnt = bi & 1, min(B, count - s0)
             eng._check(eng.L.qmri_pnp_admm_dev(eng.h, cnt, C.c_void_p(d_y.data_ptr() + s0 * m * 16), C.byref(p), None, None,
-                                               C.c_void_p(d_x.data_ptr()), None, None))
+                                               C.c_void_p(d_x[j].data_ptr()), None, None))
             for i in range(cnt):
-                match(i)
+                match(j, i)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            cstream.wait_event(ev)
+            with torch.cuda.stream(cstream):
+                h_x[j][:cnt].copy_(d_x[j][:cnt], non_blocking=True)
+                h_q[j][:cnt].copy_(d_q[j][:cnt], non_blocking=True)
+                h_pd[j][:cnt].copy_(d_pd[j][:cnt], non_blocking=True)
 
     def barrier():
         if world > 1:
@@ -274,6 +287,7 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
                "unit": "slices/s", "n_gpus": world, "scaling": "strong", "seconds": round(dt, 3), "ms_per_slice": round(dt / max(nsl, 1) * 1e3, 3),
                "slices_on_rank0": nsl, "total_slices": total, "batch": B, "admm_iters_per_slice": iters, "dict_K": K,
                "sharding": "fixed total, contiguous blocks (batch.shard_slices), no collective in the data path",
+               "results": "x (8 MB) and the T1 / T2 / PD maps of every slice copied to pinned host memory inside the timed region (copy stream, overlapped)",
                "workload": f"cut3 {total}-slice batch over {world} GPU(s), {B} slices advanced together, spiral mask, PnP-ADMM + UNetRes + dictionary match K={K}"}
         if not args.no_roofline and nsl:
             # the batched conv kernel (k_conv6p): live dispatch durations of three forwards of B slices
@@ -296,14 +310,14 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
                                    "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
                                    "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B, "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3),
                                    "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4)}
-            # the dictionary match of one reconstructed slice (d_x[0] holds the last batch's first slice), HIP events on the engine's stream
+            # the dictionary match of one reconstructed slice (d_x[0][0]: the first slice of an earlier launch), HIP events on the engine's stream
             with torch.cuda.stream(stream):
                 for _ in range(3):
-                    match(0)
+                    match(0, 0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 for _ in range(20):
-                    match(0)
+                    match(0, 0)
                 e1.record(stream)
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20

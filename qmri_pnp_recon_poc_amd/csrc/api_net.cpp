@@ -836,6 +836,11 @@ extern "C" int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qm
 // slice batches over several GPUs: one host thread + one context per device, static round-robin of launches
 // (slices are independent, no collective)
 // ---------------------------------------------------------------------------------------------------
+// Round 4: the worker no longer waits for its copies.  Every launch (slices_per_launch slices) has one of two sets of device and PINNED host
+// buffers.  After the reconstruction of launch k (qmri_pnp_admm_dev returns synchronised) the dictionary matches of its slices are queued on the
+// compute stream and the results (x, maps) are copied to the pinned set on a COPY stream behind an event; the host then moves the PREVIOUS launch's
+// results from its pinned set into the caller's (pageable) arrays while the device works, and goes on to launch k + 1, whose kernels overlap the
+// copies of launch k.  Before: pageable hipMemcpy of 8 MB per slice plus a synchronise and two small copies per slice, all in series with the compute.
 static int recon_worker(int device, int widx, int nworkers, int nslices, const qmri_problem* pb, const char* Y, char* X_out,
                         float* qmap_out, float* pd_out, std::string* err) {
     qmri_ctx* ctx = nullptr;
@@ -844,35 +849,74 @@ static int recon_worker(int device, int widx, int nworkers, int nslices, const q
     const int spl = std::max(1, pb->slices_per_launch);
     const size_t n = (size_t)pb->N * pb->M * pb->s, npix = (size_t)pb->N * pb->M;
     const int m = pb->frame_ptr[pb->T];
-    double2 *dY = nullptr, *dX = nullptr;
-    float *dq = nullptr, *dp = nullptr;
+    const int Q = std::max(pb->Q, 1);
+    const bool maps = pb->K > 0 && (qmap_out || pd_out);
+    const size_t by = (size_t)spl * m * sizeof(double2), bx = (size_t)spl * n * sizeof(double2);
+    const size_t bq = (size_t)spl * npix * Q * sizeof(float), bp = (size_t)spl * npix * 2 * sizeof(float);
+    struct Set { double2 *dY = nullptr, *dX = nullptr; float *dq = nullptr, *dp = nullptr; char *hY = nullptr, *hX = nullptr; float *hq = nullptr, *hp = nullptr;
+                 hipEvent_t matched = nullptr, copied = nullptr; int s0 = -1, cnt = 0; } set[2];
+    hipStream_t cs = nullptr;
     auto bail = [&](int code) { *err = qmri_last_error(ctx); return code; };
+    auto hipfail = [&](const char* what) { *err = std::string(what) + " failed in qmri_recon_batch"; st = QMRI_ERR_HIP; };
+    // launch held by set `S` -> the caller's arrays (its copies have been queued; wait for them, then plain host copies)
+    auto drain = [&](Set& S) {
+        if (S.s0 < 0) return;
+        if (hipEventSynchronize(S.copied) != hipSuccess) { hipfail("hipEventSynchronize"); return; }
+        std::memcpy(X_out + (size_t)S.s0 * n * sizeof(double2), S.hX, (size_t)S.cnt * n * sizeof(double2));
+        if (maps && qmap_out) std::memcpy(qmap_out + (size_t)S.s0 * npix * pb->Q, S.hq, (size_t)S.cnt * npix * pb->Q * sizeof(float));
+        if (maps && pd_out) std::memcpy(pd_out + (size_t)S.s0 * npix * 2, S.hp, (size_t)S.cnt * npix * 2 * sizeof(float));
+        S.s0 = -1;
+    };
     do {
         if ((st = qmri_set_operator(ctx, pb->N, pb->M, pb->s, pb->T, pb->V, pb->frame_ptr, pb->kidx, spl)) != QMRI_OK) { bail(st); break; }
         if ((st = qmri_set_denoiser(ctx, pb->net, pb->weights, pb->weights_nbytes, pb->N, pb->M, spl)) != QMRI_OK) { bail(st); break; }
         if (pb->K > 0 && (st = qmri_set_dictionary(ctx, pb->K, pb->s, pb->Q, pb->D, pb->normD, pb->lut)) != QMRI_OK) { bail(st); break; }
-        if (hipMalloc((void**)&dY, (size_t)spl * m * sizeof(double2)) != hipSuccess || hipMalloc((void**)&dX, (size_t)spl * n * sizeof(double2)) != hipSuccess ||
-            hipMalloc((void**)&dq, npix * std::max(pb->Q, 1) * sizeof(float)) != hipSuccess || hipMalloc((void**)&dp, npix * 2 * sizeof(float)) != hipSuccess) {
-            *err = "hipMalloc failed in qmri_recon_batch"; st = QMRI_ERR_NOMEM; break;
+        bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+        for (int j = 0; j < 2 && ok; ++j) {
+            Set& S = set[j];
+            ok = hipMalloc((void**)&S.dY, by) == hipSuccess && hipMalloc((void**)&S.dX, bx) == hipSuccess && hipHostMalloc((void**)&S.hY, by, hipHostMallocDefault) == hipSuccess &&
+                 hipHostMalloc((void**)&S.hX, bx, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&S.matched, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&S.copied, hipEventDisableTiming) == hipSuccess;
+            if (ok && maps) ok = hipMalloc((void**)&S.dq, bq) == hipSuccess && hipMalloc((void**)&S.dp, bp) == hipSuccess &&
+                                 hipHostMalloc((void**)&S.hq, bq, hipHostMallocDefault) == hipSuccess && hipHostMalloc((void**)&S.hp, bp, hipHostMallocDefault) == hipSuccess;
         }
+        if (!ok) { *err = "allocation failed in qmri_recon_batch"; st = QMRI_ERR_NOMEM; break; }
         const int nlaunch = (nslices + spl - 1) / spl;
-        for (int l = widx; l < nlaunch && st == QMRI_OK; l += nworkers) {
+        int k = 0;
+        for (int l = widx; l < nlaunch && st == QMRI_OK; l += nworkers, ++k) {
+            Set& S = set[k & 1];
+            drain(S);                                              // (its previous launch, two launches ago: long since copied)
+            if (st != QMRI_OK) break;
             const int s0 = l * spl, cnt = std::min(spl, nslices - s0);
-            if (hipMemcpy(dY, Y + (size_t)s0 * m * sizeof(double2), (size_t)cnt * m * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) { *err = "H2D copy failed"; st = QMRI_ERR_HIP; break; }
-            if ((st = qmri_pnp_admm_dev(ctx, cnt, dY, &pb->admm, nullptr, nullptr, dX, nullptr, nullptr)) != QMRI_OK) { bail(st); break; }
-            if (hipMemcpy(X_out + (size_t)s0 * n * sizeof(double2), dX, (size_t)cnt * n * sizeof(double2), hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H copy failed"; st = QMRI_ERR_HIP; break; }
-            if (pb->K > 0 && (qmap_out || pd_out)) {
-                for (int i = 0; i < cnt && st == QMRI_OK; ++i) {
-                    if ((st = qmri_dict_match_dev(ctx, dX + (size_t)i * n, (int)npix, qmap_out ? dq : nullptr, pd_out ? dp : nullptr, nullptr, nullptr)) != QMRI_OK) { bail(st); break; }
-                    if (qmri_synchronize(ctx) != QMRI_OK) { bail(QMRI_ERR_HIP); st = QMRI_ERR_HIP; break; }
-                    if (qmap_out && hipMemcpy(qmap_out + (size_t)(s0 + i) * npix * pb->Q, dq, npix * pb->Q * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H copy failed"; st = QMRI_ERR_HIP; break; }
-                    if (pd_out && hipMemcpy(pd_out + (size_t)(s0 + i) * npix * 2, dp, npix * 2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H copy failed"; st = QMRI_ERR_HIP; break; }
-                }
+            std::memcpy(S.hY, Y + (size_t)s0 * m * sizeof(double2), (size_t)cnt * m * sizeof(double2));
+            if (hipMemcpyAsync(S.dY, S.hY, (size_t)cnt * m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { hipfail("H2D copy"); break; }
+            if ((st = qmri_pnp_admm_dev(ctx, cnt, S.dY, &pb->admm, nullptr, nullptr, S.dX, nullptr, nullptr)) != QMRI_OK) { bail(st); break; }
+            if (maps) {
+                for (int i = 0; i < cnt && st == QMRI_OK; ++i)
+                    if ((st = qmri_dict_match_dev(ctx, S.dX + (size_t)i * n, (int)npix, qmap_out ? S.dq + (size_t)i * npix * Q : nullptr,
+                                                  pd_out ? S.dp + (size_t)i * npix * 2 : nullptr, nullptr, nullptr)) != QMRI_OK) bail(st);
+                if (st != QMRI_OK) break;
             }
+            if (hipEventRecord(S.matched, ctx->stream) != hipSuccess || hipStreamWaitEvent(cs, S.matched, 0) != hipSuccess) { hipfail("event"); break; }
+            if (hipMemcpyAsync(S.hX, S.dX, (size_t)cnt * n * sizeof(double2), hipMemcpyDeviceToHost, cs) != hipSuccess) { hipfail("D2H copy"); break; }
+            if (maps && qmap_out && hipMemcpyAsync(S.hq, S.dq, (size_t)cnt * npix * Q * sizeof(float), hipMemcpyDeviceToHost, cs) != hipSuccess) { hipfail("D2H copy"); break; }
+            if (maps && pd_out && hipMemcpyAsync(S.hp, S.dp, (size_t)cnt * npix * 2 * sizeof(float), hipMemcpyDeviceToHost, cs) != hipSuccess) { hipfail("D2H copy"); break; }
+            if (hipEventRecord(S.copied, cs) != hipSuccess) { hipfail("event"); break; }
+            S.s0 = s0; S.cnt = cnt;
+            drain(set[(k & 1) ^ 1]);                               // the previous launch's results, while the device matches and copies this one's
         }
+        if (st == QMRI_OK) { drain(set[0]); if (st == QMRI_OK) drain(set[1]); }
     } while (0);
-    void* ptrs[] = { dY, dX, dq, dp };
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    (void)hipDeviceSynchronize();
+    for (Set& S : set) {
+        void* dptr[] = { S.dY, S.dX, S.dq, S.dp };
+        for (void* p : dptr) if (p) (void)hipFree(p);
+        void* hptr[] = { S.hY, S.hX, S.hq, S.hp };
+        for (void* p : hptr) if (p) (void)hipHostFree(p);
+        if (S.matched) (void)hipEventDestroy(S.matched);
+        if (S.copied) (void)hipEventDestroy(S.copied);
+    }
+    if (cs) (void)hipStreamDestroy(cs);
     qmri_destroy(ctx);
     return st;
 }
