@@ -19,7 +19,7 @@
 //   D:  pack[tile32][G8][lane][4]           lane = (atom & 31) + 32 h, entry i = D(atom, 8 g + 2 i + h)     (A operand: k = 2 q + h)
 //   X:  xp[tile32][G8][re | -im][lane][4]   lane = (pixel & 31) + 32 h, entry i = single(x(pixel, 8 g + 2 i + h))   (B operand; -im: conj)
 // Bound: f32 MFMA, 157.3 TFLOP/s.  Operand traffic is small against it: a 128 x 128 tile needs 24 KB per 524 288 multiply-adds (13 GB/s per
-// workgroup); the workgroup order keeps the 64 workgroups an XCD holds on an 8 x 8 block of (pixel tile, atom part), so its L2 serves both operands.
+// workgroup); the workgroup order keeps the 64 workgroups an XCD holds on a 4 x 16 block of (pixel tile, atom part), so its L2 serves both operands.
 #include <algorithm>
 #include "qmri_internal.h"
 #include "dict_device.h"
@@ -66,14 +66,16 @@ __global__ __launch_bounds__(256) void k_dictw_pack_x(const double2* __restrict_
 // Workgroup (pixel tile pt, atom part prt): atoms tiles [prt tper, ...) of 128, each over all channel stages.
 // One barrier per stage: while a stage is multiplied out of one LDS buffer the next one travels global -> registers -> the other buffer.
 __global__ __launch_bounds__(WT, 2) void k_dictw_match(const float4* __restrict__ DP, const float4* __restrict__ XP, int G8, int AT, int PT, int P,
-                                                        int tper, int Npix, float4* __restrict__ part) {
+                                                        int tper, int Npix, float4* __restrict__ part, int lsp) {
     __shared__ float4 s_buf[2][STAGE_F4];
-    // workgroup order: blockIdx.x % 8 is the XCD under round-robin placement (speed only); an XCD walks super-tiles of 8 pixel tiles x 8 parts
+    // workgroup order: blockIdx.x % 8 is the XCD under round-robin placement (speed only); an XCD walks super-tiles of 2^lsp pixel tiles x
+    // 2^(6 - lsp) atom parts (64 workgroups = what it holds at once)
     const int id = blockIdx.x, xcd = id & 7, kk = id >> 3;
-    const int SPT = (PT + 7) >> 3, SPP = (P + 7) >> 3;
+    const int lsa = 6 - lsp;
+    const int SPT = (PT + (1 << lsp) - 1) >> lsp, SPP = (P + (1 << lsa) - 1) >> lsa;
     const int sidx = xcd + 8 * (kk >> 6), within = kk & 63;
     if (sidx >= SPT * SPP) return;
-    const int pt = (sidx % SPT) * 8 + (within & 7), prt = (sidx / SPT) * 8 + (within >> 3);
+    const int pt = ((sidx % SPT) << lsp) + (within & ((1 << lsp) - 1)), prt = ((sidx / SPT) << lsa) + (within >> lsp);
     if (pt >= PT || prt >= P) return;
     const int t0 = prt * tper, nt = min(tper, AT - t0);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -208,9 +210,9 @@ int dictw_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, flo
         D.slots_w = std::max(1, per_cu) * prop.multiProcessorCount;
     }
     const int PT = (Npix + 127) / 128, AT = D.ntiles / 4;
-    // atom parts: ~20 rounds of the device's resident workgroups (a ragged last round then costs < 5 %), whole groups of 8 for the XCD super-tiles
+    // atom parts: ~20 rounds of the device's resident workgroups (a ragged last round then costs < 5 %), whole groups of 16 for the XCD super-tiles
     int P = std::max(1, std::min(AT, (20 * D.slots_w + PT - 1) / PT));
-    if (P < AT) P = std::min(AT, (P + 7) / 8 * 8);
+    if (P < AT) P = std::min(AT, (P + 15) / 16 * 16);
     const int tper = (AT + P - 1) / P;
     P = (AT + tper - 1) / tper;                                          // no empty part
     const size_t nxp = (size_t)PT * 4 * D.G8 * 2 * 64;                   // float4
@@ -219,9 +221,14 @@ int dictw_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, flo
     const size_t nthr = (size_t)PT * 4 * D.G8 * 64;
     k_dictw_pack_x<<<dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_X, Npix, D.s, D.G8, PT * 4, (float4*)D.d_xp);
     QMRI_HIP(ctx, hipGetLastError());
-    const int nsuper = ((PT + 7) / 8) * ((P + 7) / 8);
+    // shape of the XCD super-tile (QMRI_DICTW_LSP for A/Bs): 4 pixel tiles x 16 atom parts.  Measured at s = 1000, K = 98 304 (profiles/r04_i_*): the
+    // launch time does not depend on it (144 - 147 ms: the kernel is compute-bound), the bytes leaving the L2s do -- FETCH_SIZE as counted 167 GB (64 x 1),
+    // 124 GB (8 x 8), 50 GB (4 x 16), 55 GB (2 x 32): X tiles (8 bytes per pixel and channel) are the larger operand, so more parts per pixel tile pay.
+    static const int lsp_env = getenv("QMRI_DICTW_LSP") ? atoi(getenv("QMRI_DICTW_LSP")) : 2;
+    const int lsp = std::max(0, std::min(6, lsp_env)), lsa = 6 - lsp;
+    const int nsuper = ((PT + (1 << lsp) - 1) >> lsp) * ((P + (1 << lsa) - 1) >> lsa);
     const unsigned grid = 8u * 64u * (unsigned)((nsuper + 7) / 8);
-    k_dictw_match<<<dim3(grid), dim3(WT), 0, ctx->stream>>>((const float4*)D.d_pack, (const float4*)D.d_xp, D.G8, AT, PT, P, tper, Npix, D.d_part);
+    k_dictw_match<<<dim3(grid), dim3(WT), 0, ctx->stream>>>((const float4*)D.d_pack, (const float4*)D.d_xp, D.G8, AT, PT, P, tper, Npix, D.d_part, lsp);
     QMRI_HIP(ctx, hipGetLastError());
     return dict_launch_merge(ctx, D.d_part, P, Npix, d_qmap, d_pd, d_mt, d_dm, win);
 }
