@@ -332,7 +332,14 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
                 if (ts[i]->p) QMRI_HIP(ctx, hipMemsetAsync(ts[i]->p, 0, ((size_t)p.maxB * ts[i]->batch_stride() + 8192) * sizeof(float), ctx->stream));
         }
         p.interior_fmt = blk ? 1 : 0;
-        for (int l = 0; l < 4; ++l) { p.x[l].blk = blk; p.a[l].blk = blk; p.t[l].blk = blk; }
+        // The ResBlocks' intermediate tensors can hold f16 PIECES in the f16 scheme (PTensor::pcs, QMRI_CONV_PIECES=1): bit-identical results
+        // (tests/test_gpu_net.py::test_pieces_tensors_change_no_bit) -- and, measured on one box (profiles/r04_k_*), no faster: 16.5-16.9 us per
+        // single-slice launch either way, 159.7 -> 161.4 us per 15-slice layer (the producer's epilogue, which the loader waves also run, pays
+        // what the consumer's loader saves).  OFF by default; kept as the measured answer to "store the pieces instead" (DESIGN.md 5.1 round 4).
+        // Zero bytes are zero pieces: the halo needs no re-zeroing when the format changes.
+        static const bool pieces_on = getenv("QMRI_CONV_PIECES") && atoi(getenv("QMRI_CONV_PIECES")) != 0;
+        const bool pcs = blk && pieces_on && p.sp6 == 2 && p.desc.arch == QMRI_ARCH_UNETRES && !p.d_stamps;
+        for (int l = 0; l < 4; ++l) { p.x[l].blk = blk; p.a[l].blk = blk; p.t[l].blk = blk; p.t[l].pcs = pcs; }
     }
     const bool report = !ctx->net.force_f32;                        // (the calibration's f32 pass reports nothing)
     if (report) QMRI_TRY(conv6_act_begin(ctx, (int)ctx->net.layers.size()));

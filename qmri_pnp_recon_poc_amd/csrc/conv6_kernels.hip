@@ -68,6 +68,7 @@ struct Conv6Args {
     int wt;                       // write-through (sc1) output stores, see store4()
     int xcd;                      // XCD-aware tile order, see xcd_remap()
     int in_blk, out_blk;          // the input / the output (and with it the residual operands) is a BLOCKED tensor [c/8][w][h][8] (see BRegs)
+    int in_pcs, out_pcs;          // ... whose 32-byte items hold the f16 PIECES of the 8 channels, [8 x hi][8 x lo'], instead of 8 floats (see pieces8)
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
     int ntiles;                   // k_conv6p: tiles of the launch (n_ct * tiles_h * tiles_w * B)
@@ -261,6 +262,35 @@ __device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, u
     p0 = __builtin_bit_cast(unsigned, hi);
     p1 = __builtin_bit_cast(unsigned, lo);
 }
+// PIECES tensors (round 4).  The intermediate tensor of a ResBlock (t = relu(conv1(a)), basicblock.py:211-223) has exactly one reader, the
+// block's second convolution, and that reader wants it as f16 pieces: so the producer's epilogue stores the pieces -- the 32 bytes of a
+// BLOCKED item hold [8 channels x hi][8 channels x lo'] instead of 8 floats, same addresses, same allocation, same zero halo -- and the
+// consumer's loader copies two 16-byte half-items into the two split planes of its LDS buffer without touching them (no conversion: 12 vector
+// instructions and one LDS store less per loader thread and step, on the waves whose issue slots bound the loop).  The pieces are what
+// split_pair_h() makes of the stored value either way, so results are bit-identical to the fp32-tensor form.  Tensors that are also residual
+// or skip operands stay fp32 (hi + lo' carries 22 bits, a residual needs all 24).
+// hi (lo = 0) or scaled-low (lo = 1) pieces of the 8 channels c0[0..3], c1[0..3] of one pixel, packed as the loader's split planes want them
+__device__ __forceinline__ f32x4 pieces8(const f32x4& c0, const f32x4& c1, int lo) {
+    unsigned h[4], l[4];
+    split_pair_h(c0[0], c0[1], h[0], l[0]); split_pair_h(c0[2], c0[3], h[1], l[1]);
+    split_pair_h(c1[0], c1[1], h[2], l[2]); split_pair_h(c1[2], c1[3], h[3], l[3]);
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = lo ? l[i] : h[i];
+    return __builtin_bit_cast(f32x4, r);
+}
+// the value of the neighbouring lane (lane ^ 1) on the VALU: lane pairs hold the two 4-channel halves of one pixel's 8-channel block
+__device__ __forceinline__ float lane_xor1(float v) {
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    asm volatile("" : "+v"(r));      // (one move per value: hipcc otherwise merged the four moves of a vector into one -- and read element 0 four times)
+    return __int_as_float(r);
+}
+__device__ __forceinline__ f32x4 pair_swap(const f32x4& x) {
+    const float a = x[0], b = x[1], c = x[2], d = x[3];
+    f32x4 y;
+    y[0] = lane_xor1(a); y[1] = lane_xor1(b); y[2] = lane_xor1(c); y[3] = lane_xor1(d);
+    return y;
+}
 constexpr float F16_RANGE = 60000.f;  // |activation| above this cannot be split (f16 max 65504): reported through range_flag
 __device__ __forceinline__ void act_report(const ActMax& am, float tmax, int waves_per_block) {
     if (am.layer < 0) return;
@@ -277,8 +307,9 @@ __device__ __forceinline__ void act_report(const ActMax& am, float tmax, int wav
 // (Measured and removed: streaming the residual operand into an LDS tile during the last 8 steps of the loop, so that the epilogue
 //  finds it on chip.  The loop is bound by the loader waves (tools/conv6p_stamps.py), so what the epilogue saved the loop lost:
 //  634.9 vs 634.9 ADMM it/s, residual layers 21.3 us either way against 17.8 us for layers without a residual operand.)
-template <int CFG, int SP, bool STAMP, bool INB>
+template <int CFG, int SP, bool STAMP, bool INB, bool INP = false>    // INP: the input is a PIECES tensor (pieces8)
 __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
+    static_assert(!INP || (INB && SP == 2), "pieces tensors are blocked tensors of the f16 scheme");
     constexpr int AST = ast6(SP);
     typedef Cfg6<CFG> C;
     constexpr int TH = C::TH, TW = C::TW, MW = C::MW, NCT = C::NCT, MH = C::MH;
@@ -352,7 +383,9 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                     const int h2 = item / NLP, px = item - h2 * NLP;
                     const int dw = px / IH, dh = px - dw * IH;
                     boff[part][q] = (unsigned)((((size_t)h2) * A.in_plane + dw * A.in_hp + dh) * 32 + 16 * (lt & 1));
-                    ldsB[part][q] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + 8 * (lt & 1));
+                    // (PIECES: half 0 = the 8 hi pieces = the whole 16-byte entry of split plane 0, half 1 = the lo' pieces = split plane 1)
+                    ldsB[part][q] = INP ? (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + (lt & 1) * (2 * NPX * 16))
+                                        : (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + 8 * (lt & 1));
                 }
             } else {
                 int item = part * (NBQ * NLD6) + lt;
@@ -389,7 +422,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
             else { _Pragma("unroll") for (int j = 0; j < 8; ++j) bload1(rb_.v[j], boff[part_][j], srdI, so_); }  \
         }
 #define STORE_B(c_, part_, rb_)                                                                                  \
-        if constexpr (INB) {                                                                                     \
+        if constexpr (INP) {                     /* pieces as stored: a copy */                                  \
+            _Pragma("unroll") for (int q = 0; q < NBH; ++q)                                                      \
+                *(f32x4*)((unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_][q]) = rb_.q[q];     \
+        } else if constexpr (INB) {                                                                              \
             _Pragma("unroll") for (int q = 0; q < NBH; ++q) {                                                    \
                 unsigned char* bd = (unsigned char*)(Bbuf + ((c_) & 1) * (SP * 2 * NPX)) + ldsB[part_][q];       \
                 uint2 s0, s1, s2;                /* 4 channels = 8 bytes of a 16-byte entry */                    \
@@ -647,7 +683,14 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 f32x4 x = *(const f32x4*)(ot + px * OTP + g * 8 + 4 * half);
                 x = (x + r1[k]) + r2[k];
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-                if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
+                f32x4 xs = x;
+                if constexpr (SP == 2) {
+                    if (A.out_pcs) {                                // (uniform) PIECES output: this lane's half-item = the hi (half 0) or lo' (half 1) pieces of all 8 channels
+                        const f32x4 y = pair_swap(x);               // the other half of the pixel's block
+                        xs = half ? pieces8(y, x, 1) : pieces8(x, y, 0);
+                    }
+                }
+                if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], xs, A.wt);
                 if constexpr (SP == 2) {
                     const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
                     bad |= !(gm <= F16_RANGE);                      // (also NaN)
@@ -733,6 +776,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
 }
 
 template <int CFG, int SP, bool INB, bool STAMP = false> __global__ __launch_bounds__(NT6) void k_conv6(const Conv6Args A) { conv6_body<CFG, SP, STAMP, INB>(A); }
+template <int CFG> __global__ __launch_bounds__(NT6) void k_conv6i(const Conv6Args A) { conv6_body<CFG, 2, false, true, true>(A); }     // ... reading a PIECES tensor
 
 // =====================================================================================================================
 // k_conv6p : persistent, software-pipelined form of k_conv6 (f16 x 3 scheme) for launches with several tiles per CU -- slice
@@ -779,7 +823,7 @@ template <int CFG> __device__ __forceinline__ Tile6 tile6(const Conv6Args& A, in
         }                                                                                                        \
     } while (0)
 
-template <int CFG, int NRES, bool STAMP>
+template <int CFG, int NRES, bool STAMP, bool INP = false>     // INP: the input is a PIECES tensor (pieces8)
 __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
     constexpr int SP = 2;
     constexpr int AST = ast6(SP);
@@ -837,7 +881,8 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
                 const int h2 = item / NLP, px = item - h2 * NLP;
                 const int dw = px / IH, dh = px - dw * IH;
                 boff[part][q] = (unsigned)(((size_t)h2 * A.in_plane + dw * A.in_hp + dh) * 32 + 16 * (lt & 1));
-                ldsB[part][q] = (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + 8 * (lt & 1));
+                ldsB[part][q] = INP ? (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + (lt & 1) * (2 * NPX * 16))     // (PIECES: as in k_conv6)
+                                    : (unsigned)((h2 * NPX + dw * IHP + dh) * 16 + 8 * (lt & 1));
             }
         unsigned char* const ldsA = (unsigned char*)Abuf + lt * 16;                    // + buffer * ASTB + q * NLD6 * 16 (immediates)
         unsigned char* const ldsBb = (unsigned char*)Bbuf;
@@ -890,7 +935,9 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             bload4f(rb_.q[0], boff[part_][0], srdI, so_); bload4f(rb_.q[1], boff[part_][1], srdI, so_);          \
         }
 #define PSTORE_B(c_, part_, rb_)                                                                                 \
-        {                                                                                                        \
+        if constexpr (INP) {                     /* pieces as stored: a copy */                                  \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) *(f32x4*)(ldsBb + ((c_) & 1) * (SP * 2 * NPX * 16) + ldsB[part_][q]) = rb_.q[q]; \
+        } else {                                                                                                 \
             _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
                 unsigned char* bd = ldsBb + ((c_) & 1) * (SP * 2 * NPX * 16) + ldsB[part_][q];                   \
                 uint2 s0, s1;                                                                                    \
@@ -923,7 +970,12 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
                 if constexpr (NRES > 0) x = x + rr_[0][q];                                                       \
                 if constexpr (NRES > 1) x = x + rr_[1][q];                                                       \
                 if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); } \
-                if (okhw_) bstore4(x, evoff[q], srdO, so_);                                                      \
+                f32x4 xs_ = x;                                                                                   \
+                if (A.out_pcs) {                 /* (uniform) PIECES output, as in k_conv6 */                     \
+                    const f32x4 y_ = pair_swap(x);                                                               \
+                    xs_ = ehalf ? pieces8(y_, x, 1) : pieces8(x, y_, 0);                                         \
+                }                                                                                                \
+                if (okhw_) bstore4(xs_, evoff[q], srdO, so_);                                                    \
                 {                                                                                                \
                     const float gm_ = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));   \
                     bad |= !(gm_ <= F16_RANGE);                                                                  \
@@ -1137,7 +1189,12 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
             f32x4 x = *(const f32x4*)(ot + px * OTP + g * 8 + 4 * half);
             x = (x + r1[k]) + r2[k];
             if (A.relu_out) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-            if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], x, A.wt);
+            f32x4 xs = x;
+            if (A.out_pcs) {                                        // (uniform) PIECES output, as in k_conv6
+                const f32x4 y = pair_swap(x);
+                xs = half ? pieces8(y, x, 1) : pieces8(x, y, 0);
+            }
+            if (off[k] != ~0u) store4(A.out + (size_t)b * A.out_bs + off[k], xs, A.wt);
             const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
             bad |= !(gm <= F16_RANGE);
             if (off[k] != ~0u) tmaxp = fmaxf(tmaxp, gm);
@@ -1466,6 +1523,11 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
     A.in = in.fbase(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.fbase();
     A.add1 = add1 ? add1->fbase() : nullptr; A.add2 = add2 ? add2->fbase() : nullptr;
     A.in_blk = in.blk ? 1 : 0; A.out_blk = (out.blk && !partial) ? 1 : 0;       // (split-K partial sums are planar scratch)
+    A.in_pcs = in.pcs ? 1 : 0; A.out_pcs = (out.pcs && !partial) ? 1 : 0;       // (... and the reduce kernel writes the pieces)
+    if ((in.pcs && (!in.blk || SP != 2)) || (out.pcs && (!out.blk || SP != 2 || add1 || add2)) || (add1 && add1->pcs) || (add2 && add2->pcs)) {
+        qmri_set_error(ctx, "conv layer %d: a PIECES tensor must be a blocked tensor of the f16 scheme, never a residual operand or a layer output with one", L.index);
+        return QMRI_ERR_STATE;
+    }
     if ((add1 && add1->blk != out.blk) || (add2 && add2->blk != out.blk) || (out.blk && L.Cout % 8 != 0)) {
         qmri_set_error(ctx, "conv layer %d: residual operands and output must share one tensor format (blocked needs Cout %% 8 == 0)", L.index);
         return QMRI_ERR_STATE;
@@ -1514,6 +1576,18 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
             return QMRI_OK;
         }
     }
+    if constexpr (SP == 2) {
+        if (in.pcs) {
+            if (!ctx->conv6i_attr[CFG]) {
+                QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6i<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ctx->conv6i_attr[CFG] = true;
+            }
+            if (e0) hipExtLaunchKernelGGL((k_conv6i<CFG>), dim3(grid), dim3(NT6), (std::uint32_t)lds, ctx->stream, e0, e1, 0, A);
+            else k_conv6i<CFG><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
+            QMRI_HIP(ctx, hipGetLastError());
+            return QMRI_OK;
+        }
+    }
     if (in.blk) {
         if (e0) hipExtLaunchKernelGGL((k_conv6<CFG, SP, true>), dim3(grid), dim3(NT6), (std::uint32_t)lds, ctx->stream, e0, e1, 0, A);
         else k_conv6<CFG, SP, true><<<dim3(grid), dim3(NT6), lds, ctx->stream>>>(A);
@@ -1534,6 +1608,11 @@ int launch6p_t(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, cons
     A.in = in.fbase(); A.wp = reinterpret_cast<const uint4*>(L.wp6); A.out = out.fbase();   // (BLOCKED tensors: launch6p checks)
     A.add1 = add1 ? add1->fbase() : nullptr; A.add2 = add2 ? add2->fbase() : nullptr;
     A.in_blk = 1; A.out_blk = 1;
+    A.in_pcs = in.pcs ? 1 : 0; A.out_pcs = out.pcs ? 1 : 0;
+    if ((out.pcs && NRES > 0) || (add1 && add1->pcs) || (add2 && add2->pcs)) {
+        qmri_set_error(ctx, "conv layer %d: a PIECES tensor is never a residual operand or a layer output with one", L.index);
+        return QMRI_ERR_STATE;
+    }
     A.Cout = L.Cout; A.W = in.W; A.H = in.H;
     A.in_hp = in.hp; A.in_plane = (int)in.plane(); A.in_bs = (long)in.Cal * in.plane();
     A.out_hp = out.hp; A.out_plane = (int)out.plane(); A.out_bs = (long)out.Cal * out.plane();
@@ -1554,9 +1633,18 @@ int launch6p_t(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, cons
     if (!ctx->conv6p_attr[CFG][NRES]) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6p<CFG, NRES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6p_lds<CFG>()));
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6p<CFG, NRES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6p_lds<CFG>()));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6p<CFG, NRES, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6p_lds<CFG>()));
         ctx->conv6p_attr[CFG][NRES] = true;
     }
     const int grid = std::min(A.ntiles, ctx->conv_ncu);
+    if (in.pcs) {                                                   // (no diagnostic build of this form: the stamps run on fp32 tensors)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
+        if (e0) hipExtLaunchKernelGGL((k_conv6p<CFG, NRES, false, true>), dim3(grid), dim3(NT6), (std::uint32_t)conv6p_lds<CFG>(), ctx->stream, e0, e1, 0, A);
+        else k_conv6p<CFG, NRES, false, true><<<dim3(grid), dim3(NT6), conv6p_lds<CFG>(), ctx->stream>>>(A);
+        QMRI_HIP(ctx, hipGetLastError());
+        return QMRI_OK;
+    }
     if (A.detail) {                                                 // diagnostic build of the same kernel (tools/conv6p_stamps.py)
         k_conv6p<CFG, NRES, true><<<dim3(grid), dim3(NT6), conv6p_lds<CFG>(), ctx->stream>>>(A);
         QMRI_HIP(ctx, hipGetLastError());
@@ -1655,9 +1743,10 @@ __global__ __launch_bounds__(256) void k_conv6_reduce(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_conv6_reduce_blk(const float* __restrict__ part, int ksplit, long out_ks, float* __restrict__ out,
                                                             const float* __restrict__ add1, const float* __restrict__ add2, long add1_bs,
                                                             long add2_bs, long out_bs, int Cout, int H, int W, int hp, int plane, int relu,
-                                                            long total_half_items, unsigned* range_flag, ActMax am) {
+                                                            long total_half_items, unsigned* range_flag, ActMax am, int out_pcs) {
     const long i2 = (long)blockIdx.x * 256 + threadIdx.x;
     float gm = 0.f;
+    // (out_pcs: the lane pairs exchange their halves -- every lane of a pair must be here, so an odd tail is handled by its even lane's bound)
     if (i2 < total_half_items) {
         const int half = (int)(i2 & 1);
         const long i = i2 >> 1;
@@ -1680,7 +1769,12 @@ __global__ __launch_bounds__(256) void k_conv6_reduce_blk(const float* __restric
         if (add1) x = x + *(const f32x4*)(add1 + b * add1_bs + bo);
         if (add2) x = x + *(const f32x4*)(add2 + b * add2_bs + bo);
         if (relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-        store4(out + b * out_bs + bo, x, 1);
+        f32x4 xs = x;
+        if (out_pcs) {                                              // PIECES output (pieces8): total_half_items is even, both lanes of a pair are active
+            const f32x4 y = pair_swap(x);
+            xs = half ? pieces8(y, x, 1) : pieces8(x, y, 0);
+        }
+        store4(out + b * out_bs + bo, xs, 1);
         gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
         if (range_flag && !(gm <= F16_RANGE)) atomicOr(range_flag, 1u);
     }
@@ -1976,7 +2070,7 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
                     net.d_c6part + (out.h0 - 1), ksplit, out_ks, out.fbase(), add1 ? add1->fbase() : nullptr, add2 ? add2->fbase() : nullptr,
                     add1 ? (long)add1->Cal * add1->plane() : 0, add2 ? (long)add2->Cal * add2->plane() : 0, (long)out.Cal * out.plane(), L.Cout, in.H,
                     in.W, out.hp, (int)out.plane(), relu_out, total_items, (L.sp6 == 2) ? ctx->net.d_range_flag : nullptr,
-                    conv6_act_slot(ctx, L.sp6 == 2, L));
+                    conv6_act_slot(ctx, L.sp6 == 2, L), out.pcs ? 1 : 0);
             } else if (vec) k_conv6_reduce<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, ctx->stream>>>(REDUCE_ARGS);
             else k_conv6_reduce<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(REDUCE_ARGS);
 #undef REDUCE_ARGS

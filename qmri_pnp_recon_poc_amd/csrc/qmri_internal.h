@@ -151,6 +151,9 @@ struct PTensor {
     // interior format of the matrix-core conv kernels (conv6_kernels.hip: 8 channels of a pixel = 32 contiguous bytes = two 16-byte
     // requests).  Same allocation either way (Cal % 8 == 0); a property of the current forward pass, set by net_forward_padded.
     bool blk = false;
+    // PIECES (round 4, conv6_kernels.hip pieces8): a BLOCKED tensor whose 32-byte items hold the f16 pieces of the 8 channels, [8 x hi][8 x lo'],
+    // instead of 8 floats -- the ResBlocks' intermediate tensors in the f16 scheme, written by one convolution's epilogue and copied by the next one's loader
+    bool pcs = false;
     float* base1() const { return p + (h0 - 1); }
     float* fbase() const { return p + (size_t)(h0 - 1) * (blk ? 8 : 1); }      // halo origin of row 0 in the tensor's current format
     size_t plane() const { return (size_t)hp * (W + 2); }
@@ -269,6 +272,7 @@ struct qmri_ctx {
     size_t chain_n = 0;                 // events handed out in the current forward
     bool conv6_attr[4][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
+    bool conv6i_attr[4] = {false, false, false, false};   // ... of k_conv6i<CFG> (PIECES input)
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
     int ks_persist = -1;                // k_ks_persist (all LSQR iterations in one launch): -1 = QMRI_LSQR_PERSIST (default on), 0 / 1 set by qmri_debug_lsqr_persist

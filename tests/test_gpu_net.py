@@ -455,3 +455,37 @@ def test_every_tile_configuration_matches_the_oracle(tile_oracle, cfg):
     for j in range(4):
         err = rel_err(y[..., j], tile_oracle[..., j])
         assert err < 2e-5, (cfg, j, err)
+
+
+def test_pieces_tensors_change_no_bit(tmp_path):
+    """Round 4: the ResBlocks' intermediate tensors hold the f16 PIECES of their values (written by the first convolution's epilogue, copied by the
+    second one's loader) instead of floats that every consuming tile splits again.  The pieces are what the split makes of the stored value either
+    way: the network's output must be IDENTICAL, bit for bit, with QMRI_CONV_PIECES=0 (read once per process: two child processes) -- one slice
+    (k_conv6 at all four levels, split-K reduce at 28 x 28), a batch of 5 (k_conv6p), and a 64 x 64 input (tiles that overhang the image)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from qmri_pnp_recon_poc_amd import engine as E, synth\n"
+        "w = synth.random_weights(seed=1, gain=0.7)\n"
+        "rng = np.random.default_rng(3)\n"
+        "out = {}\n"
+        "for N, B in ((224, 1), (224, 5), (64, 2)):\n"
+        "    e = E.Engine(0)\n"
+        "    e.set_denoiser(w, N, N, max_batch=B)\n"
+        "    x = rng.random((N, N, 10, B))\n"
+        "    out[f'y{N}_{B}'] = e.denoise(x if B > 1 else x[..., 0])\n"
+        "    assert e.denoiser_scheme() == (2, 0)\n"
+        "    e.close()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"pieces_{flag}.npz")
+        env = dict(os.environ, QMRI_CONV_PIECES=flag)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = np.load(path)
+    for k in res["1"].files:
+        a, b = res["1"][k], res["0"][k]
+        assert np.all(np.isfinite(a)) and np.array_equal(a, b), (k, float(np.abs(a - b).max()))
