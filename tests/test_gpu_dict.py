@@ -360,3 +360,36 @@ def test_xfit_narrow_dictionary(engine_mod, oracle, synth, case224):
             _assert_same(g, o, ("dm", "mt", "pd", "qmap", "Xfit"))
     e.dict_filter(True)
     e.close()
+
+
+def test_wide_dict_match_random_shapes(engine_mod, oracle):
+    """The channel-blocked match on 24 random problem shapes -- channel counts 17 .. 300 around the 16-channel stage, atom counts around the
+    128-atom tile and the 16-part super-tile, pixel counts around the 128-pixel tile; unit-norm random atoms plus near-duplicates (atoms a few ulps
+    apart, so that ties cross tiles and parts), pixels = scaled atoms + noise, some exactly zero, some a single non-zero channel: every output equal
+    to the oracle's bits, Xfit included."""
+    rng = np.random.default_rng(2024)
+    e = engine_mod.Engine(0)
+    for trial in range(24):
+        s = int(rng.choice([17, 18, 31, 32, 33, 47, 48, 49, 64, 100, 129, 300]))
+        K = int(rng.choice([1, 5, 31, 32, 33, 127, 128, 129, 255, 257, 1000, 2049, 5000]))
+        npix = int(rng.choice([1, 31, 33, 127, 128, 129, 500, 1025]))
+        D = rng.standard_normal((K, s)).astype(np.float32)
+        D /= np.linalg.norm(D, axis=1, keepdims=True)
+        ndup = min(K // 2, 40)
+        if ndup:                                                   # near-duplicates of random atoms at random places
+            src, dst = rng.integers(0, K, ndup), rng.integers(0, K, ndup)
+            D[dst] = (D[src].view(np.int32) + rng.integers(-2, 3, size=(ndup, s), dtype=np.int32)).view(np.float32)
+        nd = (0.5 + rng.random(K)).astype(np.float32)
+        lut = rng.random((K, 2)).astype(np.float32)
+        X = D[rng.integers(0, K, npix)] * (0.1 + rng.random((npix, 1))) * np.exp(1j * rng.random((npix, 1)) * 6.28)
+        X = X + 0.05 * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape)) / np.sqrt(s)
+        X[rng.integers(0, npix, max(1, npix // 20))] = 0.0
+        one = rng.integers(0, npix)
+        X[one] = 0.0
+        X[one, rng.integers(0, s)] = 1.0 - 2.0j
+        e.set_dictionary(D, nd, lut)
+        g = e.dict_match(X, want_xfit=True)
+        o = oracle.dict_match(X, D, nd, lut, want_xfit=True)
+        for k in ("dm", "mt", "pd", "qmap", "Xfit"):
+            assert np.array_equal(g[k], o[k]), (trial, s, K, npix, k, int(np.sum(g[k] != o[k])))
+    e.close()
