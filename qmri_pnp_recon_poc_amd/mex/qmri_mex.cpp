@@ -92,7 +92,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         d.nb = (int)mxGetScalar(prhs[5]); d.residual_noise = (int)mxGetScalar(prhs[6]);
         check(qmri_set_denoiser(ctx(), &d, (const float*)mxGetData(prhs[1]), mxGetNumberOfElements(prhs[1]) * 4,
                                 (int)mxGetScalar(prhs[7]), (int)mxGetScalar(prhs[8]), 1));
-    } else if (c == "load_onnx") {                   // in_nc = qmri_mex('load_onnx', denoiser_path, residual_noise, H, W)
+    } else if (c == "load_onnx") {                   // [in_nc, out_nc] = qmri_mex('load_onnx', denoiser_path, residual_noise, H, W)
         // the weight-loading half of `Net = importONNXNetwork(denoiser_path, ...)` (main_recon_tsmis_FFT.m:138) + set_denoiser
         char path[4096];
         if (mxGetString(prhs[1], path, sizeof path)) mexErrMsgIdAndTxt("qmri:usage", "denoiser_path must be a char vector");
@@ -105,6 +105,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         check(qmri_set_denoiser(ctx(), &d, (const float*)mxGetData(w), n * 4, (int)mxGetScalar(prhs[3]), (int)mxGetScalar(prhs[4]), 1));
         mxDestroyArray(w);
         plhs[0] = mxCreateDoubleScalar((double)d.in_nc);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar((double)d.out_nc);
     } else if (c == "denoise") {                     // I = qmri_mex('denoise', A, out_nc)   (param.net, :164)
         const mwSize* dm = mxGetDimensions(prhs[1]);
         const int nd = (int)mxGetNumberOfDimensions(prhs[1]);
