@@ -393,3 +393,38 @@ def test_wide_dict_match_random_shapes(engine_mod, oracle):
         for k in ("dm", "mt", "pd", "qmap", "Xfit"):
             assert np.array_equal(g[k], o[k]), (trial, s, K, npix, k, int(np.sum(g[k] != o[k])))
     e.close()
+
+
+def test_wide_dict_match_at_bench_size_K_98304_T_1000(engine_mod, oracle, synth):
+    """BASELINE configs[4] at full size: one 224 x 224 slice of T = 1000 uncompressed channels against K = 98 304 atoms (19.7 TFLOP, ~0.15 s on
+    the GPU).  The oracle needs minutes per slice, so it is run on 768 pixels spread over the slice -- every pixel is matched independently, and
+    on those pixels atom index, magnitude, PD and the maps must equal the oracle's bits; on the whole slice the size-independent properties:
+    the match of a noise-free pixel is an atom whose (T1, T2) sit within a grid step of the phantom's, and dm stays inside 1 .. K."""
+    T = 1000
+    dic = synth.make_dictionary(T=T, n_t1=384, n_t2=256, uncompressed=True)
+    K = int(dic["K"])
+    assert K == 98304 and dic["D"].shape == (K, T)
+    q = synth.make_phantom_qmaps(224, seed=0)
+    X = synth.synthesize_tsmi(q, dic).astype(np.complex128)
+    rng = np.random.default_rng(1)
+    X[:, :112] += 0.02 * X.real.std() * (rng.standard_normal((224, 112, T)) + 1j * rng.standard_normal((224, 112, T)))     # left half noisy, right half clean
+    X *= np.exp(0.7j)
+    e = engine_mod.Engine(0)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    g = e.dict_match(X)
+    e.close()
+    assert g["dm"].min() >= 1 and g["dm"].max() <= K
+    npix = 224 * 224
+    sel = np.linspace(0, npix - 1, 768).astype(np.int64)
+    xs = X.reshape(npix, T, order="F")[sel]
+    o = oracle.dict_match(xs, dic["D"], dic["normD"], dic["lut"])
+    for k in ("dm", "mt", "pd"):
+        assert np.array_equal(g[k].ravel(order="F")[sel], o[k]), k
+    assert np.array_equal(g["qmap"].reshape(npix, -1, order="F")[sel], o["qmap"])
+    # clean half: the matched atom is (within the rounding of a 1000-term single-precision chain) the synthesis's nearest grid atom
+    fg = (q[:, :, 2] > 0)
+    fg[:, :112] = False
+    t1g, t2g = dic["t1_grid"], dic["t2_grid"]
+    i1 = np.searchsorted(t1g, g["qmap"][:, :, 0][fg] * (1 - 1e-6)); i1 = np.clip(i1, 0, t1g.size - 1)
+    want1 = np.abs(t1g[None, :] - q[:, :, 0][fg][:, None]).argmin(1)
+    assert np.mean(np.abs(i1 - want1) <= 1) > 0.98
