@@ -309,3 +309,50 @@ def test_admm_224_full_length_100_iterations(engine_mod, oracle, synth, case224,
     mx = oracle.dict_match(xg, dic["D"], dic["normD"], dic["lut"])
     assert np.array_equal(mx["dm"], mg["dm"]) and np.array_equal(mx["qmap"], mg["qmap"])
     e.close()
+
+
+def test_fused_small_launches_equal_separate_kernels(tmp_path):
+    """Round 4 folds the launches between the network and the solve into their neighbours (k_dual_fwd_h, k_ks_init_a<FWDW>, min / max in k_adj_h).
+    The arithmetic of x, u, z is the same; only the partial sums of |z|^2 (the solve's stop threshold) are added in another fixed order.  With
+    QMRI_FUSE_EW=0 (read once per process: two child processes) the separate kernels run: after 8 ADMM iterations at 224 x 224 -- single slice
+    and a batch of 3, single- and multi-level denoiser -- the LSQR iteration counts must be identical and x equal to rounding (1e-12)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from qmri_pnp_recon_poc_amd import engine as E, synth, batch\n"
+        "dic = synth.make_dictionary(T=200, n_t1=32, n_t2=16)\n"
+        "fp, k = E.build_spiral(224, 771, 200)\n"
+        "out = {}\n"
+        "for multi in (0, 1):\n"
+        "    w = synth.structured_weights(in_nc=10 + multi, seed=2, eps=0.3)\n"
+        "    e = E.Engine(0)\n"
+        "    e.set_operator(224, 224, dic['V'], fp, k, max_batch=3)\n"
+        "    e.set_denoiser(w, 224, 224, in_nc=10 + multi, max_batch=3)\n"
+        "    ys = []\n"
+        "    for sd in range(3):\n"
+        "        X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(224, seed=sd), dic)\n"
+        "        ys.append(synth.awgn_measured(e.forward(X0), 30.0, seed=sd))\n"
+        "    x, _, li = e.pnp_admm(ys[0], iters=8, multi_level=bool(multi))\n"
+        "    out[f'x{multi}'] = x; out[f'li{multi}'] = li\n"
+        "    e.close()\n"
+        "    r = batch.recon_batch([0], np.stack(ys), N=224, M=224, V=dic['V'], frame_ptr=fp, kidx=k, weights=w, in_nc=10 + multi,\n"
+        "                          iters=8, multi_level=bool(multi), slices_per_launch=3)\n"
+        "    out[f'xb{multi}'] = r['X']\n"
+
+        "np.savez(sys.argv[1], **out)\n")
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"fuse_{flag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, QMRI_FUSE_EW=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = np.load(path)
+    for k in res["1"].files:
+        a, b = res["1"][k], res["0"][k]
+        if k.startswith("li"):
+            assert np.array_equal(a, b), (k, a, b)
+        else:
+            assert rel_err(a, b) < 1e-12, (k, rel_err(a, b))

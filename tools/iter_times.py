@@ -9,7 +9,7 @@ for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'k_unnormalise_dual' in r[2]]
+marks = [i for i, r in enumerate(rows) if 'k_unnormalise_dual' in r[2] or 'k_dual_fwd_h' in r[2]]     # (the iteration's last launch; round 4: the fused kernel)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
 lo, hi = marks[which] + 1, marks[which + 1] + 1
 it = rows[lo:hi]
