@@ -41,6 +41,12 @@ def test_main_recon_flow_small(oracle, synth):
     oo = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"])
     same = bool(np.array_equal(out["qmap"], oo["qmap"])) and bool(np.array_equal(out["dm"], oo["dm"].astype(np.float32)))
     assert same
+    assert "Xfit" not in out and "X" not in out                    # par.f.Xout = 0 (mrf_dtm_cpu.m:129)
+    # par.f.Xout = 1 (:95,129-134): the matched atoms scaled by the unnormalised inner product, single complex, and the input handed back
+    par["f"]["Xout"] = 1
+    out2 = R.mrf_dtm_cpu(dic, {"X": X}, par)
+    ox = oracle.dict_match(X, dic["D"], dic["normD"], dic["lut"], want_xfit=True)
+    assert out2["Xfit"].dtype == np.complex64 and out2["Xfit"].shape == X.shape and np.array_equal(out2["Xfit"], ox["Xfit"]) and out2["X"] is X
     # error behaviour of the denoiser plugin (validateInputImage, denoiseImage_PnP_ADMM.m:119-127)
     with pytest.raises(ValueError):
         param["net"](np.full((N, M, 6), np.nan))
