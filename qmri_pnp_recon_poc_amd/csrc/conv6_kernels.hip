@@ -68,6 +68,7 @@ struct Conv6Args {
     int wt;                       // write-through (sc1) output stores, see store4()
     int xcd;                      // XCD-aware tile order, see xcd_remap()
     int in_blk, out_blk;          // the input / the output (and with it the residual operands) is a BLOCKED tensor [c/8][w][h][8] (see BRegs)
+    int lowhalf;                  // Cfg6<3> only: launch the first 32-row half of every 64-row tile alone (Cout <= 32)
     int in_pcs, out_pcs;          // ... whose 32-byte items hold the f16 PIECES of the 8 channels, [8 x hi][8 x lo'], instead of 8 floats (see pieces8)
     int nchunk_all, ksplit;       // split-K: this launch covers nchunk of the layer's nchunk_all chunks per workgroup, ksplit workgroups per tile
     long out_ks;                  // split-K: elements between the partial outputs of consecutive K slices
@@ -341,8 +342,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     static_assert(SP == 3 ? (PXT * OTP * 4 <= 2 * 3 * 2 * NPX * 16) : (PXT * OTP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "pixel-major output tile must fit the operand buffers");
     const int tid = threadIdx.x;
     int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int mh = (MH > 1) ? bid % MH : 0;                         // which 32-row half of the 64-row tile (MH = 2)
-    if (MH > 1) bid /= MH;
+    // which 32-row half of the 64-row tile (MH = 2); A.lowhalf: only the first half exists (a layer with <= 32 output channels, the 64 -> 10
+    // tail: half the matrix work and half the weight bytes of the full tile)
+    const int mh = (MH > 1 && !A.lowhalf) ? bid % MH : 0;
+    if (MH > 1 && !A.lowhalf) bid /= MH;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
     const int th = bid % A.tiles_h; bid /= A.tiles_h;
     const int tw = bid % A.tiles_w; bid /= A.tiles_w;
@@ -729,8 +732,8 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 if (off[k] != ~0u) store4(A.out + (size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k], x, A.wt);
                 if constexpr (SP == 2) {
                     const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-                    bad |= !(gm <= F16_RANGE);                      // (also NaN)
-                    if (off[k] != ~0u) tmax = fmaxf(tmax, gm);
+                    // (only what is stored counts: with one 32-row half computed, the other rows of the LDS tile are whatever the operand buffers held)
+                    if (off[k] != ~0u) { bad |= !(gm <= F16_RANGE); tmax = fmaxf(tmax, gm); }                      // (also NaN)
                 }
             }
         } else {
@@ -763,7 +766,7 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
                 float x = (ot[co * PP + rem] + r1[k]) + r2[k];
                 if (A.relu_out) x = fmaxf(x, 0.f);
                 if (off[k] != ~0u) A.out[(size_t)ks * A.out_ks + (size_t)b * A.out_bs + off[k]] = x;
-                if constexpr (SP == 2) { bad |= !(fabsf(x) <= F16_RANGE); if (off[k] != ~0u) tmax = fmaxf(tmax, fabsf(x)); }
+                if constexpr (SP == 2) { if (off[k] != ~0u) { bad |= !(fabsf(x) <= F16_RANGE); tmax = fmaxf(tmax, fabsf(x)); } }
             }
         }
         if constexpr (SP == 2) {
@@ -1560,7 +1563,9 @@ int launch6(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const P
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6<CFG, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->conv6_attr[CFG][SP - 2] = true;
     }
-    const int grid = C::MH * A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
+    // (a layer with at most 32 output channels on the 32-row configuration: the second half of its one 64-row tile is all padding)
+    A.lowhalf = (C::MH > 1 && L.Cout <= 32 && !partial) ? 1 : 0;
+    const int grid = (A.lowhalf ? 1 : C::MH) * A.n_ct * A.tiles_h * A.tiles_w * ksplit * B;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));                  // (profile level 2 only)
     if constexpr (SP == 2 && CFG < 2) {
@@ -2010,6 +2015,12 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     auto ntiles = [&](int th, int tw) { return (long)L.n_ct6 * ((in.H + th - 1) / th) * ((in.W + tw - 1) / tw) * B; };
     // (tiles may overhang the image -- the kernel masks its stores -- as long as the padded area stays below 1.35 x the image)
     auto waste = [&](int th, int tw) { return (double)(((in.H + th - 1) / th) * th) * (((in.W + tw - 1) / tw) * tw) / ((double)in.H * in.W); };
+    // A layer with <= 32 output channels (the 64 -> 10 tail) can run on the 32-row configuration, first half only (QMRI_CONV_TAIL32=1): half the
+    // matrix work and half the weight bytes of the full 64-row tile.  Measured (profiles/r04_p_*): no faster -- 812 / 806 against 814 / 818 ADMM
+    // it/s, 14.0 against 14.0 - 14.2 slices/s: the tail's launch is its loader and its boundary, not its matrix work.  OFF by default.
+    static const bool tail32 = getenv("QMRI_CONV_TAIL32") && atoi(getenv("QMRI_CONV_TAIL32")) != 0;
+    if (tail32 && L.sp6 == 2 && L.Cout <= 32 && L.n_ct6 == 1 && L.nchunk6 >= 4 && ntiles(16, 8) >= 160 && waste(16, 8) <= 1.35)
+        return launch6<3>(ctx, L, B, in, out, add1, add2, relu_out);
     if (ntiles(16, 16) >= 160 && waste(16, 16) <= 1.35) return launch6<0>(ctx, L, B, in, out, add1, add2, relu_out);
     if (ntiles(16, 8) >= 160 && waste(16, 8) <= 1.35) return launch6<1>(ctx, L, B, in, out, add1, add2, relu_out);
     // Small feature maps with many channels (the 28 x 28 x 512 level): a 64-pixel tile would re-read the layer's weights
