@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""x-update cost per PnP-ADMM iteration for the configurations of BASELINE.json -- which of the two LSQR forms runs and what it costs:
+spiral cut3 (T = 200, the headline: one launch per solve), EPI cut3 and spiral cut0 (T = 1000) and every slice batch (two launches per LSQR
+iteration).  Stage times from the library's own stage timers (profile level 1: one synchronisation per stage), 20 ADMM iterations each.
+One JSON line per configuration."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
+from qmri_pnp_recon_poc_amd._lib import AdmmParams  # noqa: E402
+
+N, s, ITERS = 224, 10, 20
+torch.cuda.init()
+w = synth.structured_weights(seed=2, eps=0.02)
+for name, T, mask, B in (("spiral cut3", 200, "spiral", 1), ("EPI cut3", 200, "epi", 1), ("spiral cut0", 1000, "spiral", 1),
+                         ("spiral cut3", 200, "spiral", 15), ("EPI cut3", 200, "epi", 15)):
+    dic = synth.make_dictionary(T=T, n_t1=32, n_t2=16, s=s)
+    fp, k = E.build_spiral(N, 771, T) if mask == "spiral" else E.build_epi(N, N, 1 / 65, T)
+    eng = E.Engine(0)
+    eng.set_operator(N, N, dic["V"], fp, k, max_batch=B)
+    eng.set_denoiser(w, N, N, max_batch=B)
+    ys = np.stack([synth.awgn_measured(eng.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=i), dic)), 30.0, seed=i) for i in range(B)])
+    d_y = torch.from_numpy(np.ascontiguousarray(ys).view(np.float64)).cuda()
+    d_x = torch.empty((B, 2 * N * N * s), dtype=torch.float64, device="cuda")
+    li = np.zeros(B * ITERS, np.int32)
+    torch.cuda.synchronize()
+    p = AdmmParams(0.05, ITERS, 1e-4, 100, 0, 0, 0.01, 0)
+
+    def run():
+        eng._check(eng.L.qmri_pnp_admm_dev(eng.h, B, C.c_void_p(d_y.data_ptr()), C.byref(p), None, None, C.c_void_p(d_x.data_ptr()), None,
+                                           li.ctypes.data_as(C.POINTER(C.c_int32))))
+        eng.synchronize()
+    run()
+    eng.profile_get(reset=True)
+    eng.profile_enable(1)
+    run()
+    pr = eng.profile_get(reset=True)
+    eng.profile_enable(0)
+    it = max(pr["admm_iters"], 1)
+    print(json.dumps({"config": name, "T": T, "m": int(fp[-1]), "slices_per_launch": B, "admm_iters": ITERS,
+                      "lsqr_iters_mean_per_xupdate": round(float(li.mean()), 2),
+                      "xupdate_ms_per_admm_iter": round(pr["ms_xupdate"] / it, 4), "xupdate_ms_per_slice_iter": round(pr["ms_xupdate"] / it / B, 4),
+                      "denoiser_ms_per_admm_iter": round(pr["ms_denoiser"] / it, 4), "elementwise_ms_per_admm_iter": round(pr["ms_elementwise"] / it, 4),
+                      "us_per_lsqr_iteration_incl_fixed": round(pr["ms_xupdate"] / it / max(float(li.mean()), 1e-9) * 1e3, 2)}), flush=True)
+    eng.close()
