@@ -18,8 +18,11 @@ from qmri_pnp_recon_poc_amd._lib import AdmmParams  # noqa: E402
 N, s, ITERS = 224, 10, 20
 torch.cuda.init()
 w = synth.structured_weights(seed=2, eps=0.02)
-for name, T, mask, B in (("spiral cut3", 200, "spiral", 1), ("EPI cut3", 200, "epi", 1), ("spiral cut0", 1000, "spiral", 1),
-                         ("spiral cut3", 200, "spiral", 15), ("EPI cut3", 200, "epi", 15)):
+ONLY = int(sys.argv[1]) if len(sys.argv) > 1 else -1      # (a single configuration, for kernel traces)
+for idx, (name, T, mask, B) in enumerate((("spiral cut3", 200, "spiral", 1), ("EPI cut3", 200, "epi", 1), ("spiral cut0", 1000, "spiral", 1),
+                         ("spiral cut3", 200, "spiral", 15), ("EPI cut3", 200, "epi", 15))):
+    if ONLY >= 0 and idx != ONLY:
+        continue
     dic = synth.make_dictionary(T=T, n_t1=32, n_t2=16, s=s)
     fp, k = E.build_spiral(N, 771, T) if mask == "spiral" else E.build_epi(N, N, 1 / 65, T)
     eng = E.Engine(0)
