@@ -255,6 +255,11 @@ int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on);
  * every product exactly.  margin_scale (default 1) multiplies the filter's margin: the tests shrink it to measure how far the proven
  * margin is from the first wrong answer. */
 int qmri_debug_dict_filter(qmri_ctx* ctx, int on, float margin_scale);
+/* Test / A-B hook for the denoiser's convolutions: on = 1 (default) runs the ResBlocks of the full-resolution level of a one-slice forward pass as
+ * ONE launch with LDS-resident tiles (same bits as one launch per layer); on = 0 selects one launch per layer (also QMRI_CONV_RESIDENT=0); on = 2
+ * makes one tile withhold its hand-off on purpose: its neighbours' waits time out, the library reports it on stderr, repeats the call with one
+ * launch per layer and keeps the resident form off (the recovery path, tested).  timeouts_out (or NULL): hand-off time-outs seen so far. */
+int qmri_debug_conv_resident(qmri_ctx* ctx, int on, int* timeouts_out);
 
 #ifdef __cplusplus
 }

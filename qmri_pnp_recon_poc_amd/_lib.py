@@ -21,7 +21,7 @@ SYMBOLS = [
     "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
-    "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_onnx_read_unetres",
+    "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_debug_conv_resident", "qmri_onnx_read_unetres",
     "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi", "qmri_synthesize_tsmi_complex",
 ]
 

@@ -44,6 +44,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     if (p.d_stamps) (void)hipFree(p.d_stamps);
     for (hipGraphExec_t g : p.fwd_graph) if (g) (void)hipGraphExecDestroy(g);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
+    if (p.d_res_flags) (void)hipFree(p.d_res_flags);
     if (p.d_range_flag) (void)hipFree(p.d_range_flag);
     if (p.h_range_flag) (void)hipHostFree(p.h_range_flag);
     if (p.d_act_slots) (void)hipFree(p.d_act_slots);
@@ -123,9 +124,15 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     if (!f) return QMRI_OK;
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
     if (p.h_range_flag) std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
+    tripped = true;
+    if (f & 4u) {                                                   // (never seen) a hand-off of the resident-tile launch timed out: its results are garbage, and so
+        fprintf(stderr, "libqmri: a tile hand-off of the resident-tile convolution launch timed out; repeating with one launch per layer\n");   // may the other bits be
+        p.res_off = true;
+        p.res_timeouts += 1;
+        return QMRI_OK;
+    }
     QMRI_TRY(net_set_scheme(ctx, 3));
     p.fallbacks += 1;
-    tripped = true;
     return QMRI_OK;
 }
 
@@ -157,6 +164,8 @@ static int net_forward_padded(qmri_ctx* ctx, int B);
 // bf16 scheme (no range limits) from the start.  (The run-time overflow guard stays: it covers inputs the probe did not see.)
 static int net_calibrate_scheme(qmri_ctx* ctx) {
     NetPlan& p = ctx->net;
+    struct ResOff { NetPlan& n; bool was; ~ResOff() { n.res_off = was; } } res_guard{p, p.res_off};
+    p.res_off = true;                                                // (one launch per layer here: same bits, and a hand-off time-out could not be told from a range problem)
     const size_t n = (size_t)p.desc.in_nc * p.H * p.W, nout = p.out32.batch_stride();
     std::vector<float> h(n);
     uint32_t st = 0x2545F491u;
@@ -265,6 +274,13 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
             QMRI_TRY(alloc_tensor(ctx, p.a[l], nc[l], cal, H >> l, W >> l, B));
             QMRI_TRY(alloc_tensor(ctx, p.t[l], nc[l], cal, H >> l, W >> l, B));
         }
+        if (nc[0] == 64 && H % 16 == 0 && W % 16 == 0 && (H / 16) * (W / 16) <= 1024) {                   // k_conv6r's second scratch tensor and counters (one slice)
+            QMRI_TRY(alloc_tensor(ctx, p.t2, nc[0], p.t[0].Cal, H, W, 1));
+            p.res_flag_tiles = (H / 16) * (W / 16);
+            QMRI_TRY(dev_alloc(ctx, &p.d_res_flags, (size_t)p.res_flag_tiles * 32));
+            QMRI_HIP(ctx, hipMemset(p.d_res_flags, 0, (size_t)p.res_flag_tiles * 32 * sizeof(unsigned)));
+            p.res_epoch = 0; p.res_off = false;
+        }
     } else {
         const int width = desc->nc[0];
         if (nb == 1) QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, desc->out_nc, w));
@@ -305,6 +321,12 @@ static int run_conv(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const
 static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, const PTensor& src, const PTensor& cur, const PTensor& tmp,
                          const PTensor* skip) {
     NetPlan& p = ctx->net;
+    if (p.t2.p && tmp.H == p.t2.H && tmp.W == p.t2.W && !p.force_f32) {   // the full-resolution level: one launch with resident tiles where it applies
+        bool done = false;
+        p.t2.blk = tmp.blk;
+        QMRI_TRY(conv6r_try(ctx, &p.layers[li], 2 * nb, B, src, cur, tmp, p.t2, skip, &done));
+        if (done) { li += (size_t)(2 * nb); return QMRI_OK; }
+    }
     const PTensor* in = &src;
     for (int b = 0; b < nb; ++b) {
         QMRI_TRY(run_conv(ctx, p.layers[li++], B, *in, tmp, nullptr, nullptr, 1));
@@ -420,6 +442,23 @@ extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, flo
         bool again = false;
         QMRI_TRY(net_range_tripped(ctx, again));
         if (!again) break;
+    }
+    return QMRI_OK;
+}
+
+// test / A-B hook: the resident-tile launch of the full-resolution ResBlocks (conv6_kernels.hip k_conv6r)
+extern "C" int qmri_debug_conv_resident(qmri_ctx* ctx, int on, int* timeouts_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    NetPlan& p = ctx->net;
+    if (timeouts_out) *timeouts_out = p.res_timeouts;
+    if (!p.ready) return QMRI_OK;
+    p.res_off = (on == 0);
+    p.res_drop = (on == 2);
+    if (on && p.d_res_flags) {                                      // a fresh start of the counters (a timed-out launch left them uneven)
+        QMRI_HIP(ctx, hipSetDevice(ctx->device));
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        QMRI_HIP(ctx, hipMemset(p.d_res_flags, 0, (size_t)p.res_flag_tiles * 32 * sizeof(unsigned)));
+        p.res_epoch = 0;
     }
     return QMRI_OK;
 }

@@ -66,7 +66,7 @@ __device__ __forceinline__ void act_check_layer(const ActCheckArgs& a, int layer
         }
         if (a.host_words) {
             a.host_words[1 + layer] = low ? 2u : 0u;
-            if (layer == 0) a.host_words[0] = __hip_atomic_load(a.range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;   // (bit 0: set by kernels that are over)
+            if (layer == 0) a.host_words[0] = __hip_atomic_load(a.range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 5u;   // (bits 0 and 2 -- overflow, k_conv6r hand-off time-out: set by kernels that are over)
         }
     }
 }

@@ -1208,6 +1208,339 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 }
 
 // =====================================================================================================================
+// k_conv6r : the ResBlocks of the full-resolution level (64 channels) in ONE launch, every workgroup's tile RESIDENT in LDS.
+//
+// A 3x3 layer launched alone (k_conv6, one slice) is a serial chain: first operands 2 us -> 12 steps whose pace the loader waves set
+// (activations: request, split, store) -> epilogue stores 2.3 - 4 us -> kernel boundary 2 us; and the tile a workgroup writes is, but
+// for a one-pixel ring, the tile the same workgroup reads in the next layer.  Here a workgroup keeps its 18 x 18 x 64 input tile in
+// LDS as f16 pieces (109 KB next to the 36 KB of weight buffers) for all 2 nb layers of a run of ResBlocks (basicblock.py:211-223):
+//   * the loop streams WEIGHTS only (the loader waves run straight across layer ends: the next layer's first steps are in LDS before
+//     the previous layer's epilogue starts);
+//   * the epilogue splits the outputs and writes them IN PLACE into the resident tile (the input is dead once the loop is over);
+//     ResBlock outputs also go to memory as fp32 (they are residual operands -- read back by this workgroup alone -- and the run's
+//     result), the ReLU intermediates never leave the chip;
+//   * the one-pixel ring comes from the eight neighbouring workgroups through memory: each tile stores its 60 edge pixels as pieces
+//     (15 KB) into a scratch tensor of the layer's parity and raises its counter; a tile polls its neighbours' counters and loads its
+//     68-pixel ring (17 KB; the image border reads the tensor's permanent zero halo).  Hand-off form: 16-byte sc1 stores -> every storing
+//     wave's vmcnt(0) -> workgroup barrier -> one lane's agent-scope add; consumer: each loader wave polls for itself (sc1 loads),
+//     then sc1 16-byte loads (MI355X_MICROARCH.md, valid forms, first row).  Two scratch tensors in turn make the exchange race-free:
+//     a tile overwrites its layer-l edges at layer l + 2, which it reaches only after its neighbours published layer l + 1, i.e. after
+//     they consumed layer l.
+// All 196 workgroups must be resident at once (one per CU by LDS size; the host checks tiles <= CUs).  A poll that does not succeed in
+// R_SPIN_MAX tries raises bit 2 of the range flag and the workgroup runs on without waiting (so nobody waits for IT); the host then
+// repeats the call with one launch per layer and keeps this path off.
+// Arithmetic, operand order and rounding are those of k_conv6: results are bit-identical (tests/test_gpu_net.py).
+// =====================================================================================================================
+constexpr int R_MAXL = 8;                                   // layers per launch (2 nb)
+constexpr int R_IH = 18, R_IW = 18, R_IHP = 24;             // input tile with ring; LDS row pitch (= 8 mod 16 entries, as in k_conv6)
+constexpr int R_NPX = R_IHP * (R_IW - 1) + R_IH;            // LDS entries per (split, k-half) plane
+constexpr int R_CHUNK = 2 * 2 * R_NPX;                      // ... per 16-channel chunk: [split][k-half][R_NPX]
+constexpr int R_AST = ast6(2);
+constexpr int R_NSTEP = 12;                                 // 4 chunks x 3 steps
+constexpr int R_SPIN_MAX = 1 << 16;
+constexpr int R_FLAG_STRIDE = 32;                           // words between the counters of two tiles (a 128-byte line each)
+constexpr size_t conv6r_lds() { return (size_t)(NABUF * R_AST + 4 * R_CHUNK) * 16; }
+
+struct Conv6rArgs {
+    const float* src; float* cur; const float* skip;        // BLOCKED fp32 tensors (fbase): input of the first ResBlock, the ResBlocks' outputs, what the last conv adds (or null)
+    float* halo[2];                                         // BLOCKED scratch tensors holding PIECES: only the tiles' edge pixels are ever written
+    const uint4* wp[R_MAXL];
+    float dh[R_MAXL], dl[R_MAXL];                           // descale of the layer's packed weights (Conv6Args::descale_hi / _lo)
+    int am_layer[R_MAXL];                                   // row of the |output| report, -1: none
+    int nlayers, hp, plane, tiles_h, tiles_w, xcd;
+    int drop;                                               // test hook: tile (0, 0) never raises its counter
+    unsigned* flags; unsigned epoch;                        // per-tile counters (R_FLAG_STRIDE apart); their value before this launch
+    unsigned* range_flag; float* am_slots; int* am_count;
+};
+
+template <int N> __device__ __forceinline__ void gwait_a(u32x4 (&a)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N) : "memory"); }
+__device__ __forceinline__ void gload4r_sc1(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gstore4r(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(x), "s"(base) : "memory"); }
+__device__ __forceinline__ void gstore4r_sc1(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(x), "s"(base) : "memory"); }
+
+__global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
+    constexpr int SP = 2, AST = R_AST, IHP = R_IHP, NPX = R_NPX, NAQ = 3;
+    static_assert(AST == NAQ * NLD6, "one weight step = three 16-byte entries per loader thread");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* Abuf = (uint4*)smem;                                     // [NABUF][AST]
+    uint4* Bt = Abuf + NABUF * AST;                                 // [4 chunks][SP][2 k-halves][NPX]: the resident tile
+    const int tid = threadIdx.x;
+    const int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int th = bid % A.tiles_h, tw = bid / A.tiles_h;
+    const int oh0 = th * 16, ow0 = tw * 16;
+    const int nl = A.nlayers;
+    const unsigned plane32 = (unsigned)A.plane * 32u;               // bytes between channel blocks
+    const unsigned tile0 = (unsigned)((ow0 * A.hp + oh0) * 32);     // byte offset of the tile's ring origin (relative to fbase)
+
+    if (tid >= NT6 - NLD6) {
+        // ------------------------------------------------------------------ loaders
+        const int lt = tid - (NT6 - NLD6), lane = lt & 63;
+        __builtin_amdgcn_s_setprio(2);
+        constexpr unsigned ASTB = AST * 16;
+        unsigned aoff[NAQ];
+#pragma unroll
+        for (int q = 0; q < NAQ; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);
+        // the weight stream: steps 0 .. 12 nl - 1 across layers, requested four steps ahead of the step the matrix waves are in
+        int rq_l = 0, rq_s = 0;
+        u32x4 srdW = make_srd(A.wp[0]);
+#define R_REQ(ra_)                                                                                               \
+        {                                                                                                        \
+            const unsigned so_ = (unsigned)rq_s * ASTB;                                                          \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) bload4(ra_[q], aoff[q], srdW, so_);                  \
+            if (++rq_s == R_NSTEP) {                                                                             \
+                if (rq_l + 1 < nl) { ++rq_l; rq_s = 0; srdW = make_srd(A.wp[rq_l]); }                            \
+                else rq_s = R_NSTEP - 1;             /* past the end: the last step again (stored where nobody reads) */ \
+            }                                                                                                    \
+        }
+#define R_STORE_A(buf_, ra_)                                                                                     \
+        {                                                                                                        \
+            uint4* ad = Abuf + (buf_) * AST;                                                                     \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) *(uint4*)((unsigned char*)ad + aoff[q]) = __builtin_bit_cast(uint4, ra_[q]); \
+        }
+        u32x4 ra0[NAQ], ra1[NAQ], ra2[NAQ];
+        {
+            u32x4 pa1[NAQ];
+            R_REQ(ra0) R_REQ(pa1) R_REQ(ra1) R_REQ(ra2)             // steps 0 .. 3
+            // the whole input tile with its ring, fp32 -> pieces: 8 channel blocks x 324 pixels x 2 halves, 21 per thread in three batches
+            constexpr int NHALF = 8 * R_IH * R_IW * 2;
+#pragma unroll 1
+            for (int batch = 0; batch < 3; ++batch) {
+                f32x4 v[7];
+                unsigned lo[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const int idx = lt + NLD6 * (batch * 7 + k);
+                    const bool valid = idx < NHALF;
+                    const int idc = valid ? idx : 0, half = idc & 1, item = idc >> 1;
+                    const int cb = item / (R_IH * R_IW), px = item - cb * (R_IH * R_IW), dw = px / R_IH, dh = px - dw * R_IH;
+                    gload4r(v[k], (unsigned)cb * plane32 + (unsigned)((dw * A.hp + dh) * 32 + 16 * half) + tile0, A.src);
+                    lo[k] = valid ? (unsigned)(((cb >> 1) * R_CHUNK + (cb & 1) * NPX + dw * IHP + dh) * 16 + 8 * half) : ~0u;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6])::"memory");
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    uint2 s0, s1;
+                    split_pair_h(v[k][0], v[k][1], s0.x, s1.x);
+                    split_pair_h(v[k][2], v[k][3], s0.y, s1.y);
+                    if (lo[k] != ~0u) {
+                        *(uint2*)((unsigned char*)Bt + lo[k]) = s0;
+                        *(uint2*)((unsigned char*)Bt + lo[k] + 2 * NPX * 16) = s1;
+                    }
+                }
+            }
+            gwait_a<0>(ra0); gwait_a<0>(pa1);
+            R_STORE_A(0, ra0) R_STORE_A(1, pa1)
+        }
+        // this thread's share of the edge pixels it publishes (60 pixels x 16 entries, 4 per thread) and of the ring it fetches (68 x 16, 5 per
+        // thread): LDS byte offset and byte offset in the scratch tensor; ~0u = none.  An entry = the 8 hi or the 8 lo' pieces of one channel
+        // block at one pixel = half a 32-byte item of the tensor.
+        unsigned e_lds[4], e_g[4], r_lds[5], r_g[5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lt + NLD6 * q;
+            const bool valid = idx < 60 * 16;
+            const int idc = valid ? idx : 0, sp = idc & 1, rest = idc >> 1, cb = rest / 60, e = rest - cb * 60;
+            int w, h;
+            if (e < 16) { w = 0; h = e; } else if (e < 32) { w = 15; h = e - 16; } else if (e < 46) { h = 0; w = e - 31; } else { h = 15; w = e - 45; }
+            e_lds[q] = (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * NPX + (cb & 1) * NPX + (w + 1) * IHP + (h + 1)) * 16);
+            e_g[q] = valid ? (unsigned)cb * plane32 + (unsigned)(((w + 1) * A.hp + (h + 1)) * 32 + 16 * sp) + tile0 : ~0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int idx = lt + NLD6 * q;
+            const bool valid = idx < 68 * 16;
+            const int idc = valid ? idx : 0, sp = idc & 1, rest = idc >> 1, cb = rest / 68, r = rest - cb * 68;
+            int dw, dh;
+            if (r < 18) { dw = 0; dh = r; } else if (r < 36) { dw = 17; dh = r - 18; } else if (r < 52) { dh = 0; dw = r - 35; } else { dh = 17; dw = r - 51; }
+            r_lds[q] = valid ? (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * NPX + (cb & 1) * NPX + dw * IHP + dh) * 16) : ~0u;
+            r_g[q] = (unsigned)cb * plane32 + (unsigned)((dw * A.hp + dh) * 32 + 16 * sp) + tile0;
+        }
+        // lanes 0 .. 7 of every loader wave watch one neighbour each
+        const int ni = (lane < 8) ? lane : 0;
+        const int dtw = (ni < 3) ? -1 : (ni < 5) ? 0 : 1, dth = (ni < 3) ? ni - 1 : (ni == 3) ? -1 : (ni == 4) ? 1 : ni - 6;
+        const bool need = lane < 8 && tw + dtw >= 0 && tw + dtw < A.tiles_w && th + dth >= 0 && th + dth < A.tiles_h;
+        const unsigned* fp = A.flags + (size_t)(need ? (tw + dtw) * A.tiles_h + th + dth : tw * A.tiles_h + th) * R_FLAG_STRIDE;
+        bool dead = false;                                          // a poll timed out: no more waiting in this workgroup
+        lds_barrier6();                                             // barrier 0: step 0 may start
+#define R_ITER(k_, rs_, rq_)     /* stores step g + k_ + 2 into its buffer, requests step g + k_ + 4 */          \
+        {                                                                                                        \
+            __builtin_amdgcn_s_setprio(2);                                                                       \
+            R_REQ(rq_)                                                                                           \
+            __builtin_amdgcn_s_setprio(0);                                                                       \
+            gwait_a<2 * NAQ>(rs_);                                                                               \
+            R_STORE_A(((k_) + 2) % NABUF, rs_)                                                                   \
+            lds_barrier6();                                                                                      \
+        }
+#pragma unroll 1
+        for (int l = 0; l < nl; ++l) {
+#pragma unroll 1
+            for (int g = 0; g < R_NSTEP; g += 3) {
+                R_ITER(0, ra1, ra0)
+                R_ITER(1, ra2, ra1)
+                R_ITER(2, ra0, ra2)
+            }
+            if (l == nl - 1) break;
+            lds_barrier6();                                         // E2: the matrix waves have written this layer's output into the tile
+            float* hb = A.halo[l & 1];
+            {
+                u32x4 ev[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ev[q] = __builtin_bit_cast(u32x4, *(const uint4*)((const unsigned char*)Bt + e_lds[q]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (e_g[q] != ~0u) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(e_g[q]), "v"(ev[q]), "s"(hb) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's edge stores are acknowledged (and its weight requests have arrived)
+            lds_barrier6();                                         // E2b: ... and every other wave's
+            if (lt == 0 && !(A.drop && th == 0 && tw == 0)) __hip_atomic_fetch_add(A.flags + (size_t)(tw * A.tiles_h + th) * R_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!dead) {
+                const unsigned target = A.epoch + (unsigned)l + 1u;
+                bool ok = false;
+                for (int spin = 0; spin < R_SPIN_MAX; ++spin) {
+                    const unsigned v = need ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                    if (__all((int)(v - target) >= 0)) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!ok) { dead = true; if (lane == 0 && A.range_flag) atomicOr(A.range_flag, 4u); }
+            }
+            {
+                u32x4 rv[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(rv[q]) : "v"(r_g[q]), "s"(hb) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4])::"memory");
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    if (r_lds[q] != ~0u) *(uint4*)((unsigned char*)Bt + r_lds[q]) = __builtin_bit_cast(uint4, rv[q]);
+            }
+            lds_barrier6();                                         // E3: the tile is the next layer's input
+        }
+        gwait_a<0>(ra0); gwait_a<0>(ra1); gwait_a<0>(ra2);          // (clamped requests past the end are still in flight)
+#undef R_ITER
+#undef R_REQ
+#undef R_STORE_A
+        return;
+    }
+    // ---------------------------------------------------------------------- MFMA waves (tile configuration 0: 64 cout x 64 pixels each, side by side in w)
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, h2 = lane >> 5;
+    const int pbw = 4 * wave;
+    const int pxl = (pbw + (li >> 3)) * IHP + (li & 7);             // LDS entry of this lane's pixel at tap (0,0), pixel block 0
+    // byte offset (relative to fbase) of this lane's 4 channels of block 0 at its pixel of pixel block 0; + 8 rows per pixel block, + plane32 per channel block
+    const unsigned gpx = (unsigned)(((ow0 + pbw + (li >> 3) + 1) * A.hp + (oh0 + (li & 7)) + 1) * 32 + 16 * h2);
+    lds_barrier6();                                                 // barrier 0
+#pragma unroll 1
+    for (int l = 0; l < nl; ++l) {
+        f32x16 acc[2][2], accl[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.f; accl[m][n][r] = 0.f; }
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            const uint4* ab = Abuf + lane;
+            const uint4* bb = Bt + c * R_CHUNK + h2 * NPX + pxl;
+            u32x4 bf[2][2][SP], af[2][2][SP];
+            auto frag_a = [&](int T, int set, int m, int sp) __attribute__((always_inline)) {
+                const int kh = T / 3, kw = T - 3 * kh;
+                af[set][m][sp] = __builtin_bit_cast(u32x4, ab[kh * AST + ((kw * 2 + m) * SP + sp) * 64]);
+            };
+            auto frag_b = [&](int T, int set, int n, int sp) __attribute__((always_inline)) {
+                const int kh = T / 3, kw = T - 3 * kh;
+                bf[set][n][sp] = __builtin_bit_cast(u32x4, bb[sp * 2 * NPX + kw * IHP + kh + 8 * n]);
+            };
+            auto frags = [&](int T, int set) __attribute__((always_inline)) {      // in the order the MFMAs consume (k_conv6)
+                frag_a(T, set, 0, 0); frag_b(T, set, 0, 0); frag_a(T, set, 0, 1); frag_b(T, set, 0, 1);
+                frag_b(T, set, 1, 0); frag_b(T, set, 1, 1);
+                frag_a(T, set, 1, 0); frag_a(T, set, 1, 1);
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int T = 0; T < 9; ++T) {
+                const int cur = T & 1;
+                if (T < 8) frags(T + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = mfma_h(af[cur][m][0], bf[cur][n][0], acc[m][n]);
+                        f32x16 l_ = accl[m][n];
+                        l_ = mfma_h(af[cur][m][1], bf[cur][n][0], l_);
+                        l_ = mfma_h(af[cur][m][0], bf[cur][n][1], l_);
+                        accl[m][n] = l_;
+                    }
+                if (T % 3 == 2) lds_barrier6();                     // end of step 3 c + T / 3 (the last one: every wave is done with the tile)
+            }
+        }
+        // ---- epilogue in registers.  C/D layout: column = lane & 31 = pixel, rows 8 rg + 4 h2 + j = output channels: one lane holds
+        // four consecutive channels (half a channel block: cb = 4 m + rg, half h2) of its pixel per (m, n, rg)
+        const bool conv2 = (l & 1) != 0, last = l == nl - 1;
+        const float dh_ = A.dh[l], dl_ = A.dl[l];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = acc[m][n][r] * dh_ + accl[m][n][r] * dl_;      // (powers of two: exact)
+        for (int pass = 0; pass < 2; ++pass) {                      // residual operands: the block input (every second layer), then the skip tensor (last layer)
+            const float* rp = (pass == 0) ? (conv2 ? ((l == 1) ? A.src : (const float*)A.cur) : nullptr) : ((last && conv2) ? A.skip : nullptr);
+            if (!rp) continue;                                      // (uniform)
+            f32x4 res[2][2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) gload4r_sc1(res[m][n][rg], gpx + (unsigned)(4 * m + rg) * plane32 + (unsigned)(8 * n * 32), rp);
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(res[0][0][0]), "+v"(res[0][0][1]), "+v"(res[0][0][2]), "+v"(res[0][0][3]), "+v"(res[0][1][0]), "+v"(res[0][1][1]),
+                           "+v"(res[0][1][2]), "+v"(res[0][1][3]), "+v"(res[1][0][0]), "+v"(res[1][0][1]), "+v"(res[1][0][2]), "+v"(res[1][0][3]),
+                           "+v"(res[1][1][0]), "+v"(res[1][1][1]), "+v"(res[1][1][2]), "+v"(res[1][1][3])::"memory");
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] += res[m][n][r >> 2][r & 3];
+        }
+        bool bad = false;
+        float tmax = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 x;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] = acc[m][n][4 * rg + j]; if (!conv2) x[j] = fmaxf(x[j], 0.f); }
+                    const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+                    bad |= !(gm <= F16_RANGE);                      // (also NaN)
+                    tmax = fmaxf(tmax, gm);
+                    if (!last) {                                    // the next layer's operand, in place
+                        uint2 s0, s1;
+                        split_pair_h(x[0], x[1], s0.x, s1.x);
+                        split_pair_h(x[2], x[3], s0.y, s1.y);
+                        unsigned char* bd = (unsigned char*)Bt + (((2 * m + (rg >> 1)) * R_CHUNK + (rg & 1) * NPX + pxl + IHP + 1 + 8 * n) * 16 + 8 * h2);
+                        *(uint2*)bd = s0;
+                        *(uint2*)(bd + 2 * NPX * 16) = s1;
+                    }
+                    if (conv2) {                                    // a ResBlock's output: the next block's residual operand (this workgroup reads it back, sc1) / the run's result
+                        const unsigned go = gpx + (unsigned)(4 * m + rg) * plane32 + (unsigned)(8 * n * 32);
+                        if (last) gstore4r_sc1(go, x, A.cur); else gstore4r(go, x, A.cur);
+                    }
+                }
+        if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+        act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, tmax, 4);
+        if (last) break;
+        lds_barrier6();                                             // E2
+        lds_barrier6();                                             // E2b
+        lds_barrier6();                                             // E3
+    }
+}
+
+// =====================================================================================================================
 // k_conv6s : the 2x2 / stride-2 layers on the same operand-splitting schemes.
 //   DOWN  Conv2d(k=2, s=2)           out[co][oh][ow]       = sum_ci,kh,kw w[co][ci][kh][kw] in[ci][2oh+kh][2ow+kw]
 //   UP    ConvTranspose2d(k=2, s=2)  out[co][2ih+kh][2iw+kw] = sum_ci     w[ci][co][kh][kw] in[ci][ih][iw]
@@ -2091,4 +2424,57 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
     }
     if (L.nchunk6 >= 16 && L.Cout % 64 == 0 && ((in.H <= 32) ? deep_cfg_g : mid_cfg) == 3) return launch6<3>(ctx, L, B, in, out, add1, add2, relu_out);
     return launch6<2>(ctx, L, B, in, out, add1, add2, relu_out);
+}
+
+// The ResBlocks of one level as ONE launch with resident tiles (k_conv6r): layers Ls[0 .. nl), run input `src`, ResBlock outputs in `cur`, `skip`
+// added by the last layer; `h0`, `h1` are BLOCKED scratch tensors of the level's geometry.  *done = false: not eligible, nothing launched.
+int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor& h0, const PTensor& h1,
+               const PTensor* skip, bool* done) {
+    *done = false;
+    NetPlan& net = ctx->net;
+    static const int resident = getenv("QMRI_CONV_RESIDENT") ? atoi(getenv("QMRI_CONV_RESIDENT")) : 1;
+    static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;     // (a captured launch would replay a stale counter value)
+    if (!resident || graph_replay || net.res_off || !net.d_res_flags || B != 1 || nl < 2 || nl > R_MAXL || (nl & 1) || net.d_stamps || ctx->prof_level >= 2) return QMRI_OK;
+    for (int l = 0; l < nl; ++l) {
+        const ConvLayer& L = Ls[l];
+        if ((L.kind != CONV_3X3 && L.kind != CONV_3X3N) || L.Cin != 64 || L.Cout != 64 || L.sp6 != 2 || !L.wp6 || L.nchunk6 != 4 || L.n_ct6 != 1) return QMRI_OK;
+    }
+    const PTensor* ts[5] = {&src, &cur, &h0, &h1, skip};
+    for (const PTensor* t : ts) {
+        if (!t) continue;
+        if (!t->p || !t->blk || t->Cal < 64 || t->H != src.H || t->W != src.W || t->hp != src.hp || t->h0 != src.h0) return QMRI_OK;
+    }
+    if (src.H % 16 || src.W % 16 || h0.p == h1.p || h0.p == cur.p || h1.p == cur.p || h0.p == src.p || h1.p == src.p) return QMRI_OK;
+    if ((size_t)src.Cal * src.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;       // (32-bit byte offsets)
+    if (!ctx->conv_ncu) {
+        hipDeviceProp_t prop;
+        QMRI_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->conv_ncu = prop.multiProcessorCount;
+    }
+    const int tiles_h = src.H / 16, tiles_w = src.W / 16, tiles = tiles_h * tiles_w;
+    if (tiles > ctx->conv_ncu || tiles > net.res_flag_tiles) return QMRI_OK;             // every workgroup must be resident: one per CU
+    Conv6rArgs A{};
+    A.src = src.fbase(); A.cur = cur.fbase(); A.skip = skip ? skip->fbase() : nullptr;
+    A.halo[0] = h0.fbase(); A.halo[1] = h1.fbase();
+    for (int l = 0; l < R_MAXL; ++l) {
+        const ConvLayer& L = Ls[l < nl ? l : nl - 1];
+        A.wp[l] = reinterpret_cast<const uint4*>(L.wp6);
+        A.dh[l] = L.w6_descale; A.dl[l] = L.w6_descale * (1.f / LO_SCALE);
+        A.am_layer[l] = (l < nl) ? conv6_act_slot(ctx, true, L).layer : -1;
+    }
+    A.nlayers = nl; A.hp = src.hp; A.plane = (int)src.plane(); A.tiles_h = tiles_h; A.tiles_w = tiles_w;
+    static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
+    A.xcd = xcd_order;
+    A.flags = net.d_res_flags; A.epoch = net.res_epoch; A.drop = net.res_drop ? 1 : 0;
+    A.range_flag = net.d_range_flag; A.am_slots = net.d_act_slots; A.am_count = net.d_act_count;
+    if (!ctx->conv6r_attr) {
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6r_lds()));
+        ctx->conv6r_attr = true;
+    }
+    g_launch_counter.fetch_add(nl, std::memory_order_relaxed);
+    k_conv6r<<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
+    QMRI_HIP(ctx, hipGetLastError());
+    net.res_epoch += (unsigned)(nl - 1);                            // every tile's counter: one add per layer but the last
+    *done = true;
+    return QMRI_OK;
 }

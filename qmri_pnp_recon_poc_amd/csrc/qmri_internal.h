@@ -197,6 +197,15 @@ struct NetPlan {
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
+    // resident-tile ResBlock runs (conv6_kernels.hip k_conv6r): a second scratch tensor at the full-resolution level, the tiles' hand-off counters
+    // (never reset: a launch is told their value before it), and the switch a timed-out hand-off turns off for the life of the plan
+    PTensor t2;
+    unsigned* d_res_flags = nullptr;
+    int res_flag_tiles = 0;
+    unsigned res_epoch = 0;
+    bool res_off = false;
+    int res_timeouts = 0;
+    bool res_drop = false;           // test hook: tile 0 withholds its hand-off
     bool ready = false;
 };
 
@@ -273,6 +282,7 @@ struct qmri_ctx {
     bool conv6_attr[4][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
     bool conv6i_attr[4] = {false, false, false, false};   // ... of k_conv6i<CFG> (PIECES input)
+    bool conv6r_attr = false;           // ... of k_conv6r
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
     int ks_persist = -1;                // k_ks_persist (all LSQR iterations in one launch): -1 = QMRI_LSQR_PERSIST (default on), 0 / 1 set by qmri_debug_lsqr_persist
@@ -347,6 +357,9 @@ bool conv6_weights_fit_f16(const float* w, size_t n);
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out);
+// a run of nl 64-channel 3x3 layers (ResBlocks) as one launch with LDS-resident tiles; *done = false: not eligible, nothing launched
+int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor& h0, const PTensor& h1,
+               const PTensor* skip, bool* done);
 void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);   // 2x2 / stride-2 layers
 bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out);
 int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out);

@@ -203,6 +203,14 @@ class Engine:
         self.L.qmri_debug_dict_filter.argtypes = [C.c_void_p, C.c_int, C.c_float]
         self._check(self.L.qmri_debug_dict_filter(self.h, int(bool(on)), float(margin_scale)))
 
+    def conv_resident(self, on=True):
+        """Test / A-B hook (qmri_debug_conv_resident): the full-resolution ResBlocks as one launch with LDS-resident tiles (default) or one
+        launch per layer; on = 2: a tile withholds its hand-off (recovery path).  Returns the hand-off time-outs seen so far."""
+        n = C.c_int(0)
+        self.L.qmri_debug_conv_resident.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self._check(self.L.qmri_debug_conv_resident(self.h, 2 if on == 2 else int(bool(on)), C.byref(n)))
+        return n.value
+
     def denoiser_scheme(self):
         """(scheme, fallbacks): 2 = f16 x 3 products, 3 = bf16 x 6 products; how often a run-time guard switched 2 -> 3."""
         sc, fb = C.c_int(0), C.c_int(0)
