@@ -44,7 +44,8 @@ void qmri_free_net(qmri_ctx* ctx) {
     if (p.d_stamps) (void)hipFree(p.d_stamps);
     for (hipGraphExec_t g : p.fwd_graph) if (g) (void)hipGraphExecDestroy(g);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
-    if (p.d_res_flags) (void)hipFree(p.d_res_flags);
+    if (p.d_res_xbuf) (void)hipFree(p.d_res_xbuf);
+    if (p.d_res_stamps) (void)hipFree(p.d_res_stamps);
     if (p.d_range_flag) (void)hipFree(p.d_range_flag);
     if (p.h_range_flag) (void)hipHostFree(p.h_range_flag);
     if (p.d_act_slots) (void)hipFree(p.d_act_slots);
@@ -274,12 +275,12 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
             QMRI_TRY(alloc_tensor(ctx, p.a[l], nc[l], cal, H >> l, W >> l, B));
             QMRI_TRY(alloc_tensor(ctx, p.t[l], nc[l], cal, H >> l, W >> l, B));
         }
-        if (nc[0] == 64 && H % 16 == 0 && W % 16 == 0 && (H / 16) * (W / 16) <= 1024) {                   // k_conv6r's second scratch tensor and counters (one slice)
-            QMRI_TRY(alloc_tensor(ctx, p.t2, nc[0], p.t[0].Cal, H, W, 1));
-            p.res_flag_tiles = (H / 16) * (W / 16);
-            QMRI_TRY(dev_alloc(ctx, &p.d_res_flags, (size_t)p.res_flag_tiles * 32));
-            QMRI_HIP(ctx, hipMemset(p.d_res_flags, 0, (size_t)p.res_flag_tiles * 32 * sizeof(unsigned)));
+        if (nc[0] == 64 && H % 16 == 0 && W % 16 == 0 && (H / 16) * (W / 16) <= 1024) {                   // k_conv6r's exchange buffer (one slice)
+            p.res_tiles = (H / 16) * (W / 16);
+            QMRI_TRY(dev_alloc(ctx, &p.d_res_xbuf, conv6r_xbuf_bytes(p.res_tiles)));
+            QMRI_HIP(ctx, hipMemset(p.d_res_xbuf, 0, conv6r_xbuf_bytes(p.res_tiles)));
             p.res_epoch = 0; p.res_off = false;
+            if (getenv("QMRI_RES_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_res_stamps, 512 * sizeof(unsigned long long))); QMRI_HIP(ctx, hipMemset(p.d_res_stamps, 0, 512 * sizeof(unsigned long long))); }
         }
     } else {
         const int width = desc->nc[0];
@@ -321,10 +322,9 @@ static int run_conv(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const
 static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, const PTensor& src, const PTensor& cur, const PTensor& tmp,
                          const PTensor* skip) {
     NetPlan& p = ctx->net;
-    if (p.t2.p && tmp.H == p.t2.H && tmp.W == p.t2.W && !p.force_f32) {   // the full-resolution level: one launch with resident tiles where it applies
+    if (p.d_res_xbuf && src.H == p.H && !p.force_f32) {            // the full-resolution level: one launch with resident tiles where it applies
         bool done = false;
-        p.t2.blk = tmp.blk;
-        QMRI_TRY(conv6r_try(ctx, &p.layers[li], 2 * nb, B, src, cur, tmp, p.t2, skip, &done));
+        QMRI_TRY(conv6r_try(ctx, &p.layers[li], 2 * nb, B, src, cur, skip, &done));
         if (done) { li += (size_t)(2 * nb); return QMRI_OK; }
     }
     const PTensor* in = &src;
@@ -453,13 +453,7 @@ extern "C" int qmri_debug_conv_resident(qmri_ctx* ctx, int on, int* timeouts_out
     if (timeouts_out) *timeouts_out = p.res_timeouts;
     if (!p.ready) return QMRI_OK;
     p.res_off = (on == 0);
-    p.res_drop = (on == 2);
-    if (on && p.d_res_flags) {                                      // a fresh start of the counters (a timed-out launch left them uneven)
-        QMRI_HIP(ctx, hipSetDevice(ctx->device));
-        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        QMRI_HIP(ctx, hipMemset(p.d_res_flags, 0, (size_t)p.res_flag_tiles * 32 * sizeof(unsigned)));
-        p.res_epoch = 0;
-    }
+    p.res_drop = (on == 2) ? 1 : (on >= 256 ? (on & ~0xFF) : 0);       // (on >= 256: experiment fields, bits 8-15 / 16-23)
     return QMRI_OK;
 }
 
@@ -990,6 +984,11 @@ extern "C" int qmri_recon_batch(int ndev, const int* devs, int nslices, const qm
 
 // diagnostic: copy the per-workgroup stamps of the most recent conv launch (see conv_kernels.hip) to the host
 extern "C" int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int nwg) {
+    if (ctx && nwg == -6 && ctx->net.d_res_stamps) {                // (the resident-tile launch's stamps: 512 values, QMRI_RES_STAMPS=1)
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        QMRI_HIP(ctx, hipMemcpy(out, ctx->net.d_res_stamps, (size_t)512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return QMRI_OK;
+    }
     if (!ctx || !ctx->net.d_stamps) return QMRI_ERR_STATE;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     QMRI_HIP(ctx, hipMemcpy(out, ctx->net.d_stamps, (size_t)4096 * 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -258,9 +258,14 @@ __device__ __forceinline__ void split_pair_h(float xa, float xb, unsigned& p0, u
     p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){xa, xb}, f16x2)); p1 = p0 ^ 0x03ff03ffu; return;   // (a lo piece that toggles like a real one: zeros would let the matrix cores run cooler and clock higher)      // (timing only: one instruction instead of the split; finite values -- garbage trips the range guard and the run repeats with bf16 pieces)
 #endif
     const f16x2 hi = __builtin_convertvector((f32x2){xa, xb}, f16x2);
-    const float ra = __builtin_fmaf((float)hi[0], -1.0f, xa), rb = __builtin_fmaf((float)hi[1], -1.0f, xb);
-    const f16x2 lo = __builtin_convertvector((f32x2){ra * LO_SCALE, rb * LO_SCALE}, f16x2);
     p0 = __builtin_bit_cast(unsigned, hi);
+    // 2^11 (x - hi) = fma(hi, -2^11, 2^11 x): every step exact (x - hi is representable, the factor a power of two), one v_fma_mix_f32 per value
+    // reading the f16 half in place (hipcc, left alone, converts, subtracts and multiplies: twice the instructions)
+    const f32x2 xs = (f32x2){xa, xb} * (f32x2){LO_SCALE, LO_SCALE};
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p0), "s"(-LO_SCALE), "v"(xs[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p0), "s"(-LO_SCALE), "v"(xs[1]));
+    const f16x2 lo = __builtin_convertvector((f32x2){ra, rb}, f16x2);
     p1 = __builtin_bit_cast(unsigned, lo);
 }
 // PIECES tensors (round 4).  The intermediate tensor of a ResBlock (t = relu(conv1(a)), basicblock.py:211-223) has exactly one reader, the
@@ -1238,26 +1243,40 @@ constexpr int R_CHUNK = 2 * 2 * R_NPX;                      // ... per 16-channe
 constexpr int R_AST = ast6(2);
 constexpr int R_NSTEP = 12;                                 // 4 chunks x 3 steps
 constexpr int R_SPIN_MAX = 1 << 16;
-constexpr int R_FLAG_STRIDE = 32;                           // words between the counters of two tiles (a 128-byte line each)
+constexpr int R_SEGT = 86, R_CORT = 6;                      // triples per edge segment (16 pixels x 16 entries, padded) / per corner pixel
+constexpr int R_NTRI = 4 * R_SEGT + 4 * R_CORT;             // triples (64 bytes each) a tile publishes per layer
 constexpr size_t conv6r_lds() { return (size_t)(NABUF * R_AST + 4 * R_CHUNK) * 16; }
 
 struct Conv6rArgs {
     const float* src; float* cur; const float* skip;        // BLOCKED fp32 tensors (fbase): input of the first ResBlock, the ResBlocks' outputs, what the last conv adds (or null)
-    float* halo[2];                                         // BLOCKED scratch tensors holding PIECES: only the tiles' edge pixels are ever written
+    unsigned char* xbuf; size_t xbuf_half;                  // exchange buffer [2 layer parities][tiles][R_NTRI][64 bytes]; bytes per parity
     const uint4* wp[R_MAXL];
     float dh[R_MAXL], dl[R_MAXL];                           // descale of the layer's packed weights (Conv6Args::descale_hi / _lo)
     int am_layer[R_MAXL];                                   // row of the |output| report, -1: none
     int nlayers, hp, plane, tiles_h, tiles_w, xcd;
-    int drop;                                               // test hook: tile (0, 0) never raises its counter
-    unsigned* flags; unsigned epoch;                        // per-tile counters (R_FLAG_STRIDE apart); their value before this launch
+    int drop;                                               // test hook: tile (0, 0) publishes nothing
+    unsigned epoch;                                         // layers published before this launch: layer l of this launch tags its granules (epoch + l + 1) mod 2^16
     unsigned* range_flag; float* am_slots; int* am_count;
+    unsigned long long* stamps;                             // diagnostic instantiation only
 };
 
 template <int N> __device__ __forceinline__ void gwait_a(u32x4 (&a)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N) : "memory"); }
-__device__ __forceinline__ void gload4r_sc1(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void gstore4r(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(x), "s"(base) : "memory"); }
-__device__ __forceinline__ void gstore4r_sc1(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(x), "s"(base) : "memory"); }
+// (scalar base per channel block + one per-lane offset + an immediate for the pixel block: no per-request address registers)
+// (the s_nop behind every store: a VMEM store of more than 8 bytes needs wait states before its data registers are written again, and the hazard
+//  recognizer does not look inside inline asm -- without it the next value's arithmetic corrupts the store)
+template <int IMM> __device__ __forceinline__ void gload4r_sc1(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1" : "=v"(dst) : "v"(off), "s"(base), "n"(IMM) : "memory"); }
+template <int IMM> __device__ __forceinline__ void gstore4r(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(off), "v"(x), "s"(base), "n"(IMM) : "memory"); }
+template <int IMM> __device__ __forceinline__ void gstore4r_sc1(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(off), "v"(x), "s"(base), "n"(IMM) : "memory"); }
 
+// (STAMP: diagnostic instantiation, QMRI_RES_STAMPS=1 -- tools/conv6r_stamps.py: 100 MHz phase stamps of four workgroups, [wg][matrix wave 0 / loader wave 0][layer][8])
+#define R_STAMP(role, k)                                                                                         \
+    do {                                                                                                         \
+        if constexpr (STAMP) {                                                                                   \
+            if (A.stamps && (threadIdx.x & 255) == 0 && blockIdx.x % 50 == 0 && blockIdx.x / 50 < 4)             \
+                A.stamps[(((blockIdx.x / 50) * 2 + (role)) * R_MAXL + l) * 8 + (k)] = wall_clock64();            \
+        }                                                                                                        \
+    } while (0)
+template <bool STAMP>
 __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
     constexpr int SP = 2, AST = R_AST, IHP = R_IHP, NPX = R_NPX, NAQ = 3;
     static_assert(AST == NAQ * NLD6, "one weight step = three 16-byte entries per loader thread");
@@ -1331,35 +1350,44 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
             gwait_a<0>(ra0); gwait_a<0>(pa1);
             R_STORE_A(0, ra0) R_STORE_A(1, pa1)
         }
-        // this thread's share of the edge pixels it publishes (60 pixels x 16 entries, 4 per thread) and of the ring it fetches (68 x 16, 5 per
-        // thread): LDS byte offset and byte offset in the scratch tensor; ~0u = none.  An entry = the 8 hi or the 8 lo' pieces of one channel
-        // block at one pixel = half a 32-byte item of the tensor.
-        unsigned e_lds[4], e_g[4], r_lds[5], r_g[5];
+        // The ring exchange, per thread and layer: <= 2 TRIPLES to publish and <= 2 to fetch.  A triple = three 16-byte LDS entries (an entry = the 8 hi
+        // or the 8 lo' pieces of one channel block at one pixel) = 24 f16 values = eight 8-byte granules {3 x f16, 16-bit tag} = four 16-byte stores.
+        // A tile publishes eight segments -- its columns w = 0 / 15, its rows h = 0 / 15 (16 pixels x 16 entries, padded to 86 triples) and its four
+        // corner pixels (16 entries, 6 triples) -- into its own 368 x 64 bytes of the exchange buffer of the layer's parity; a tile fetches the
+        // matching segments of its eight neighbours (its left ring column = the left neighbour's column w = 15, ...).  Offsets: ~0u = none.
+        unsigned p_lds[2][3], p_x[2], c_lds[2][3], c_x[2];
+        auto tri_decode = [](int t, int& seg, int& j) { if (t < 4 * R_SEGT) { seg = t / R_SEGT; j = t - seg * R_SEGT; } else { seg = 4 + (t - 4 * R_SEGT) / R_CORT; j = (t - 4 * R_SEGT) - (seg - 4) * R_CORT; } };
+        auto seg_base = [](int seg) { return seg < 4 ? seg * R_SEGT : 4 * R_SEGT + (seg - 4) * R_CORT; };
+        auto ent_lds = [&](int k, int dw, int dh) { const int cb = k >> 1, sp = k & 1; return (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * NPX + (cb & 1) * NPX + dw * IHP + dh) * 16); };
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = lt + NLD6 * q;
-            const bool valid = idx < 60 * 16;
-            const int idc = valid ? idx : 0, sp = idc & 1, rest = idc >> 1, cb = rest / 60, e = rest - cb * 60;
-            int w, h;
-            if (e < 16) { w = 0; h = e; } else if (e < 32) { w = 15; h = e - 16; } else if (e < 46) { h = 0; w = e - 31; } else { h = 15; w = e - 45; }
-            e_lds[q] = (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * NPX + (cb & 1) * NPX + (w + 1) * IHP + (h + 1)) * 16);
-            e_g[q] = valid ? (unsigned)cb * plane32 + (unsigned)(((w + 1) * A.hp + (h + 1)) * 32 + 16 * sp) + tile0 : ~0u;
-        }
+        for (int q = 0; q < 2; ++q) {
+            const int t = lt + NLD6 * q;
+            const bool valid = t < R_NTRI;
+            int seg, j;
+            tri_decode(valid ? t : 0, seg, j);
+            const int npx = seg < 4 ? 16 : 1;
+            // publish: segment `seg` of this tile, pixel p at interior position (w, h)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int idx = lt + NLD6 * q;
-            const bool valid = idx < 68 * 16;
-            const int idc = valid ? idx : 0, sp = idc & 1, rest = idc >> 1, cb = rest / 68, r = rest - cb * 68;
-            int dw, dh;
-            if (r < 18) { dw = 0; dh = r; } else if (r < 36) { dw = 17; dh = r - 18; } else if (r < 52) { dh = 0; dw = r - 35; } else { dh = 17; dw = r - 51; }
-            r_lds[q] = valid ? (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * NPX + (cb & 1) * NPX + dw * IHP + dh) * 16) : ~0u;
-            r_g[q] = (unsigned)cb * plane32 + (unsigned)((dw * A.hp + dh) * 32 + 16 * sp) + tile0;
+            for (int i = 0; i < 3; ++i) {
+                const int E = 3 * j + i, Ec = (E < npx * 16) ? E : 0, pp = Ec >> 4, k = Ec & 15;
+                const int w = (seg == 0) ? 0 : (seg == 1) ? 15 : (seg == 2 || seg == 3) ? pp : (seg < 6 ? 0 : 15);
+                const int h = (seg == 0 || seg == 1) ? pp : (seg == 2) ? 0 : (seg == 3) ? 15 : ((seg & 1) ? 15 : 0);
+                p_lds[q][i] = ent_lds(k, w + 1, h + 1);
+            }
+            p_x[q] = valid ? (unsigned)((tw * A.tiles_h + th) * (R_NTRI * 64) + t * 16) : ~0u;   // (quarter i of a triple: + i * R_NTRI * 16 -- consecutive lanes, consecutive 16 bytes)
+            // fetch: ring segment `seg` <- neighbour (dtw, dth), its segment ns
+            const int dtw = (seg == 0 || seg == 4 || seg == 5) ? -1 : (seg == 1 || seg == 6 || seg == 7) ? 1 : 0;
+            const int dth = (seg == 2 || seg == 4 || seg == 6) ? -1 : (seg == 3 || seg == 5 || seg == 7) ? 1 : 0;
+            const int ns = (seg < 4) ? (seg ^ 1) : 11 - seg;
+            const bool have = valid && tw + dtw >= 0 && tw + dtw < A.tiles_w && th + dth >= 0 && th + dth < A.tiles_h;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int E = 3 * j + i, pp = E >> 4, k = E & 15;
+                const int dw = (dtw < 0) ? 0 : (dtw > 0) ? 17 : pp + 1, dh = (dth < 0) ? 0 : (dth > 0) ? 17 : pp + 1;
+                c_lds[q][i] = (have && E < npx * 16) ? ent_lds(k, dw, dh) : ~0u;
+            }
+            c_x[q] = have ? (unsigned)(((tw + dtw) * A.tiles_h + th + dth) * (R_NTRI * 64) + (seg_base(ns) + j) * 16) : ~0u;
         }
-        // lanes 0 .. 7 of every loader wave watch one neighbour each
-        const int ni = (lane < 8) ? lane : 0;
-        const int dtw = (ni < 3) ? -1 : (ni < 5) ? 0 : 1, dth = (ni < 3) ? ni - 1 : (ni == 3) ? -1 : (ni == 4) ? 1 : ni - 6;
-        const bool need = lane < 8 && tw + dtw >= 0 && tw + dtw < A.tiles_w && th + dth >= 0 && th + dth < A.tiles_h;
-        const unsigned* fp = A.flags + (size_t)(need ? (tw + dtw) * A.tiles_h + th + dth : tw * A.tiles_h + th) * R_FLAG_STRIDE;
         bool dead = false;                                          // a poll timed out: no more waiting in this workgroup
         lds_barrier6();                                             // barrier 0: step 0 may start
 #define R_ITER(k_, rs_, rq_)     /* stores step g + k_ + 2 into its buffer, requests step g + k_ + 4 */          \
@@ -1379,40 +1407,76 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                 R_ITER(1, ra2, ra1)
                 R_ITER(2, ra0, ra2)
             }
+            R_STAMP(1, 0);
             if (l == nl - 1) break;
             lds_barrier6();                                         // E2: the matrix waves have written this layer's output into the tile
-            float* hb = A.halo[l & 1];
-            {
-                u32x4 ev[4];
+            R_STAMP(1, 1);
+            const unsigned tag = (A.epoch + (unsigned)l + 1u) & 0xFFFFu, thi = tag << 16;
+            unsigned char* xb = A.xbuf + (size_t)(l & 1) * A.xbuf_half;
+            if (!((A.drop & 1) && th == 0 && tw == 0)) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ev[q] = __builtin_bit_cast(u32x4, *(const uint4*)((const unsigned char*)Bt + e_lds[q]));
+                for (int q = 0; q < 2; ++q) {
+                    if (p_x[q] == ~0u) continue;
+                    unsigned d[12];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (e_g[q] != ~0u) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(e_g[q]), "v"(ev[q]), "s"(hb) : "memory");
+                    for (int i = 0; i < 3; ++i) {
+                        const uint4 e = *(const uint4*)((const unsigned char*)Bt + p_lds[q][i]);
+                        d[4 * i] = e.x; d[4 * i + 1] = e.y; d[4 * i + 2] = e.z; d[4 * i + 3] = e.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {                   // two granules per store: {F0 F1 | F2 tag} {F3 F4 | F5 tag}
+                        u32x4 g;
+                        g[0] = d[3 * i];
+                        g[1] = (d[3 * i + 1] & 0xFFFFu) | thi;
+                        g[2] = (d[3 * i + 1] >> 16) | (d[3 * i + 2] << 16);
+                        g[3] = (d[3 * i + 2] >> 16) | thi;
+                        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(p_x[q]), "v"(g), "s"(xb + i * (R_NTRI * 16)) : "memory");
+                    }
+                }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's edge stores are acknowledged (and its weight requests have arrived)
-            lds_barrier6();                                         // E2b: ... and every other wave's
-            if (lt == 0 && !(A.drop && th == 0 && tw == 0)) __hip_atomic_fetch_add(A.flags + (size_t)(tw * A.tiles_h + th) * R_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!dead) {
-                const unsigned target = A.epoch + (unsigned)l + 1u;
+            for (int i = 0; i < ((A.drop >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);      // (experiment: delay before the first fetch, 64 clocks each)
+            R_STAMP(1, 2);
+            {
+                bool pend[2] = {c_x[0] != ~0u && !dead, c_x[1] != ~0u && !dead};
                 bool ok = false;
                 for (int spin = 0; spin < R_SPIN_MAX; ++spin) {
-                    const unsigned v = need ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-                    if (__all((int)(v - target) >= 0)) { ok = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    u32x4 g[2][4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (pend[q]) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(g[q][i]) : "v"(c_x[q]), "s"(xb + i * (R_NTRI * 16)) : "memory");
+                        }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3])::"memory");
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (pend[q]) {
+                            unsigned bad = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) bad |= (g[q][i][1] ^ thi) | (g[q][i][3] ^ thi);
+                            if ((bad >> 16) == 0) {                 // all eight granules carry this layer's tag: the three entries are complete
+                                unsigned d[12];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    d[3 * i] = g[q][i][0];
+                                    d[3 * i + 1] = (g[q][i][1] & 0xFFFFu) | (g[q][i][2] << 16);
+                                    d[3 * i + 2] = (g[q][i][2] >> 16) | (g[q][i][3] << 16);
+                                }
+#pragma unroll
+                                for (int i = 0; i < 3; ++i)
+                                    if (c_lds[q][i] != ~0u) *(uint4*)((unsigned char*)Bt + c_lds[q][i]) = make_uint4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
+                                pend[q] = false;
+                            }
+                        }
+                    if (!__any(pend[0] || pend[1])) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    for (int i = 0; i < ((A.drop >> 16) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);      // (experiment: back-off between attempts)
                 }
-                if (!ok) { dead = true; if (lane == 0 && A.range_flag) atomicOr(A.range_flag, 4u); }
+                if (!ok && !dead) { dead = true; if (lane == 0 && A.range_flag) atomicOr(A.range_flag, 4u); }
             }
-            {
-                u32x4 rv[5];
-#pragma unroll
-                for (int q = 0; q < 5; ++q) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(rv[q]) : "v"(r_g[q]), "s"(hb) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4])::"memory");
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-                    if (r_lds[q] != ~0u) *(uint4*)((unsigned char*)Bt + r_lds[q]) = __builtin_bit_cast(uint4, rv[q]);
-            }
+            R_STAMP(1, 5);
             lds_barrier6();                                         // E3: the tile is the next layer's input
+            R_STAMP(1, 6);
         }
         gwait_a<0>(ra0); gwait_a<0>(ra1); gwait_a<0>(ra2);          // (clamped requests past the end are still in flight)
 #undef R_ITER
@@ -1429,6 +1493,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
     lds_barrier6();                                                 // barrier 0
 #pragma unroll 1
     for (int l = 0; l < nl; ++l) {
+        R_STAMP(0, 0);
         f32x16 acc[2][2], accl[2][2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1473,70 +1538,102 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                 if (T % 3 == 2) lds_barrier6();                     // end of step 3 c + T / 3 (the last one: every wave is done with the tile)
             }
         }
-        // ---- epilogue in registers.  C/D layout: column = lane & 31 = pixel, rows 8 rg + 4 h2 + j = output channels: one lane holds
-        // four consecutive channels (half a channel block: cb = 4 m + rg, half h2) of its pixel per (m, n, rg)
         const bool conv2 = (l & 1) != 0, last = l == nl - 1;
-        const float dh_ = A.dh[l], dl_ = A.dl[l];
+        // ---- epilogue in registers.  C/D layout: column = lane & 31 = pixel, rows 8 rg + 4 h2 + j = output channels: one lane holds
+        // four consecutive channels (half a channel block: cb = 4 m + rg, half h2) of its pixel per (m, n, rg).  Three straight-line forms
+        // (first conv of a ResBlock / second / the run's last layer), packed fp32 arithmetic where gfx950 has it.
+        R_STAMP(0, 1);
+        const f32x2 dh2 = {A.dh[l], A.dh[l]}, dl2 = {A.dl[l], A.dl[l]};
+        auto pair = [&](int m, int n, int r) __attribute__((always_inline)) { return f32x2{acc[m][n][r], acc[m][n][r + 1]}; };
+        auto pairl = [&](int m, int n, int r) __attribute__((always_inline)) { return f32x2{accl[m][n][r], accl[m][n][r + 1]}; };
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = acc[m][n][r] * dh_ + accl[m][n][r] * dl_;      // (powers of two: exact)
-        for (int pass = 0; pass < 2; ++pass) {                      // residual operands: the block input (every second layer), then the skip tensor (last layer)
-            const float* rp = (pass == 0) ? (conv2 ? ((l == 1) ? A.src : (const float*)A.cur) : nullptr) : ((last && conv2) ? A.skip : nullptr);
-            if (!rp) continue;                                      // (uniform)
-            f32x4 res[2][2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) gload4r_sc1(res[m][n][rg], gpx + (unsigned)(4 * m + rg) * plane32 + (unsigned)(8 * n * 32), rp);
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(res[0][0][0]), "+v"(res[0][0][1]), "+v"(res[0][0][2]), "+v"(res[0][0][3]), "+v"(res[0][1][0]), "+v"(res[0][1][1]),
-                           "+v"(res[0][1][2]), "+v"(res[0][1][3]), "+v"(res[1][0][0]), "+v"(res[1][0][1]), "+v"(res[1][0][2]), "+v"(res[1][0][3]),
-                           "+v"(res[1][1][0]), "+v"(res[1][1][1]), "+v"(res[1][1][2]), "+v"(res[1][1][3])::"memory");
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] += res[m][n][r >> 2][r & 3];
-        }
-        bool bad = false;
-        float tmax = 0.f;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    f32x4 x;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { x[j] = acc[m][n][4 * rg + j]; if (!conv2) x[j] = fmaxf(x[j], 0.f); }
-                    const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-                    bad |= !(gm <= F16_RANGE);                      // (also NaN)
-                    tmax = fmaxf(tmax, gm);
-                    if (!last) {                                    // the next layer's operand, in place
-                        uint2 s0, s1;
-                        split_pair_h(x[0], x[1], s0.x, s1.x);
-                        split_pair_h(x[2], x[3], s0.y, s1.y);
-                        unsigned char* bd = (unsigned char*)Bt + (((2 * m + (rg >> 1)) * R_CHUNK + (rg & 1) * NPX + pxl + IHP + 1 + 8 * n) * 16 + 8 * h2);
-                        *(uint2*)bd = s0;
-                        *(uint2*)(bd + 2 * NPX * 16) = s1;
-                    }
-                    if (conv2) {                                    // a ResBlock's output: the next block's residual operand (this workgroup reads it back, sc1) / the run's result
-                        const unsigned go = gpx + (unsigned)(4 * m + rg) * plane32 + (unsigned)(8 * n * 32);
-                        if (last) gstore4r_sc1(go, x, A.cur); else gstore4r(go, x, A.cur);
-                    }
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 x = __builtin_elementwise_fma(pairl(m, n, r), dl2, pair(m, n, r) * dh2);      // (powers of two: exact; the sum rounds once, as in k_conv6)
+                    acc[m][n][r] = x[0]; acc[m][n][r + 1] = x[1];
                 }
+        // the second conv of a ResBlock adds the block's input, requested once the descaled sums have freed the second accumulator set (requesting it a chunk
+        // earlier needs 32 registers the loop does not have: 212 bytes of scratch per lane; right after the loop: 60).  sc1 loads of what this workgroup itself stored two layers ago
+        // (or of the run's input): they bypass this CU's L1, which may hold the lines from the previous read of the same addresses.
+        f32x4 res[2][2][4];
+        if (conv2) {
+            const float* rp = (l == 1) ? A.src : (const float*)A.cur;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) { const unsigned char* cb = (const unsigned char*)rp + (size_t)(4 * m + rg) * plane32; if (n) gload4r_sc1<256>(res[m][n][rg], gpx, cb); else gload4r_sc1<0>(res[m][n][rg], gpx, cb); }
+        }
+#define R_ADD_OPERAND()         /* x += the requested operand's values at this lane's pixels */                   \
+        {                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(0)"                                                                    \
+                         : "+v"(res[0][0][0]), "+v"(res[0][0][1]), "+v"(res[0][0][2]), "+v"(res[0][0][3]), "+v"(res[0][1][0]), "+v"(res[0][1][1]), \
+                           "+v"(res[0][1][2]), "+v"(res[0][1][3]), "+v"(res[1][0][0]), "+v"(res[1][0][1]), "+v"(res[1][0][2]), "+v"(res[1][0][3]), \
+                           "+v"(res[1][1][0]), "+v"(res[1][1][1]), "+v"(res[1][1][2]), "+v"(res[1][1][3])::"memory");     \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                        \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                    \
+                    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                          \
+                        const f32x2 x = pair(m, n, r) + f32x2{res[m][n][r >> 2][r & 3], res[m][n][r >> 2][(r & 3) + 1]}; \
+                        acc[m][n][r] = x[0]; acc[m][n][r + 1] = x[1];                                            \
+                    }                                                                                            \
+        }
+        if (conv2) R_ADD_OPERAND()                                  // the block input (uniform branches)
+        if (conv2 && last && A.skip) {                              // the run's last layer also adds the skip tensor (UNetRes.forward, network_unet.py:106-117)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) { const unsigned char* cb = (const unsigned char*)A.skip + (size_t)(4 * m + rg) * plane32; if (n) gload4r_sc1<256>(res[m][n][rg], gpx, cb); else gload4r_sc1<0>(res[m][n][rg], gpx, cb); }
+            R_ADD_OPERAND()
+        }
+#undef R_ADD_OPERAND
+        R_STAMP(0, 2);
+        float gmax = 0.f;                                           // largest |output| of this lane; NaN-propagating where it matters (the compare below)
+        bool bad = false;
+        auto finish = [&](auto conv2_c, auto last_c) __attribute__((always_inline)) {
+            constexpr bool CONV2 = decltype(conv2_c)::value, LAST = decltype(last_c)::value;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        f32x4 x;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { x[j] = acc[m][n][4 * rg + j]; if constexpr (!CONV2) x[j] = fmaxf(x[j], 0.f); }
+                        const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+                        bad |= !(gm <= F16_RANGE);                  // (also NaN)
+                        gmax = fmaxf(gmax, gm);
+                        if constexpr (!LAST) {                      // the next layer's operand, in place
+                            uint2 s0, s1;
+                            split_pair_h(x[0], x[1], s0.x, s1.x);
+                            split_pair_h(x[2], x[3], s0.y, s1.y);
+                            unsigned char* bd = (unsigned char*)Bt + (((2 * m + (rg >> 1)) * R_CHUNK + (rg & 1) * NPX + pxl + IHP + 1 + 8 * n) * 16 + 8 * h2);
+                            *(uint2*)bd = s0;
+                            *(uint2*)(bd + 2 * NPX * 16) = s1;
+                        }
+                        if constexpr (CONV2) {                      // a ResBlock's output: the next block's residual operand (this workgroup reads it back, sc1) / the run's result
+                            unsigned char* cb = (unsigned char*)A.cur + (size_t)(4 * m + rg) * plane32;
+                            if constexpr (LAST) { if (n) gstore4r_sc1<256>(gpx, x, cb); else gstore4r_sc1<0>(gpx, x, cb); } else { if (n) gstore4r<256>(gpx, x, cb); else gstore4r<0>(gpx, x, cb); }
+                        }
+                    }
+        };
+        if (!conv2) finish(std::false_type{}, std::false_type{});
+        else if (!last) finish(std::true_type{}, std::false_type{});
+        else finish(std::true_type{}, std::true_type{});
         if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
-        act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, tmax, 4);
+        act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, gmax, 4);
+        R_STAMP(0, 3);
         if (last) break;
         lds_barrier6();                                             // E2
-        lds_barrier6();                                             // E2b
+        R_STAMP(0, 4);
         lds_barrier6();                                             // E3
+        R_STAMP(0, 6);
     }
 }
 
@@ -2427,24 +2524,23 @@ int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, co
 }
 
 // The ResBlocks of one level as ONE launch with resident tiles (k_conv6r): layers Ls[0 .. nl), run input `src`, ResBlock outputs in `cur`, `skip`
-// added by the last layer; `h0`, `h1` are BLOCKED scratch tensors of the level's geometry.  *done = false: not eligible, nothing launched.
-int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor& h0, const PTensor& h1,
-               const PTensor* skip, bool* done) {
+// added by the last layer.  *done = false: not eligible, nothing launched.
+int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor* skip, bool* done) {
     *done = false;
     NetPlan& net = ctx->net;
     static const int resident = getenv("QMRI_CONV_RESIDENT") ? atoi(getenv("QMRI_CONV_RESIDENT")) : 1;
-    static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;     // (a captured launch would replay a stale counter value)
-    if (!resident || graph_replay || net.res_off || !net.d_res_flags || B != 1 || nl < 2 || nl > R_MAXL || (nl & 1) || net.d_stamps || ctx->prof_level >= 2) return QMRI_OK;
+    static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;     // (a captured launch would replay stale tags)
+    if (!resident || graph_replay || net.res_off || !net.d_res_xbuf || B != 1 || nl < 2 || nl > R_MAXL || (nl & 1) || net.d_stamps || ctx->prof_level >= 2) return QMRI_OK;
     for (int l = 0; l < nl; ++l) {
         const ConvLayer& L = Ls[l];
         if ((L.kind != CONV_3X3 && L.kind != CONV_3X3N) || L.Cin != 64 || L.Cout != 64 || L.sp6 != 2 || !L.wp6 || L.nchunk6 != 4 || L.n_ct6 != 1) return QMRI_OK;
     }
-    const PTensor* ts[5] = {&src, &cur, &h0, &h1, skip};
+    const PTensor* ts[3] = {&src, &cur, skip};
     for (const PTensor* t : ts) {
         if (!t) continue;
         if (!t->p || !t->blk || t->Cal < 64 || t->H != src.H || t->W != src.W || t->hp != src.hp || t->h0 != src.h0) return QMRI_OK;
     }
-    if (src.H % 16 || src.W % 16 || h0.p == h1.p || h0.p == cur.p || h1.p == cur.p || h0.p == src.p || h1.p == src.p) return QMRI_OK;
+    if (src.H % 16 || src.W % 16) return QMRI_OK;
     if ((size_t)src.Cal * src.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;       // (32-bit byte offsets)
     if (!ctx->conv_ncu) {
         hipDeviceProp_t prop;
@@ -2452,10 +2548,10 @@ int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor&
         ctx->conv_ncu = prop.multiProcessorCount;
     }
     const int tiles_h = src.H / 16, tiles_w = src.W / 16, tiles = tiles_h * tiles_w;
-    if (tiles > ctx->conv_ncu || tiles > net.res_flag_tiles) return QMRI_OK;             // every workgroup must be resident: one per CU
+    if (tiles > ctx->conv_ncu || tiles != net.res_tiles) return QMRI_OK;               // every workgroup must be resident: one per CU
     Conv6rArgs A{};
     A.src = src.fbase(); A.cur = cur.fbase(); A.skip = skip ? skip->fbase() : nullptr;
-    A.halo[0] = h0.fbase(); A.halo[1] = h1.fbase();
+    A.xbuf = net.d_res_xbuf; A.xbuf_half = (size_t)tiles * R_NTRI * 64;
     for (int l = 0; l < R_MAXL; ++l) {
         const ConvLayer& L = Ls[l < nl ? l : nl - 1];
         A.wp[l] = reinterpret_cast<const uint4*>(L.wp6);
@@ -2465,16 +2561,21 @@ int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor&
     A.nlayers = nl; A.hp = src.hp; A.plane = (int)src.plane(); A.tiles_h = tiles_h; A.tiles_w = tiles_w;
     static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
     A.xcd = xcd_order;
-    A.flags = net.d_res_flags; A.epoch = net.res_epoch; A.drop = net.res_drop ? 1 : 0;
+    A.epoch = net.res_epoch; A.drop = net.res_drop;
     A.range_flag = net.d_range_flag; A.am_slots = net.d_act_slots; A.am_count = net.d_act_count;
     if (!ctx->conv6r_attr) {
-        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6r_lds()));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6r<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6r_lds()));
+        QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6r_lds()));
         ctx->conv6r_attr = true;
     }
     g_launch_counter.fetch_add(nl, std::memory_order_relaxed);
-    k_conv6r<<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
+    A.stamps = (unsigned long long*)net.d_res_stamps;
+    if (A.stamps) k_conv6r<true><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
+    else k_conv6r<false><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
-    net.res_epoch += (unsigned)(nl - 1);                            // every tile's counter: one add per layer but the last
+    net.res_epoch += (unsigned)(nl - 1);                            // one tag per layer but the last; never reset, so a stale granule never carries a current tag
     *done = true;
     return QMRI_OK;
 }
+
+size_t conv6r_xbuf_bytes(int tiles) { return (size_t)2 * tiles * R_NTRI * 64; }

@@ -197,15 +197,15 @@ struct NetPlan {
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
-    // resident-tile ResBlock runs (conv6_kernels.hip k_conv6r): a second scratch tensor at the full-resolution level, the tiles' hand-off counters
-    // (never reset: a launch is told their value before it), and the switch a timed-out hand-off turns off for the life of the plan
-    PTensor t2;
-    unsigned* d_res_flags = nullptr;
-    int res_flag_tiles = 0;
+    // resident-tile ResBlock runs (conv6_kernels.hip k_conv6r): the exchange buffer of the tiles' edge pixels (two layer parities x tiles x 23.5 KB), the
+    // running tag of its granules (never reset), and the switch a timed-out hand-off turns off for the life of the plan
+    unsigned char* d_res_xbuf = nullptr;
+    int res_tiles = 0;
     unsigned res_epoch = 0;
     bool res_off = false;
     int res_timeouts = 0;
-    bool res_drop = false;           // test hook: tile 0 withholds its hand-off
+    int res_drop = 0;                // test hook: bit 0 = tile 0 withholds its hand-off
+    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (QMRI_RES_STAMPS=1), 4 x 2 x 8 x 8 values
     bool ready = false;
 };
 
@@ -358,8 +358,8 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out);
 // a run of nl 64-channel 3x3 layers (ResBlocks) as one launch with LDS-resident tiles; *done = false: not eligible, nothing launched
-int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor& h0, const PTensor& h1,
-               const PTensor* skip, bool* done);
+int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor* skip, bool* done);
+size_t conv6r_xbuf_bytes(int tiles);
 void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);   // 2x2 / stride-2 layers
 bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out);
 int conv6s_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out);

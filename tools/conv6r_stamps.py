@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Phase times inside the resident-tile ResBlock launch (k_conv6r, QMRI_RES_STAMPS=1): 100 MHz stamps of four workgroups (matrix wave 0 and loader
+wave 0), per layer, of the LAST launch of a forward pass (the up path's run)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+os.environ["QMRI_RES_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
+
+w = synth.random_weights(seed=1, gain=0.7)
+e = E.Engine(0)
+e.set_denoiser(w, 224, 224, max_batch=1)
+x = np.random.default_rng(3).random((224, 224, 10))
+for _ in range(5):
+    e.denoise(x)
+out = (C.c_ulonglong * 512)()
+e.L.qmri_debug_conv_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+assert e.L.qmri_debug_conv_stamps(e.h, out, -6) == 0
+s = np.array(out[:], dtype=np.int64).reshape(4, 2, 8, 8)
+us = lambda a, b: (b - a) / 100.0
+print("matrix wave 0: loop | residual operand | epilogue (split, LDS writes, stores) | wait E2 | wait E3   ;   loader wave 0: E1->E2 | publish (issue) | fetch (poll-loads + ring writes) | E3     [us]")
+for wg in range(4):
+    print(f"workgroup {wg * 50}")
+    for l in range(8):
+        m, ld = s[wg, 0, l], s[wg, 1, l]
+        if l < 7:
+            nxt = s[wg, 0, l + 1, 0]
+            print(f"  layer {l}: M loop {us(m[0], m[1]):5.2f} res {us(m[1], m[2]):5.2f} epi {us(m[2], m[3]):5.2f} E2 {us(m[3], m[4]):5.2f} E3 {us(m[4], m[6]):5.2f}"
+                  f" | L E2 {us(ld[0], ld[1]):5.2f} publish {us(ld[1], ld[2]):5.2f} fetch {us(ld[2], ld[5]):5.2f} E3 {us(ld[5], ld[6]):5.2f}"
+                  f" | layer total {us(m[0], nxt):5.2f}")
+        else:
+            print(f"  layer {l}: M loop {us(m[0], m[1]):5.2f} res {us(m[1], m[2]):5.2f} epi {us(m[2], m[3]):5.2f}")
+e.close()
