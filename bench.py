@@ -545,7 +545,10 @@ def worker(args):
             else:
                 ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
                 traffic, tsrc = load_traffic(B)
-                roof = {"kernel": f"k_conv6 (implicit-GEMM conv3x3 on {SCHEME_TEXT})",
+                resident = os.environ.get("QMRI_CONV_RESIDENT", "1") != "0"
+                roof = {"kernel": (f"k_conv6 + k_conv6r (implicit-GEMM conv3x3 on {SCHEME_TEXT}; per LAYER: the 16 full-resolution ResBlock layers of a forward "
+                                   "pass run as two resident-tile launches of eight layers, each timed as one dispatch and counted as eight)") if resident
+                        else f"k_conv6 (implicit-GEMM conv3x3 on {SCHEME_TEXT})",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                         "avg_launch_us": round(avg_s * 1e6, 2),

@@ -453,7 +453,7 @@ extern "C" int qmri_debug_conv_resident(qmri_ctx* ctx, int on, int* timeouts_out
     if (timeouts_out) *timeouts_out = p.res_timeouts;
     if (!p.ready) return QMRI_OK;
     p.res_off = (on == 0);
-    p.res_drop = (on == 2) ? 1 : (on >= 256 ? (on & ~0xFF) : 0);       // (on >= 256: experiment fields, bits 8-15 / 16-23)
+    p.res_drop = (on == 2) ? 1 : 0;
     return QMRI_OK;
 }
 

@@ -1255,6 +1255,7 @@ struct Conv6rArgs {
     int am_layer[R_MAXL];                                   // row of the |output| report, -1: none
     int nlayers, hp, plane, tiles_h, tiles_w, xcd;
     int drop;                                               // test hook: tile (0, 0) publishes nothing
+    int delay;                                              // s_sleep(1) units (64 clocks) between E2 and the first fetch attempt
     unsigned epoch;                                         // layers published before this launch: layer l of this launch tags its granules (epoch + l + 1) mod 2^16
     unsigned* range_flag; float* am_slots; int* am_count;
     unsigned long long* stamps;                             // diagnostic instantiation only
@@ -1267,6 +1268,16 @@ template <int N> __device__ __forceinline__ void gwait_a(u32x4 (&a)[3]) { asm vo
 template <int IMM> __device__ __forceinline__ void gload4r_sc1(f32x4& dst, unsigned off, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1" : "=v"(dst) : "v"(off), "s"(base), "n"(IMM) : "memory"); }
 template <int IMM> __device__ __forceinline__ void gstore4r(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(off), "v"(x), "s"(base), "n"(IMM) : "memory"); }
 template <int IMM> __device__ __forceinline__ void gstore4r_sc1(unsigned off, f32x4 x, void* base) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(off), "v"(x), "s"(base), "n"(IMM) : "memory"); }
+
+// triple t of a tile's 368 -> (segment, index inside it); first triple of a segment; LDS byte offset of entry kind k (channel block, piece) at tile position (dw, dh)
+__device__ __forceinline__ void r_tri_decode(int t, int& seg, int& j) {
+    if (t < 4 * R_SEGT) { seg = t / R_SEGT; j = t - seg * R_SEGT; } else { seg = 4 + (t - 4 * R_SEGT) / R_CORT; j = (t - 4 * R_SEGT) - (seg - 4) * R_CORT; }
+}
+__device__ __forceinline__ int r_seg_base(int seg) { return seg < 4 ? seg * R_SEGT : 4 * R_SEGT + (seg - 4) * R_CORT; }
+__device__ __forceinline__ unsigned r_ent_lds(int k, int dw, int dh) {
+    const int cb = k >> 1, sp = k & 1;
+    return (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * R_NPX + (cb & 1) * R_NPX + dw * R_IHP + dh) * 16);
+}
 
 // (STAMP: diagnostic instantiation, QMRI_RES_STAMPS=1 -- tools/conv6r_stamps.py: 100 MHz phase stamps of four workgroups, [wg][matrix wave 0 / loader wave 0][layer][8])
 #define R_STAMP(role, k)                                                                                         \
@@ -1293,7 +1304,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
 
     if (tid >= NT6 - NLD6) {
         // ------------------------------------------------------------------ loaders
-        const int lt = tid - (NT6 - NLD6), lane = lt & 63;
+        const int lt = tid - (NT6 - NLD6);
         __builtin_amdgcn_s_setprio(2);
         constexpr unsigned ASTB = AST * 16;
         unsigned aoff[NAQ];
@@ -1355,40 +1366,23 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
         // A tile publishes eight segments -- its columns w = 0 / 15, its rows h = 0 / 15 (16 pixels x 16 entries, padded to 86 triples) and its four
         // corner pixels (16 entries, 6 triples) -- into its own 368 x 64 bytes of the exchange buffer of the layer's parity; a tile fetches the
         // matching segments of its eight neighbours (its left ring column = the left neighbour's column w = 15, ...).  Offsets: ~0u = none.
-        unsigned p_lds[2][3], p_x[2], c_lds[2][3], c_x[2];
-        auto tri_decode = [](int t, int& seg, int& j) { if (t < 4 * R_SEGT) { seg = t / R_SEGT; j = t - seg * R_SEGT; } else { seg = 4 + (t - 4 * R_SEGT) / R_CORT; j = (t - 4 * R_SEGT) - (seg - 4) * R_CORT; } };
-        auto seg_base = [](int seg) { return seg < 4 ? seg * R_SEGT : 4 * R_SEGT + (seg - 4) * R_CORT; };
-        auto ent_lds = [&](int k, int dw, int dh) { const int cb = k >> 1, sp = k & 1; return (unsigned)(((cb >> 1) * R_CHUNK + sp * 2 * NPX + (cb & 1) * NPX + dw * IHP + dh) * 16); };
+        unsigned p_lds[2][3], p_x[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int t = lt + NLD6 * q;
             const bool valid = t < R_NTRI;
             int seg, j;
-            tri_decode(valid ? t : 0, seg, j);
+            r_tri_decode(valid ? t : 0, seg, j);
             const int npx = seg < 4 ? 16 : 1;
-            // publish: segment `seg` of this tile, pixel p at interior position (w, h)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 3; ++i) {                           // segment `seg` of this tile, pixel pp at interior position (w, h)
                 const int E = 3 * j + i, Ec = (E < npx * 16) ? E : 0, pp = Ec >> 4, k = Ec & 15;
                 const int w = (seg == 0) ? 0 : (seg == 1) ? 15 : (seg == 2 || seg == 3) ? pp : (seg < 6 ? 0 : 15);
                 const int h = (seg == 0 || seg == 1) ? pp : (seg == 2) ? 0 : (seg == 3) ? 15 : ((seg & 1) ? 15 : 0);
-                p_lds[q][i] = ent_lds(k, w + 1, h + 1);
+                p_lds[q][i] = r_ent_lds(k, w + 1, h + 1);
             }
             p_x[q] = valid ? (unsigned)((tw * A.tiles_h + th) * (R_NTRI * 64) + t * 16) : ~0u;   // (quarter i of a triple: + i * R_NTRI * 16 -- consecutive lanes, consecutive 16 bytes)
-            // fetch: ring segment `seg` <- neighbour (dtw, dth), its segment ns
-            const int dtw = (seg == 0 || seg == 4 || seg == 5) ? -1 : (seg == 1 || seg == 6 || seg == 7) ? 1 : 0;
-            const int dth = (seg == 2 || seg == 4 || seg == 6) ? -1 : (seg == 3 || seg == 5 || seg == 7) ? 1 : 0;
-            const int ns = (seg < 4) ? (seg ^ 1) : 11 - seg;
-            const bool have = valid && tw + dtw >= 0 && tw + dtw < A.tiles_w && th + dth >= 0 && th + dth < A.tiles_h;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int E = 3 * j + i, pp = E >> 4, k = E & 15;
-                const int dw = (dtw < 0) ? 0 : (dtw > 0) ? 17 : pp + 1, dh = (dth < 0) ? 0 : (dth > 0) ? 17 : pp + 1;
-                c_lds[q][i] = (have && E < npx * 16) ? ent_lds(k, dw, dh) : ~0u;
-            }
-            c_x[q] = have ? (unsigned)(((tw + dtw) * A.tiles_h + th + dth) * (R_NTRI * 64) + (seg_base(ns) + j) * 16) : ~0u;
         }
-        bool dead = false;                                          // a poll timed out: no more waiting in this workgroup
         lds_barrier6();                                             // barrier 0: step 0 may start
 #define R_ITER(k_, rs_, rq_)     /* stores step g + k_ + 2 into its buffer, requests step g + k_ + 4 */          \
         {                                                                                                        \
@@ -1413,7 +1407,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
             R_STAMP(1, 1);
             const unsigned tag = (A.epoch + (unsigned)l + 1u) & 0xFFFFu, thi = tag << 16;
             unsigned char* xb = A.xbuf + (size_t)(l & 1) * A.xbuf_half;
-            if (!((A.drop & 1) && th == 0 && tw == 0)) {
+            if (!(A.drop && th == 0 && tw == 0)) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     if (p_x[q] == ~0u) continue;
@@ -1430,50 +1424,11 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                         g[1] = (d[3 * i + 1] & 0xFFFFu) | thi;
                         g[2] = (d[3 * i + 1] >> 16) | (d[3 * i + 2] << 16);
                         g[3] = (d[3 * i + 2] >> 16) | thi;
-                        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(p_x[q]), "v"(g), "s"(xb + i * (R_NTRI * 16)) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(p_x[q] + (unsigned)(i * (R_NTRI * 16))), "v"(g), "s"(xb) : "memory");
                     }
                 }
             }
-            for (int i = 0; i < ((A.drop >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);      // (experiment: delay before the first fetch, 64 clocks each)
             R_STAMP(1, 2);
-            {
-                bool pend[2] = {c_x[0] != ~0u && !dead, c_x[1] != ~0u && !dead};
-                bool ok = false;
-                for (int spin = 0; spin < R_SPIN_MAX; ++spin) {
-                    u32x4 g[2][4];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        if (pend[q]) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(g[q][i]) : "v"(c_x[q]), "s"(xb + i * (R_NTRI * 16)) : "memory");
-                        }
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3])::"memory");
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        if (pend[q]) {
-                            unsigned bad = 0;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) bad |= (g[q][i][1] ^ thi) | (g[q][i][3] ^ thi);
-                            if ((bad >> 16) == 0) {                 // all eight granules carry this layer's tag: the three entries are complete
-                                unsigned d[12];
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    d[3 * i] = g[q][i][0];
-                                    d[3 * i + 1] = (g[q][i][1] & 0xFFFFu) | (g[q][i][2] << 16);
-                                    d[3 * i + 2] = (g[q][i][2] >> 16) | (g[q][i][3] << 16);
-                                }
-#pragma unroll
-                                for (int i = 0; i < 3; ++i)
-                                    if (c_lds[q][i] != ~0u) *(uint4*)((unsigned char*)Bt + c_lds[q][i]) = make_uint4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
-                                pend[q] = false;
-                            }
-                        }
-                    if (!__any(pend[0] || pend[1])) { ok = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    for (int i = 0; i < ((A.drop >> 16) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);      // (experiment: back-off between attempts)
-                }
-                if (!ok && !dead) { dead = true; if (lane == 0 && A.range_flag) atomicOr(A.range_flag, 4u); }
-            }
             R_STAMP(1, 5);
             lds_barrier6();                                         // E3: the tile is the next layer's input
             R_STAMP(1, 6);
@@ -1490,10 +1445,39 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
     const int pxl = (pbw + (li >> 3)) * IHP + (li & 7);             // LDS entry of this lane's pixel at tap (0,0), pixel block 0
     // byte offset (relative to fbase) of this lane's 4 channels of block 0 at its pixel of pixel block 0; + 8 rows per pixel block, + plane32 per channel block
     const unsigned gpx = (unsigned)(((ow0 + pbw + (li >> 3) + 1) * A.hp + (oh0 + (li & 7)) + 1) * 32 + 16 * h2);
+    // this thread's <= 2 triples of the ring (fetched by the matrix waves, which have nothing else to do between two layers -- and, unlike the loader
+    // waves, no stores of their own in front of the requests): ring segment `seg` <- neighbour (dtw, dth), its segment ns
+    unsigned c_lds[2][3], c_x[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = tid + 256 * q;
+        const bool valid = t < R_NTRI;
+        int seg, j;
+        r_tri_decode(valid ? t : 0, seg, j);
+        const int npx = seg < 4 ? 16 : 1;
+        const int dtw = (seg == 0 || seg == 4 || seg == 5) ? -1 : (seg == 1 || seg == 6 || seg == 7) ? 1 : 0;
+        const int dth = (seg == 2 || seg == 4 || seg == 6) ? -1 : (seg == 3 || seg == 5 || seg == 7) ? 1 : 0;
+        const int ns = (seg < 4) ? (seg ^ 1) : 11 - seg;
+        const bool have = valid && tw + dtw >= 0 && tw + dtw < A.tiles_w && th + dth >= 0 && th + dth < A.tiles_h;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int E = 3 * j + i, pp = E >> 4, k = E & 15;
+            const int dw = (dtw < 0) ? 0 : (dtw > 0) ? 17 : pp + 1, dh = (dth < 0) ? 0 : (dth > 0) ? 17 : pp + 1;
+            c_lds[q][i] = (have && E < npx * 16) ? r_ent_lds(k, dw, dh) : ~0u;
+        }
+        c_x[q] = have ? (unsigned)(((tw + dtw) * A.tiles_h + th + dth) * (R_NTRI * 64) + (r_seg_base(ns) + j) * 16) : ~0u;
+    }
+    bool dead = false;                                              // a fetch timed out: no more waiting in this wave
     lds_barrier6();                                                 // barrier 0
 #pragma unroll 1
     for (int l = 0; l < nl; ++l) {
         R_STAMP(0, 0);
+        // (One scalar base per tensor and per-request offsets made in the epilogue itself: a scalar base per channel block costs 48 SGPRs across the
+        //  layer loop -- hipcc then spills SGPRs into VGPR lanes, and a v_readlane reload directly in front of an inline-asm VMEM instruction is a
+        //  hazard its recognizer does not see: the first version of this faulted on a garbage address.  The empty asm keeps the offsets out of the
+        //  loop-invariant code that would pin 16 VGPRs instead.  tools/audit_conv6_isa.py checks both.)
+        unsigned gpx_l = gpx;
+        asm volatile("" : "+v"(gpx_l));
         f32x16 acc[2][2], accl[2][2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1566,7 +1550,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) { const unsigned char* cb = (const unsigned char*)rp + (size_t)(4 * m + rg) * plane32; if (n) gload4r_sc1<256>(res[m][n][rg], gpx, cb); else gload4r_sc1<0>(res[m][n][rg], gpx, cb); }
+                    for (int rg = 0; rg < 4; ++rg) { const unsigned go = gpx_l + (unsigned)(4 * m + rg) * plane32; if (n) gload4r_sc1<256>(res[m][n][rg], go, rp); else gload4r_sc1<0>(res[m][n][rg], go, rp); }
         }
 #define R_ADD_OPERAND()         /* x += the requested operand's values at this lane's pixels */                   \
         {                                                                                                        \
@@ -1588,7 +1572,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) { const unsigned char* cb = (const unsigned char*)A.skip + (size_t)(4 * m + rg) * plane32; if (n) gload4r_sc1<256>(res[m][n][rg], gpx, cb); else gload4r_sc1<0>(res[m][n][rg], gpx, cb); }
+                    for (int rg = 0; rg < 4; ++rg) { const unsigned go = gpx_l + (unsigned)(4 * m + rg) * plane32; if (n) gload4r_sc1<256>(res[m][n][rg], go, A.skip); else gload4r_sc1<0>(res[m][n][rg], go, A.skip); }
             R_ADD_OPERAND()
         }
 #undef R_ADD_OPERAND
@@ -1618,8 +1602,8 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                             *(uint2*)(bd + 2 * NPX * 16) = s1;
                         }
                         if constexpr (CONV2) {                      // a ResBlock's output: the next block's residual operand (this workgroup reads it back, sc1) / the run's result
-                            unsigned char* cb = (unsigned char*)A.cur + (size_t)(4 * m + rg) * plane32;
-                            if constexpr (LAST) { if (n) gstore4r_sc1<256>(gpx, x, cb); else gstore4r_sc1<0>(gpx, x, cb); } else { if (n) gstore4r<256>(gpx, x, cb); else gstore4r<0>(gpx, x, cb); }
+                            const unsigned go = gpx_l + (unsigned)(4 * m + rg) * plane32;
+                            if constexpr (LAST) { if (n) gstore4r_sc1<256>(go, x, A.cur); else gstore4r_sc1<0>(go, x, A.cur); } else { if (n) gstore4r<256>(go, x, A.cur); else gstore4r<0>(go, x, A.cur); }
                         }
                     }
         };
@@ -1632,6 +1616,51 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
         if (last) break;
         lds_barrier6();                                             // E2
         R_STAMP(0, 4);
+        {
+            const unsigned tag = (A.epoch + (unsigned)l + 1u) & 0xFFFFu, thi = tag << 16;
+            const unsigned char* xb = A.xbuf + (size_t)(l & 1) * A.xbuf_half;
+            // the neighbours publish about now and their stores need ~1 us to be visible: requests sent at once only find old tags -- and 196 x 256
+            // lanes re-reading 17 KB each slow the stores they wait for (measured per forward: 1117 us without the pause, 1094 - 1104 with 32 - 48 units)
+            for (int i = 0; i < A.delay; ++i) __builtin_amdgcn_s_sleep(1);
+            {
+                bool pend[2] = {c_x[0] != ~0u && !dead, c_x[1] != ~0u && !dead};
+                bool ok = false;
+                for (int spin = 0; spin < R_SPIN_MAX; ++spin) {
+                    u32x4 g[2][4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (pend[q]) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(g[q][i]) : "v"(c_x[q] + (unsigned)(i * (R_NTRI * 16))), "s"(xb) : "memory");
+                        }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3])::"memory");
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (pend[q]) {
+                            unsigned bad = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) bad |= (g[q][i][1] ^ thi) | (g[q][i][3] ^ thi);
+                            if ((bad >> 16) == 0) {                 // all eight granules carry this layer's tag: the three entries are complete
+                                unsigned d[12];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    d[3 * i] = g[q][i][0];
+                                    d[3 * i + 1] = (g[q][i][1] & 0xFFFFu) | (g[q][i][2] << 16);
+                                    d[3 * i + 2] = (g[q][i][2] >> 16) | (g[q][i][3] << 16);
+                                }
+#pragma unroll
+                                for (int i = 0; i < 3; ++i)
+                                    if (c_lds[q][i] != ~0u) *(uint4*)((unsigned char*)Bt + c_lds[q][i]) = make_uint4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
+                                pend[q] = false;
+                            }
+                        }
+                    if (!__any(pend[0] || pend[1])) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok && !dead) { dead = true; if (lane == 0 && A.range_flag) atomicOr(A.range_flag, 4u); }
+            }
+        }
+        R_STAMP(0, 5);
         lds_barrier6();                                             // E3
         R_STAMP(0, 6);
     }
@@ -2530,7 +2559,7 @@ int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor&
     NetPlan& net = ctx->net;
     static const int resident = getenv("QMRI_CONV_RESIDENT") ? atoi(getenv("QMRI_CONV_RESIDENT")) : 1;
     static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;     // (a captured launch would replay stale tags)
-    if (!resident || graph_replay || net.res_off || !net.d_res_xbuf || B != 1 || nl < 2 || nl > R_MAXL || (nl & 1) || net.d_stamps || ctx->prof_level >= 2) return QMRI_OK;
+    if (!resident || graph_replay || net.res_off || !net.d_res_xbuf || B != 1 || nl < 2 || nl > R_MAXL || (nl & 1) || net.d_stamps) return QMRI_OK;
     for (int l = 0; l < nl; ++l) {
         const ConvLayer& L = Ls[l];
         if ((L.kind != CONV_3X3 && L.kind != CONV_3X3N) || L.Cin != 64 || L.Cout != 64 || L.sp6 != 2 || !L.wp6 || L.nchunk6 != 4 || L.n_ct6 != 1) return QMRI_OK;
@@ -2561,7 +2590,8 @@ int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor&
     A.nlayers = nl; A.hp = src.hp; A.plane = (int)src.plane(); A.tiles_h = tiles_h; A.tiles_w = tiles_w;
     static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
     A.xcd = xcd_order;
-    A.epoch = net.res_epoch; A.drop = net.res_drop;
+    static const int delay = getenv("QMRI_RES_DELAY") ? std::max(0, std::min(4096, atoi(getenv("QMRI_RES_DELAY")))) : 40;
+    A.epoch = net.res_epoch; A.drop = net.res_drop; A.delay = delay;
     A.range_flag = net.d_range_flag; A.am_slots = net.d_act_slots; A.am_count = net.d_act_count;
     if (!ctx->conv6r_attr) {
         QMRI_HIP(ctx, hipFuncSetAttribute((const void*)k_conv6r<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv6r_lds()));
@@ -2570,7 +2600,10 @@ int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor&
     }
     g_launch_counter.fetch_add(nl, std::memory_order_relaxed);
     A.stamps = (unsigned long long*)net.d_res_stamps;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, nl));                    // (profile level 2: one pair for the launch, counted as its nl layers)
     if (A.stamps) k_conv6r<true><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
+    else if (e0) hipExtLaunchKernelGGL((k_conv6r<false>), dim3(tiles), dim3(NT6), (std::uint32_t)conv6r_lds(), ctx->stream, e0, e1, 0, A);
     else k_conv6r<false><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
     QMRI_HIP(ctx, hipGetLastError());
     net.res_epoch += (unsigned)(nl - 1);                            // one tag per layer but the last; never reset, so a stale granule never carries a current tag

@@ -279,6 +279,7 @@ struct qmri_ctx {
     // without putting extra packets between dependent kernels (event records in the stream add 3-5 us per kernel)
     std::vector<hipEvent_t> chain;      // pairs: [2i] start, [2i+1] stop
     size_t chain_n = 0;                 // events handed out in the current forward
+    std::vector<int> chain_w;           // layers a pair stands for (1; a resident-tile launch: all its layers)
     bool conv6_attr[4][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
     bool conv6i_attr[4] = {false, false, false, false};   // ... of k_conv6i<CFG> (PIECES input)
@@ -347,7 +348,7 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
                 const PTensor* add2, int relu_out);
 int conv_cin_pad(ConvKind kind, int Cin);
 // bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
-int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop);   // profile level 2: next event pair of the forward (else nullptrs)
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers = 1);   // profile level 2: next event pair of the forward (else nullptrs)
 int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv = false, long count = -1);   // count >= 0: only the first `count` pairs are accumulated   // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3 (tv: ms_tv_iter / n_tv_iter)
 bool conv6_enabled();
 int conv6_act_begin(qmri_ctx* ctx, int nlayers);           // f16 scheme: start / finish the per-layer |output| report of a forward pass

@@ -208,7 +208,7 @@ class Engine:
         launch per layer; on = 2: a tile withholds its hand-off (recovery path).  Returns the hand-off time-outs seen so far."""
         n = C.c_int(0)
         self.L.qmri_debug_conv_resident.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-        self._check(self.L.qmri_debug_conv_resident(self.h, int(on) if int(on) >= 2 else int(bool(on)), C.byref(n)))
+        self._check(self.L.qmri_debug_conv_resident(self.h, 2 if on == 2 else int(bool(on)), C.byref(n)))
         return n.value
 
     def denoiser_scheme(self):

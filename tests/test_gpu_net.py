@@ -489,3 +489,52 @@ def test_pieces_tensors_change_no_bit(tmp_path):
     for k in res["1"].files:
         a, b = res["1"][k], res["0"][k]
         assert np.all(np.isfinite(a)) and np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
+def test_resident_tile_launch_changes_no_bit(engine_mod, synth):
+    """Round 4: the ResBlocks of the full-resolution level of a one-slice forward pass run as ONE launch (k_conv6r): a workgroup keeps its
+    18 x 18 x 64 tile in LDS across the eight layers, writes each layer's output in place and exchanges only the one-pixel ring with its
+    eight neighbours (tagged granules through memory).  Same arithmetic in the same order as one launch per layer: the output must be
+    IDENTICAL, bit for bit, with the hook off -- sensitive weights (every level matters), 10 and 11 input channels, 224 x 224 (14 x 14 tiles:
+    interior, edge and corner tiles) and 32 x 32 (2 x 2 tiles: every tile a corner), many passes (the exchange buffers are reused every
+    second layer: a stale or torn granule would show up as a difference that varies from pass to pass)."""
+    rng = np.random.default_rng(11)
+    for N, in_nc in ((224, 10), (224, 11), (32, 10)):
+        w = synth.random_weights(seed=1, gain=0.7, in_nc=in_nc)
+        e = engine_mod.Engine(0)
+        e.set_denoiser(w, N, N, in_nc=in_nc)
+        x = rng.random((N, N, in_nc))
+        e.conv_resident(0)
+        ref = e.denoise(x)
+        assert np.all(np.isfinite(ref)) and float(np.abs(ref).max()) > 0.0
+        e.conv_resident(1)
+        for k in range(6):
+            y = e.denoise(x)
+            assert np.array_equal(y, ref), (N, in_nc, k, float(np.abs(y - ref).max()))
+        x2 = rng.random((N, N, in_nc))                              # (another image: the buffers hold the previous one's edges)
+        y2 = e.denoise(x2)
+        e.conv_resident(0)
+        assert np.array_equal(y2, e.denoise(x2))
+        assert e.conv_resident(1) == 0 and e.denoiser_scheme() == (2, 0)
+        e.close()
+
+
+def test_resident_tile_launch_recovers_from_a_lost_hand_off(engine_mod, synth, capfd):
+    """The workgroups of k_conv6r wait for each other's edge pixels.  Every wait is bounded: with the hook at 2 one tile publishes nothing, its
+    neighbours' fetches time out and raise bit 2 of the range flag, the library says so on stderr, repeats the call with one launch per layer
+    and keeps the resident form off for this denoiser -- the result is the reference's, the scheme stays f16 x 3."""
+    w = synth.random_weights(seed=1, gain=0.7)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 224, 224)
+    x = np.random.default_rng(12).random((224, 224, 10))
+    e.conv_resident(0)
+    ref = e.denoise(x)
+    e.conv_resident(2)
+    y = e.denoise(x)
+    assert np.array_equal(y, ref)
+    assert "hand-off" in capfd.readouterr().err
+    assert e.conv_resident(2) == 1 and e.denoiser_scheme() == (2, 0)   # one time-out seen; still the f16 scheme, no fallback counted
+    assert np.array_equal(e.denoise(x), ref)                        # (the hook call above re-armed the resident form with the loss: recovers again)
+    assert e.conv_resident(1) == 2
+    assert np.array_equal(e.denoise(x), ref) and e.conv_resident(1) == 2    # hook off: the resident form runs again, no further time-out
+    e.close()

@@ -17,7 +17,8 @@ def regs(tok):
 
 
 def sgpr_hazards(lines, name):
-    """VALU write of an SGPR (v_readfirstlane) followed by an inline-asm VMEM read of it needs 5 wait states."""
+    """VALU write of an SGPR (v_readfirstlane; v_readlane = the reload of an SGPR hipcc spilled into a VGPR lane) followed by an inline-asm VMEM
+    read of it needs 5 wait states; a VMEM store of more than 8 bytes needs 2 before its data registers are written again."""
     bad = 0
     real = [(i, l.strip()) for i, l in enumerate(lines) if l.strip() and not l.strip().startswith(';') and not l.strip().startswith('.')]
     for k, (i, t) in enumerate(real):
@@ -30,13 +31,37 @@ def sgpr_hazards(lines, name):
         for j in range(k - 1, max(k - 12, -1), -1):
             u = real[j][1]
             if slots >= 5: break
-            w = re.match(r'v_readfirstlane_b32 s(\d+),', u)
+            w = re.match(r'v_read(?:first)?lane_b32 s(\d+),', u)
             if w and int(w.group(1)) in need:
                 bad += 1
                 print('  SGPR HAZARD %s line %d: %s  (written at line %d, %d wait states)' % (name, i + 1, t, real[j][0] + 1, slots))
                 break
             n = re.match(r's_nop (\d+)', u)
             slots += (int(n.group(1)) + 1) if n else 1
+    in_asm, flag = set(), False
+    for i, l in enumerate(lines):
+        u = l.strip()
+        if u.startswith(';;#ASMSTART'): flag = True
+        elif u.startswith(';;#ASMEND'): flag = False
+        elif flag: in_asm.add(i)
+    for k, (i, t) in enumerate(real):                                 # store data overwritten too early (inline-asm stores: hipcc guards its own)
+        if i not in in_asm: continue
+        if not (t.startswith('global_store_dwordx4') or t.startswith('buffer_store_dwordx4') or t.startswith('global_store_dwordx3')): continue
+        ops = t.split(None, 1)[1].split(',')
+        data = set(regs(ops[1] if t.startswith('global_store') else ops[0]))
+        slots = 0
+        for j in range(k + 1, min(k + 4, len(real))):
+            u = real[j][1]
+            n = re.match(r's_nop (\d+)', u)
+            if n: slots += int(n.group(1)) + 1; continue
+            if slots >= 2: break
+            if u.startswith('s_') or u.startswith('.LBB'): slots += 1; continue
+            dst = u.split(None, 1)[1].split(',')[0] if ' ' in u else ''
+            if not (u.startswith('global_store') or u.startswith('buffer_store') or u.startswith('ds_write')) and data & set(regs(dst)):
+                bad += 1
+                print('  STORE-DATA HAZARD %s line %d: %s   then line %d: %s' % (name, i + 1, t, real[j][0] + 1, u))
+                break
+            slots += 1
     return bad
 
 
