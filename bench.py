@@ -185,7 +185,7 @@ def load_traffic(B: int):
             t = json.load(f)
         if int(t.get("batch", 1)) != B:
             return None, f"no PMC pass for batch {B}"
-        return int(t["corrected_bytes_per_launch_per_slice"] * B), t.get("source")
+        return int(t["corrected_bytes_per_launch_per_slice"] * B), (t.get("kernel", "") + ": " + t.get("source", ""))
     except (OSError, KeyError, ValueError):
         return None, (None if B == 1 else f"no PMC pass for batch {B} (profiles/conv_traffic_batch{B}.json)")
 

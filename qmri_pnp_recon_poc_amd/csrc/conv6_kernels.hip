@@ -1331,31 +1331,32 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
         {
             u32x4 pa1[NAQ];
             R_REQ(ra0) R_REQ(pa1) R_REQ(ra1) R_REQ(ra2)             // steps 0 .. 3
-            // the whole input tile with its ring, fp32 -> pieces: 8 channel blocks x 324 pixels x 2 halves, 21 per thread in three batches
-            constexpr int NHALF = 8 * R_IH * R_IW * 2;
-#pragma unroll 1
-            for (int batch = 0; batch < 3; ++batch) {
-                f32x4 v[7];
-                unsigned lo[7];
+            // the whole input tile with its ring, fp32 -> pieces: 8 channel blocks x 324 pixels x 2 halves, 21 per thread, all requested at once (one
+            // memory latency; the matrix waves wait for this anyway and the loader waves have the registers)
+            constexpr int NHALF = 8 * R_IH * R_IW * 2, NPRO = (NHALF + NLD6 - 1) / NLD6;
+            f32x4 v[NPRO];
+            unsigned lo[NPRO];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    const int idx = lt + NLD6 * (batch * 7 + k);
-                    const bool valid = idx < NHALF;
-                    const int idc = valid ? idx : 0, half = idc & 1, item = idc >> 1;
-                    const int cb = item / (R_IH * R_IW), px = item - cb * (R_IH * R_IW), dw = px / R_IH, dh = px - dw * R_IH;
-                    gload4r(v[k], (unsigned)cb * plane32 + (unsigned)((dw * A.hp + dh) * 32 + 16 * half) + tile0, A.src);
-                    lo[k] = valid ? (unsigned)(((cb >> 1) * R_CHUNK + (cb & 1) * NPX + dw * IHP + dh) * 16 + 8 * half) : ~0u;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6])::"memory");
+            for (int k = 0; k < NPRO; ++k) {
+                const int idx = lt + NLD6 * k;
+                const bool valid = idx < NHALF;
+                const int idc = valid ? idx : 0, half = idc & 1, item = idc >> 1;
+                const int cb = item / (R_IH * R_IW), px = item - cb * (R_IH * R_IW), dw = px / R_IH, dh = px - dw * R_IH;
+                gload4r(v[k], (unsigned)cb * plane32 + (unsigned)((dw * A.hp + dh) * 32 + 16 * half) + tile0, A.src);
+                lo[k] = valid ? (unsigned)(((cb >> 1) * R_CHUNK + (cb & 1) * NPX + dw * IHP + dh) * 16 + 8 * half) : ~0u;
+            }
+            static_assert(NPRO == 21, "the wait below names 21 registers");
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
+                           "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20])::"memory");
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    uint2 s0, s1;
-                    split_pair_h(v[k][0], v[k][1], s0.x, s1.x);
-                    split_pair_h(v[k][2], v[k][3], s0.y, s1.y);
-                    if (lo[k] != ~0u) {
-                        *(uint2*)((unsigned char*)Bt + lo[k]) = s0;
-                        *(uint2*)((unsigned char*)Bt + lo[k] + 2 * NPX * 16) = s1;
-                    }
+            for (int k = 0; k < NPRO; ++k) {
+                uint2 s0, s1;
+                split_pair_h(v[k][0], v[k][1], s0.x, s1.x);
+                split_pair_h(v[k][2], v[k][3], s0.y, s1.y);
+                if (lo[k] != ~0u) {
+                    *(uint2*)((unsigned char*)Bt + lo[k]) = s0;
+                    *(uint2*)((unsigned char*)Bt + lo[k] + 2 * NPX * 16) = s1;
                 }
             }
             gwait_a<0>(ra0); gwait_a<0>(pa1);
@@ -1566,7 +1567,8 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                     }                                                                                            \
         }
         if (conv2) R_ADD_OPERAND()                                  // the block input (uniform branches)
-        if (conv2 && last && A.skip) {                              // the run's last layer also adds the skip tensor (UNetRes.forward, network_unet.py:106-117)
+        if (conv2 && last && A.skip) {                              // the run's last layer also adds the skip tensor (UNetRes.forward, network_unet.py:106-117); (requesting it together
+                                                                    // with the block input -- one latency less, once per forward -- costs 226 spilled registers: not done)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll

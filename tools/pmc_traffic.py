@@ -77,6 +77,43 @@ def main_batch(dfetch, dwrite, batch):
     print(txt)
 
 
+def main_resident(f, w):
+    """k_conv6r: one launch = the eight ResBlock layers of the 224 x 224 x 64 level with LDS-resident tiles (conv6_kernels.hip).  Two launches per
+    forward pass: the down path's (no skip operand) and the up path's (+ the skip tensor at the last layer): the two populations of FETCH_SIZE.
+    Every request is 16 B per lane: FETCH_SIZE x 2.  Algorithmic bytes per launch: the input tile with its ring once, the four block inputs read
+    back as residual operands, the four ResBlock outputs written, seven ring exchanges (196 tiles x 368 triples x 64 B written and read), the
+    weights of eight layers once per XCD -- and for the up path the skip tensor."""
+    med = lambda a: sorted(a)[len(a) // 2]
+    half = len(f) // 2
+    f_down, f_up = med(f[:half]) * 1024, med(f[half:]) * 1024
+    wm = med(w) * 1024
+    xch = 196 * 368 * 64
+    alg_w = 8 * ALG["weights_f16_pairs"] * 8
+    alg_read_down = ALG["input_with_halo"] + 4 * ALG["residual"] + 7 * xch + alg_w
+    alg_read_up = alg_read_down + ALG["residual"]
+    alg_write = 4 * ALG["output"] + 7 * xch
+    per_layer = ((2 * f_down + wm) + (2 * f_up + wm)) / 2 / 8
+    out = {"kernel": "k_conv6r (224 x 224 x 64 level: the eight ResBlock layers of a path in one launch, 196 workgroups with LDS-resident tiles)", "batch": 1,
+           "launches": {"down_path": half, "up_path": len(f) - half}, "layers_per_launch": 8,
+           "raw": {"fetch_down_bytes": int(f_down), "fetch_up_bytes": int(f_up), "write_bytes": int(wm)},
+           "corrected": {"fetch_down_bytes": int(2 * f_down), "fetch_up_bytes": int(2 * f_up), "write_bytes": int(wm)},
+           "algorithmic": {"read_down_bytes": alg_read_down, "read_up_bytes": alg_read_up, "write_bytes": alg_write, "ring_exchange_bytes_per_layer": xch, **ALG},
+           "ratio_corrected_over_algorithmic": {"down_path": round((2 * f_down + wm) / (alg_read_down + alg_write), 3), "up_path": round((2 * f_up + wm) / (alg_read_up + alg_write), 3)},
+           "corrected_bytes_per_launch": int(((2 * f_down + wm) + (2 * f_up + wm)) / 2),
+           "corrected_bytes_per_launch_per_slice": int(per_layer),
+           "per_layer_note": "corrected_bytes_per_launch_per_slice = bytes per LAYER (a launch is eight layers): against 29.5 / 42.6 MB of a plain / residual layer "
+                             "launched alone (profiles/r04_l_pmc_conv_traffic.txt): the ReLU intermediates never leave the chip",
+           "tensor_format": "blocked [c/8][w][h][8]",
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/prof_net.py 1 3; tools/pmc_traffic.py; FETCH x2 (every request of the kernel is 16 B per lane)"}
+    with open(os.path.join(ROOT, "profiles", "conv_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    txt = json.dumps(out, indent=1)
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as fh:
+            fh.write(txt + "\n")
+    print(txt)
+
+
 def main():
     batch = 1
     if sys.argv[1] == "--batch":
@@ -84,6 +121,9 @@ def main():
     dfetch, dwrite = sys.argv[1], sys.argv[2]
     if batch > 1:
         return main_batch(dfetch, dwrite, batch)
+    rf, rw = [v for (_, n, g, v) in rows(dfetch, "FETCH_SIZE") if "k_conv6r" in n], [v for (_, n, g, v) in rows(dwrite, "WRITE_SIZE") if "k_conv6r" in n]
+    if rf and rw:
+        return main_resident(sorted(rf), sorted(rw))
     sel = lambda rs: [v for (_, n, g, v) in rs if "k_conv6<0, 2" in n and g == 196 * 512]
     f, w = sel(rows(dfetch, "FETCH_SIZE")), sel(rows(dwrite, "WRITE_SIZE"))
     if not f or not w:
