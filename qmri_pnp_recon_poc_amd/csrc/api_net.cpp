@@ -324,7 +324,9 @@ static int run_resblocks(qmri_ctx* ctx, size_t& li, int nb, int B, const PTensor
     NetPlan& p = ctx->net;
     if (p.d_res_xbuf && src.H == p.H && !p.force_f32) {            // the full-resolution level: one launch with resident tiles where it applies
         bool done = false;
-        QMRI_TRY(conv6r_try(ctx, &p.layers[li], 2 * nb, B, src, cur, skip, &done));
+        Conv6rRun r;
+        r.res = &p.layers[li]; r.nres = 2 * nb; r.src = &src; r.cur = &cur; r.skip = skip;
+        QMRI_TRY(conv6r_try(ctx, r, B, &done));
         if (done) { li += (size_t)(2 * nb); return QMRI_OK; }
     }
     const PTensor* in = &src;
@@ -386,9 +388,18 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
         return QMRI_OK;
     }
     // UNetRes.forward, network_unet.py:106-117
-    QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.in32, p.x[0], nullptr, nullptr, 0));                       // x1 = m_head(x0)
+    // (the head belongs to the down path's resident-tile launch of the full-resolution level where that applies: QMRI_RES_HEAD=0 keeps it apart)
+    static const bool res_ends = !(getenv("QMRI_RES_HEAD") && atoi(getenv("QMRI_RES_HEAD")) == 0);
+    bool head_done = false;
+    if (res_ends && p.d_res_xbuf && !p.force_f32 && p.layers.size() >= (size_t)(2 + 2 * nb)) {
+        Conv6rRun r;
+        r.head = &p.layers[0]; r.head_in = &p.in32; r.res = &p.layers[1]; r.nres = 2 * nb; r.src = &p.x[0]; r.cur = &p.a[0];
+        QMRI_TRY(conv6r_try(ctx, r, B, &head_done));
+        if (head_done) li = (size_t)(1 + 2 * nb);
+    }
+    if (!head_done) QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.in32, p.x[0], nullptr, nullptr, 0));      // x1 = m_head(x0)
     for (int l = 0; l < 3; ++l) {                                                                          // x_{l+2} = m_down_{l+1}(x_{l+1})
-        QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[l], p.a[l], p.t[l], nullptr));
+        if (!(l == 0 && head_done)) QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[l], p.a[l], p.t[l], nullptr));
         QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[l], p.x[l + 1], nullptr, nullptr, 0));
     }
     QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[3], p.a[3], p.t[3], &p.x[3]));                               // m_body(x4) + x4

@@ -358,8 +358,14 @@ bool conv6_weights_fit_f16(const float* w, size_t n);
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out);
-// a run of nl 64-channel 3x3 layers (ResBlocks) as one launch with LDS-resident tiles; *done = false: not eligible, nothing launched
-int conv6r_try(qmri_ctx* ctx, const ConvLayer* Ls, int nl, int B, const PTensor& src, const PTensor& cur, const PTensor* skip, bool* done);
+// a run of 3x3 layers of the full-resolution level as ONE launch with LDS-resident tiles (conv6_kernels.hip k_conv6r): nres = 2 nb ResBlock layers
+// 64 -> 64 on src -> cur (+ skip at the last one), optionally with the network's head in front (head_in -> src)
+struct Conv6rRun {
+    const ConvLayer* head = nullptr; const PTensor* head_in = nullptr;
+    const ConvLayer* res = nullptr; int nres = 0;
+    const PTensor* src = nullptr; const PTensor* cur = nullptr; const PTensor* skip = nullptr;
+};
+int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done);   // *done = false: not eligible, nothing launched
 size_t conv6r_xbuf_bytes(int tiles);
 void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);   // 2x2 / stride-2 layers
 bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out);
