@@ -280,7 +280,7 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
             QMRI_TRY(dev_alloc(ctx, &p.d_res_xbuf, conv6r_xbuf_bytes(p.res_tiles)));
             QMRI_HIP(ctx, hipMemset(p.d_res_xbuf, 0, conv6r_xbuf_bytes(p.res_tiles)));
             p.res_epoch = 0; p.res_off = false;
-            if (getenv("QMRI_RES_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_res_stamps, 512 * sizeof(unsigned long long))); QMRI_HIP(ctx, hipMemset(p.d_res_stamps, 0, 512 * sizeof(unsigned long long))); }
+            if (getenv("QMRI_RES_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_res_stamps, 1024 * sizeof(unsigned long long))); QMRI_HIP(ctx, hipMemset(p.d_res_stamps, 0, 1024 * sizeof(unsigned long long))); }
         }
     } else {
         const int width = desc->nc[0];
@@ -995,9 +995,9 @@ extern "C" int qmri_recon_batch(int ndev, const int* devs, int nslices, const qm
 
 // diagnostic: copy the per-workgroup stamps of the most recent conv launch (see conv_kernels.hip) to the host
 extern "C" int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int nwg) {
-    if (ctx && nwg == -6 && ctx->net.d_res_stamps) {                // (the resident-tile launch's stamps: 512 values, QMRI_RES_STAMPS=1)
+    if (ctx && nwg == -6 && ctx->net.d_res_stamps) {                // (the resident-tile launch's stamps: 1024 values, QMRI_RES_STAMPS=1)
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        QMRI_HIP(ctx, hipMemcpy(out, ctx->net.d_res_stamps, (size_t)512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        QMRI_HIP(ctx, hipMemcpy(out, ctx->net.d_res_stamps, (size_t)1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return QMRI_OK;
     }
     if (!ctx || !ctx->net.d_stamps) return QMRI_ERR_STATE;

@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
             const unsigned char* xb = A.xbuf + (size_t)(l & 1) * A.xbuf_half;
             // the neighbours publish about now and their stores need ~1 us to be visible: requests sent at once only find old tags -- and 196 x 256
             // lanes re-reading 17 KB each slow the stores they wait for (measured per forward: 1117 us without the pause, 1094 - 1104 with 32 - 48 units)
-            for (int i = 0; i < A.delay; ++i) __builtin_amdgcn_s_sleep(1);
+            for (int i = 0; i < A.delay; ++i) __builtin_amdgcn_s_sleep(1);     // (timed against the 100 MHz clock instead -- the chip's own varies between boxes -- it was slower at every setting: the clock reads of 784 waves are traffic of their own)
             {
                 bool pend[2] = {c_x[0] != ~0u && !dead, c_x[1] != ~0u && !dead};
                 bool ok = false;
@@ -2668,7 +2668,7 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     A.xbuf = net.d_res_xbuf; A.xbuf_half = (size_t)tiles * R_NTRI * 64;
     static const int xcd_order = getenv("QMRI_CONV_XCD") ? atoi(getenv("QMRI_CONV_XCD")) : 1;
     A.xcd = xcd_order;
-    static const int delay = getenv("QMRI_RES_DELAY") ? std::max(0, std::min(4096, atoi(getenv("QMRI_RES_DELAY")))) : 40;
+    static const int delay = getenv("QMRI_RES_DELAY") ? std::max(0, std::min(4096, atoi(getenv("QMRI_RES_DELAY")))) : 24;
     A.epoch = net.res_epoch; A.drop = net.res_drop; A.delay = delay;
     A.range_flag = net.d_range_flag; A.am_slots = net.d_act_slots; A.am_count = net.d_act_count;
     if (!ctx->conv6r_attr) {

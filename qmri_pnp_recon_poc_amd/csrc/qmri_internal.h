@@ -205,7 +205,7 @@ struct NetPlan {
     bool res_off = false;
     int res_timeouts = 0;
     int res_drop = 0;                // test hook: bit 0 = tile 0 withholds its hand-off
-    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (QMRI_RES_STAMPS=1), 4 x 2 x 8 x 8 values
+    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (QMRI_RES_STAMPS=1), 4 x 2 x R_MAXL (9) x 8 of 1024 values
     bool ready = false;
 };
 

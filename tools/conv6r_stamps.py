@@ -17,10 +17,10 @@ e.set_denoiser(w, 224, 224, max_batch=1)
 x = np.random.default_rng(3).random((224, 224, 10))
 for _ in range(5):
     e.denoise(x)
-out = (C.c_ulonglong * 512)()
+out = (C.c_ulonglong * 1024)()
 e.L.qmri_debug_conv_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 assert e.L.qmri_debug_conv_stamps(e.h, out, -6) == 0
-s = np.array(out[:], dtype=np.int64).reshape(4, 2, 8, 8)
+s = np.array(out[:576], dtype=np.int64).reshape(4, 2, 9, 8)             # [workgroup][matrix / loader wave 0][layer < R_MAXL][stamp]; the last launch = the up path's eight layers
 us = lambda a, b: (b - a) / 100.0
 print("matrix wave 0: loop | residual operand | epilogue (split, LDS writes, stores) | wait E2 | ring fetch (poll-loads, LDS writes) | wait E3   ;   loader wave 0: E1->E2 | publish (issue) | wait E3     [us]")
 for wg in range(4):
