@@ -132,6 +132,7 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
         p.res_timeouts += 1;
         return QMRI_OK;
     }
+    if (getenv("QMRI_CALIB_VERBOSE")) fprintf(stderr, "libqmri: range guard of the f16 scheme tripped (flag %u: 1 overflow, 2 a layer collapsed): the network moves to the bf16 scheme\n", f);
     QMRI_TRY(net_set_scheme(ctx, 3));
     p.fallbacks += 1;
     return QMRI_OK;

@@ -538,3 +538,39 @@ def test_resident_tile_launch_recovers_from_a_lost_hand_off(engine_mod, synth, c
     assert e.conv_resident(1) == 2
     assert np.array_equal(e.denoise(x), ref) and e.conv_resident(1) == 2    # hook off: the resident form runs again, no further time-out
     e.close()
+
+
+def test_resident_tile_launch_survives_a_second_context_on_the_device(engine_mod, synth, capfd):
+    """k_conv6r needs all its 196 workgroups on the chip at once.  Two contexts on two host threads launching it at the same time may each get
+    half of the CUs: neither launch is complete, both wait -- for a bounded time; the waits give up, the library repeats the calls with one
+    launch per layer and keeps the resident form off for the context that saw it.  Whatever the interleaving: no hang, every result is the
+    reference's, bit for bit, and the network stays on the f16 scheme.  (The first run of this test found a false alarm of the f16 range guard that is
+    older than k_conv6r: the epilogue of the 32-row tile configuration also range-checked the LDS rows of the half it does not compute -- with one
+    context those hold the network's own weights, with a second context's kernels on the same CU anything, and both networks fell back to bf16 pieces.)"""
+    import threading
+    w = synth.random_weights(seed=1, gain=0.7)
+    x = np.random.default_rng(13).random((224, 224, 10))
+    e0 = engine_mod.Engine(0)
+    e0.set_denoiser(w, 224, 224)
+    e0.conv_resident(0)
+    ref = e0.denoise(x)
+    e0.conv_resident(1)
+    e1 = engine_mod.Engine(0)
+    e1.set_denoiser(w, 224, 224)
+    bad = []
+
+    def work(e):
+        for _ in range(12):
+            if not np.array_equal(e.denoise(x), ref):
+                bad.append(1)
+
+    ts = [threading.Thread(target=work, args=(e,)) for e in (e0, e1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in ts) and not bad
+    n0, n1 = e0.conv_resident(1), e1.conv_resident(1)               # time-outs seen per context: 0 if the launches never overlapped halfway
+    assert n0 <= 1 and n1 <= 1 and e0.denoiser_scheme() == (2, 0) and e1.denoiser_scheme() == (2, 0)
+    capfd.readouterr()
+    e0.close(); e1.close()
