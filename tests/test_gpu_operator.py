@@ -284,3 +284,41 @@ def test_every_cut_operator_and_lsqr_224(engine_mod, oracle, synth, T, mask):
     assert (ig, fg_) == (io, fo)
     assert rel_err(xg, xo) < 1e-10
     e.close()
+
+
+def test_admm_two_contexts_on_one_device_concurrently(engine_mod, synth, case224, capfd):
+    """Two reconstructions at once on one device, one context and one host thread each.  The one-launch LSQR kernel and the resident-tile
+    convolution launch both need all their workgroups on the chip together; with a second context's kernels in between they may not get them:
+    their waits are bounded, the calls repeat themselves on the forms that need no co-residency, and x and the LSQR counts come out identical
+    to a run alone -- whatever the interleaving, and without the f16 range guard mistaking the neighbour's LDS leftovers for an overflow."""
+    import threading
+    y = case224["y"]
+    w = synth.structured_weights(seed=2, eps=0.02)
+    es = []
+    for _ in range(2):
+        e = engine_mod.Engine(0)
+        e.set_operator(224, 224, case224["dic"]["V"], case224["fp"], case224["k"])
+        e.set_denoiser(w, 224, 224)
+        es.append(e)
+    xr, _, lr = es[0].pnp_admm(y, iters=8)
+    res = [None, None]
+
+    def work(i):
+        out = []
+        for _ in range(3):
+            out.append(es[i].pnp_admm(y, iters=8))
+        res[i] = out
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=280)
+    assert not any(t.is_alive() for t in ts)
+    for i in range(2):
+        for x, _, l in res[i]:
+            assert np.array_equal(l, lr) and np.array_equal(x, xr)
+        assert es[i].denoiser_scheme() == (2, 0)
+    capfd.readouterr()
+    for e in es:
+        e.close()
