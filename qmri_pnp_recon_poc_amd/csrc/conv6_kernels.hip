@@ -1215,26 +1215,30 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 // =====================================================================================================================
 // k_conv6r : the ResBlocks of the full-resolution level (64 channels) in ONE launch, every workgroup's tile RESIDENT in LDS.
 //
-// A 3x3 layer launched alone (k_conv6, one slice) is a serial chain: first operands 2 us -> 12 steps whose pace the loader waves set
-// (activations: request, split, store) -> epilogue stores 2.3 - 4 us -> kernel boundary 2 us; and the tile a workgroup writes is, but
-// for a one-pixel ring, the tile the same workgroup reads in the next layer.  Here a workgroup keeps its 18 x 18 x 64 input tile in
-// LDS as f16 pieces (109 KB next to the 36 KB of weight buffers) for all 2 nb layers of a run of ResBlocks (basicblock.py:211-223):
-//   * the loop streams WEIGHTS only (the loader waves run straight across layer ends: the next layer's first steps are in LDS before
-//     the previous layer's epilogue starts);
-//   * the epilogue splits the outputs and writes them IN PLACE into the resident tile (the input is dead once the loop is over);
-//     ResBlock outputs also go to memory as fp32 (they are residual operands -- read back by this workgroup alone -- and the run's
-//     result), the ReLU intermediates never leave the chip;
-//   * the one-pixel ring comes from the eight neighbouring workgroups through memory: each tile stores its 60 edge pixels as pieces
-//     (15 KB) into a scratch tensor of the layer's parity and raises its counter; a tile polls its neighbours' counters and loads its
-//     68-pixel ring (17 KB; the image border reads the tensor's permanent zero halo).  Hand-off form: 16-byte sc1 stores -> every storing
-//     wave's vmcnt(0) -> workgroup barrier -> one lane's agent-scope add; consumer: each loader wave polls for itself (sc1 loads),
-//     then sc1 16-byte loads (MI355X_MICROARCH.md, valid forms, first row).  Two scratch tensors in turn make the exchange race-free:
-//     a tile overwrites its layer-l edges at layer l + 2, which it reaches only after its neighbours published layer l + 1, i.e. after
-//     they consumed layer l.
-// All 196 workgroups must be resident at once (one per CU by LDS size; the host checks tiles <= CUs).  A poll that does not succeed in
-// R_SPIN_MAX tries raises bit 2 of the range flag and the workgroup runs on without waiting (so nobody waits for IT); the host then
-// repeats the call with one launch per layer and keeps this path off.
-// Arithmetic, operand order and rounding are those of k_conv6: results are bit-identical (tests/test_gpu_net.py).
+// A 3x3 layer launched alone (k_conv6, one slice) is a serial chain: first operands 2 us -> 12 steps at the matrix cores' sustained rate
+// (9.4 us) -> epilogue stores 2.3 - 4 us -> kernel boundary 2 us; and the tile a workgroup writes is, but for a one-pixel ring, the tile
+// the same workgroup reads in the next layer.  Here a workgroup keeps its 18 x 18 x 64 input tile in LDS as f16 pieces (109 KB next to
+// the 36 KB of weight buffers) for all layers of a run of ResBlocks (basicblock.py:211-223), the network's head in front where it applies:
+//   * the loop (k_conv6's: same fragments, same MFMA order) reads activations from the resident tile; the loader waves stream WEIGHTS
+//     only, straight across layer ends (the next layer's first steps are in LDS before the previous layer's epilogue starts);
+//   * the epilogue stays in the matrix waves' registers (descale, + block input, ReLU, range check, f16 split) and writes the pieces IN
+//     PLACE into the resident tile (the input is dead once the loop is over); ResBlock outputs also go to memory as fp32 (they are
+//     residual operands -- read back by this workgroup alone -- and the run's result), the ReLU intermediates never leave the chip;
+//   * the one-pixel ring comes from the eight neighbouring workgroups through memory, as TAGGED GRANULES: the loader waves publish the
+//     tile's edges (columns w = 0 / 15, rows h = 0 / 15, four corner pixels: 368 triples of three 16-byte LDS entries) as 8-byte words
+//     {3 x f16, 16-bit tag}, four 16-byte sc1 stores per triple, into the tile's part of the exchange buffer of the layer's parity; the
+//     matrix waves (idle between two layers) pause, request the matching segments of the eight neighbours, check the eight tags of each
+//     triple, write its three entries into the ring and ask again for what was not complete.  No counter, no drain of the stores, no
+//     barrier between publish and fetch: a granule is its own flag (MI355X_MICROARCH.md, valid forms, R2).  Two buffers in turn make it
+//     race-free: a tile overwrites its layer-l edges at layer l + 2, which it reaches only after its neighbours published layer l + 1,
+//     i.e. after they consumed layer l.  The tag is a running count the host never resets.  At the image border nothing is fetched: the
+//     ring there keeps the zeros of the run input's halo.
+// The launch is a small layer program (Conv6rArgs: per layer the chunks of its input, what its epilogue does, the tensors involved).
+// All 196 workgroups must be resident at once (one per CU by LDS size; the host checks tiles <= CUs).  A fetch that is not complete after
+// R_SPIN_MAX attempts raises bit 2 of the range flag and the wave runs on without waiting (its workgroup goes on publishing, so nobody
+// waits for IT); the host then repeats the call with one launch per layer and keeps this path off (api_net.cpp net_range_tripped).
+// Arithmetic, operand order and rounding are those of k_conv6: results are bit-identical (tests/test_gpu_net.py).  DESIGN.md section 5.1
+// has the measurements and what was tried on the way.
 // =====================================================================================================================
 constexpr int R_MAXL = 9;                                   // layers per launch (2 nb ResBlock layers + the network's head)
 // what a layer of the launch does behind its loop (Conv6rArgs::kind)
