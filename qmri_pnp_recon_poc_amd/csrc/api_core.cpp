@@ -696,7 +696,7 @@ extern "C" int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out) {
     return QMRI_OK;
 }
 
-int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers) {
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers, float share) {
     *start = *stop = nullptr;
     if (ctx->prof_level < 2) return QMRI_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -710,6 +710,8 @@ int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layer
     *stop = ctx->chain[ctx->chain_n + 1];
     if (ctx->chain_w.size() < ctx->chain_n / 2 + 1) ctx->chain_w.resize(ctx->chain_n / 2 + 1, 1);
     ctx->chain_w[ctx->chain_n / 2] = layers;
+    if (ctx->chain_s.size() < ctx->chain_n / 2 + 1) ctx->chain_s.resize(ctx->chain_n / 2 + 1, 1.f);
+    ctx->chain_s[ctx->chain_n / 2] = share;
     ctx->chain_n += 2;
     return QMRI_OK;
 }
@@ -722,7 +724,7 @@ int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv, long count) {
         float ms = 0.f;
         QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->chain[i], ctx->chain[i + 1]));
         if (tv) { ctx->prof.ms_tv_iter += ms; ctx->prof.n_tv_iter += 1; }
-        else { ctx->prof.ms_conv3x3 += ms; ctx->prof.n_conv3x3 += (i / 2 < ctx->chain_w.size()) ? ctx->chain_w[i / 2] : 1; }
+        else { ctx->prof.ms_conv3x3 += ms * ((i / 2 < ctx->chain_s.size()) ? ctx->chain_s[i / 2] : 1.f); ctx->prof.n_conv3x3 += (i / 2 < ctx->chain_w.size()) ? ctx->chain_w[i / 2] : 1; }
     }
     ctx->chain_n = 0;
     return QMRI_OK;

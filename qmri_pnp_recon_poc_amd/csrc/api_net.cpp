@@ -391,6 +391,7 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
     // UNetRes.forward, network_unet.py:106-117
     // (the head belongs to the down path's resident-tile launch of the full-resolution level where that applies: QMRI_RES_HEAD=0 keeps it apart)
     static const bool res_ends = !(getenv("QMRI_RES_HEAD") && atoi(getenv("QMRI_RES_HEAD")) == 0);
+    static const bool res_tail = !(getenv("QMRI_RES_TAIL") && atoi(getenv("QMRI_RES_TAIL")) == 0);
     bool head_done = false;
     if (res_ends && p.d_res_xbuf && !p.force_f32 && p.layers.size() >= (size_t)(2 + 2 * nb)) {
         Conv6rRun r;
@@ -406,6 +407,13 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
     QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[3], p.a[3], p.t[3], &p.x[3]));                               // m_body(x4) + x4
     for (int l = 3; l > 0; --l) {                                                                          // m_up_l(x + x_{l+1})
         QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[l], p.a[l - 1], nullptr, nullptr, 0));               // transposed conv
+        if (l == 1 && res_tail && p.d_res_xbuf && !p.force_f32 && li + (size_t)(2 * nb) < p.layers.size()) {   // ... the level's ResBlocks and the tail in one launch
+            bool done = false;
+            Conv6rRun r;
+            r.res = &p.layers[li]; r.nres = 2 * nb; r.src = &p.a[0]; r.cur = &p.a[0]; r.skip = &p.x[0]; r.tail = &p.layers[li + 2 * nb]; r.tail_out = &p.out32;
+            QMRI_TRY(conv6r_try(ctx, r, B, &done));
+            if (done) { li += (size_t)(2 * nb + 1); return QMRI_OK; }
+        }
         QMRI_TRY(run_resblocks(ctx, li, nb, B, p.a[l - 1], p.a[l - 1], p.t[l - 1], &p.x[l - 1]));
     }
     QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[0], p.out32, nullptr, nullptr, 0));                      // m_tail(x + x1)

@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 // Arithmetic, operand order and rounding are those of k_conv6: results are bit-identical (tests/test_gpu_net.py).  DESIGN.md section 5.1
 // has the measurements and what was tried on the way.
 // =====================================================================================================================
-constexpr int R_MAXL = 9;                                   // layers per launch (2 nb ResBlock layers + the network's head)
+constexpr int R_MAXL = 10;                                  // layers per launch (2 nb ResBlock layers + the network's head or tail)
 // what a layer of the launch does behind its loop (Conv6rArgs::kind)
 constexpr int R_RELU = 1;                                   // ReLU
 constexpr int R_ADD = 2;                                    // + radd[l] (an fp32 BLOCKED tensor, this tile's pixels: a ResBlock's input)
@@ -1248,6 +1248,7 @@ constexpr int R_SKIP = 4;                                   // + skip, after it
 constexpr int R_STORE = 8;                                  // the output goes to sdst[l] as fp32 (BLOCKED): a later layer's residual operand
 constexpr int R_STORE_WT = 16;                              // ... written through: the run's result
 constexpr int R_KEEP = 32;                                  // a layer follows: pieces in place into the resident tile, ring exchange
+constexpr int R_TAIL = 64;                                  // the network's last layer (<= 16 output channels): first 32-row tile of the weights only, PLANAR fp32 output
 constexpr int R_IH = 18, R_IW = 18, R_IHP = 24;             // input tile with ring; LDS row pitch (= 8 mod 16 entries, as in k_conv6)
 constexpr int R_NPX = R_IHP * (R_IW - 1) + R_IH;            // LDS entries per (split, k-half) plane
 constexpr int R_CHUNK = 2 * 2 * R_NPX;                      // ... per 16-channel chunk: [split][k-half][R_NPX]
@@ -1260,6 +1261,7 @@ constexpr size_t conv6r_lds() { return (size_t)(NABUF * R_AST + 4 * R_CHUNK) * 1
 struct Conv6rArgs {
     const float* src; const float* skip;                    // fbase of the run's input (BLOCKED 64 channels, or the PLANAR network input: in_planar) and of the skip tensor (or null)
     const float* radd[R_MAXL]; float* sdst[R_MAXL];         // per layer: the operand R_ADD adds, where R_STORE / R_STORE_WT store (BLOCKED fp32 tensors of the level's geometry)
+    float* out; int out_hp, out_plane, out_c;               // R_TAIL: the PLANAR output tensor (fbase), its pitch and plane (elements), its channels (<= 16)
     int in_planar, in_plane;                                // the run's first layer is the network's head: src = the PLANAR input (16 channels allocated), its plane (elements)
     int nch[R_MAXL], kind[R_MAXL];                          // 16-channel chunks of the layer's input (1: the head; 4), R_* flags
     unsigned char* xbuf; size_t xbuf_half;                  // exchange buffer [2 layer parities][tiles][R_NTRI][64 bytes]; bytes per parity
@@ -1456,6 +1458,16 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                 R_ITER(2, ra0, ra2)
             }
             R_STAMP(1, 0);
+            if (A.kind[l] & R_TAIL) {                               // the network's output: out_c planes of this tile from the matrix waves' LDS copy
+                lds_barrier6();
+                const float* tl = (const float*)Bt;
+                const unsigned opx = (unsigned)(((ow0 + (lt >> 4) + 1) * A.out_hp + (oh0 + (lt & 15)) + 1) * 4), opl = (unsigned)A.out_plane * 4u;
+                for (int c = 0; c < A.out_c; ++c) {
+                    const float x = tl[c * 256 + lt];
+                    asm volatile("global_store_dword %0, %1, %2" ::"v"(opx + (unsigned)c * opl), "v"(x), "s"(A.out) : "memory");
+                }
+                break;
+            }
             if (!(A.kind[l] & R_KEEP)) break;                      // (the last layer)
             lds_barrier6();                                         // E2: the matrix waves have written this layer's output into the tile
             R_STAMP(1, 1);
@@ -1551,11 +1563,40 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                 if (T % 3 == 2) lds_barrier6();     /* end of a step (the last one: every wave is done with the tile) */ \
             }                                                                                                    \
         }
-        R_LOOP(2)
+        if (kind & R_TAIL) { R_LOOP(1) } else { R_LOOP(2) }          // (uniform; two copies of the code: a predicate inside the taps costs registers the loop does not have)
 #undef R_LOOP
         unsigned gpx_l = gpx;
         int pxl_l = pxl;
         asm volatile("" : "+v"(gpx_l), "+v"(pxl_l));           // (behind the loop: what is derived from them is then made here, not kept across the loop)
+        if (kind & R_TAIL) {
+            // The network's last layer (64 -> out_c <= 16 channels, no ReLU, no operand): channels 0 .. 15 of the first 32-row tile go through LDS
+            // (the tile is dead: [channel][w][h] fp32, 16 KB) to the loader waves, which store the out_c planes of the PLANAR output -- their side of
+            // the kernel has the scalar registers for it, this side has not.
+            R_STAMP(0, 1);
+            R_STAMP(0, 2);
+            float* tl = (float*)Bt;
+            const float dh_ = A.dh[l], dl_ = A.dl[l];
+            float gmax = 0.f;
+            bool bad = false;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = 8 * rg + 4 * h2 + j;
+                        const float x = __builtin_fmaf(accl[0][n][4 * rg + j], dl_, acc[0][n][4 * rg + j] * dh_);
+                        tl[(ch * 16 + pbw + (li >> 3)) * 16 + 8 * n + (li & 7)] = x;
+                        const float xa = (ch < A.out_c) ? fabsf(x) : 0.f;
+                        bad |= !(xa <= F16_RANGE);
+                        gmax = fmaxf(gmax, xa);
+                    }
+            if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+            act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, gmax, 4);
+            lds_barrier6();                                         // the loader waves store it
+            R_STAMP(0, 3);
+            break;
+        }
         // ---- epilogue in registers.  C/D layout: column = lane & 31 = pixel, rows 8 rg + 4 h2 + j = output channels: one lane holds
         // four consecutive channels (half a channel block: cb = 4 m + rg, half h2) of its pixel per (m, n, rg).  Straight-line forms per
         // kind of layer, packed fp32 arithmetic where gfx950 has it.
@@ -1645,7 +1686,8 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
         typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1; typedef std::integral_constant<int, 2> S2;
         if ((kind & R_RELU) && (kind & R_KEEP)) finish(T1{}, S0{}, T1{});                                 // a ResBlock's first conv
         else if ((kind & R_STORE) && (kind & R_KEEP)) finish(T0{}, S1{}, T1{});                                  // ... its second one (and the head)
-        else finish(T0{}, S2{}, T0{});                                                                          // the run's result
+        else if (kind & R_STORE_WT) finish(T0{}, S2{}, T0{});                                                   // the run's result
+        else finish(T0{}, S0{}, T1{});                                                                          // the layer in front of the tail: nobody else reads it
         if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
         act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, gmax, 4);
         R_STAMP(0, 3);
@@ -2618,9 +2660,9 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     NetPlan& net = ctx->net;
     static const int resident = getenv("QMRI_CONV_RESIDENT") ? atoi(getenv("QMRI_CONV_RESIDENT")) : 1;
     static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;     // (a captured launch would replay stale tags)
-    const int nres = run.nres, nl = nres + (run.head ? 1 : 0);
+    const int nres = run.nres, nl = nres + (run.head ? 1 : 0) + (run.tail ? 1 : 0);
     if (!resident || graph_replay || net.res_off || !net.d_res_xbuf || B != 1 || nres < 2 || nl > R_MAXL || (nres & 1) || net.d_stamps) return QMRI_OK;
-    if (!run.res || !run.src || !run.cur || (run.head && (!run.head_in || run.skip))) return QMRI_OK;
+    if (!run.res || !run.src || !run.cur || (run.head && (!run.head_in || run.skip)) || (run.tail && !run.tail_out)) return QMRI_OK;
     auto is3 = [](const ConvLayer& L) { return (L.kind == CONV_3X3 || L.kind == CONV_3X3N) && L.sp6 == 2 && L.wp6 && L.n_ct6 == 1; };
     for (int l = 0; l < nres; ++l) {
         const ConvLayer& L = run.res[l];
@@ -2638,6 +2680,12 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
         if (!is3(L) || L.Cout != 64 || L.nchunk6 != 1 || L.Cin > 16 || !in.p || in.blk || in.Cal < 16 || in.H != src.H || in.W != src.W || in.hp != src.hp ||
             in.h0 != src.h0 || src.p == cur.p) return QMRI_OK;
     }
+    if (run.tail) {                                                 // 64 -> out_nc <= 16 to the PLANAR network output
+        const ConvLayer& L = *run.tail;
+        const PTensor& out = *run.tail_out;
+        if (!is3(L) || L.Cin != 64 || L.nchunk6 != 4 || L.Cout > 16 || !out.p || out.blk || out.H != src.H || out.W != src.W ||
+            (size_t)out.Cal * out.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;
+    }
     if (src.H % 16 || src.W % 16) return QMRI_OK;
     if ((size_t)src.Cal * src.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;       // (32-bit byte offsets)
     if (!ctx->conv_ncu) {
@@ -2651,6 +2699,7 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     A.src = run.head ? run.head_in->fbase() : src.fbase();
     A.in_planar = run.head ? 1 : 0; A.in_plane = run.head ? (int)run.head_in->plane() : 0;
     A.skip = run.skip ? run.skip->fbase() : nullptr;
+    if (run.tail) { A.out = run.tail_out->fbase(); A.out_hp = run.tail_out->hp; A.out_plane = (int)run.tail_out->plane(); A.out_c = run.tail->Cout; }
     int l = 0;
     auto put = [&](const ConvLayer& L, int kind, const float* radd, float* sdst) {
         A.wp[l] = reinterpret_cast<const uint4*>(L.wp6);
@@ -2664,8 +2713,10 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
         const bool last = r == nres - 1;
         if (!(r & 1)) put(run.res[r], R_RELU | R_KEEP, nullptr, nullptr);
         else if (!last) put(run.res[r], R_ADD | R_STORE | R_KEEP, (r == 1) ? src.fbase() : cur.fbase(), cur.fbase());
+        else if (run.tail) put(run.res[r], R_ADD | (run.skip ? R_SKIP : 0) | R_KEEP, (r == 1) ? src.fbase() : cur.fbase(), nullptr);   // only the tail reads it
         else put(run.res[r], R_ADD | (run.skip ? R_SKIP : 0) | R_STORE_WT, (r == 1) ? src.fbase() : cur.fbase(), cur.fbase());
     }
+    if (run.tail) put(*run.tail, R_TAIL, nullptr, nullptr);
     for (int k = l; k < R_MAXL; ++k) { A.wp[k] = A.wp[l - 1]; A.nch[k] = A.nch[l - 1]; A.am_layer[k] = -1; }
     A.nlayers = nl; A.hp = src.hp; A.plane = (int)src.plane(); A.tiles_h = tiles_h; A.tiles_w = tiles_w;
     A.xbuf = net.d_res_xbuf; A.xbuf_half = (size_t)tiles * R_NTRI * 64;
@@ -2682,7 +2733,9 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     g_launch_counter.fetch_add(nl, std::memory_order_relaxed);
     A.stamps = (unsigned long long*)net.d_res_stamps;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, nres));                  // (profile level 2: one pair for the launch, counted as its 64 -> 64 layers -- the head's time rides along uncounted, as when it is launched alone)
+    // (profile level 2: one pair for the launch, counted as its 64 -> 64 layers; the head and the tail -- not timed when they are launched alone -- take the
+    //  share of the duration that their matrix work has: a quarter / half of a layer's)
+    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, nres, (float)nres / ((float)nres + (run.head ? 0.25f : 0.f) + (run.tail ? 0.5f : 0.f))));
     if (A.stamps) k_conv6r<true><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
     else if (e0) hipExtLaunchKernelGGL((k_conv6r<false>), dim3(tiles), dim3(NT6), (std::uint32_t)conv6r_lds(), ctx->stream, e0, e1, 0, A);
     else k_conv6r<false><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);

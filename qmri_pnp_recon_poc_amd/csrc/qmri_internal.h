@@ -205,7 +205,7 @@ struct NetPlan {
     bool res_off = false;
     int res_timeouts = 0;
     int res_drop = 0;                // test hook: bit 0 = tile 0 withholds its hand-off
-    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (QMRI_RES_STAMPS=1), 4 x 2 x R_MAXL (9) x 8 of 1024 values
+    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (QMRI_RES_STAMPS=1), 4 x 2 x R_MAXL (10) x 8 of 1024 values
     bool ready = false;
 };
 
@@ -280,6 +280,7 @@ struct qmri_ctx {
     std::vector<hipEvent_t> chain;      // pairs: [2i] start, [2i+1] stop
     size_t chain_n = 0;                 // events handed out in the current forward
     std::vector<int> chain_w;           // layers a pair stands for (1; a resident-tile launch: all its layers)
+    std::vector<float> chain_s;         // share of the pair's duration that belongs to those layers (a resident-tile launch with the head / tail inside: their matrix work's share is left out)
     bool conv6_attr[4][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
     bool conv6i_attr[4] = {false, false, false, false};   // ... of k_conv6i<CFG> (PIECES input)
@@ -348,7 +349,7 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
                 const PTensor* add2, int relu_out);
 int conv_cin_pad(ConvKind kind, int Cin);
 // bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
-int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers = 1);   // profile level 2: next event pair of the forward (else nullptrs)
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers = 1, float share = 1.f);   // profile level 2: next event pair of the forward (else nullptrs)
 int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv = false, long count = -1);   // count >= 0: only the first `count` pairs are accumulated   // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3 (tv: ms_tv_iter / n_tv_iter)
 bool conv6_enabled();
 int conv6_act_begin(qmri_ctx* ctx, int nlayers);           // f16 scheme: start / finish the per-layer |output| report of a forward pass
@@ -364,6 +365,7 @@ struct Conv6rRun {
     const ConvLayer* head = nullptr; const PTensor* head_in = nullptr;
     const ConvLayer* res = nullptr; int nres = 0;
     const PTensor* src = nullptr; const PTensor* cur = nullptr; const PTensor* skip = nullptr;
+    const ConvLayer* tail = nullptr; const PTensor* tail_out = nullptr;   // optional last layer 64 -> out_nc writing the planar network output
 };
 int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done);   // *done = false: not eligible, nothing launched
 size_t conv6r_xbuf_bytes(int tiles);

@@ -20,14 +20,15 @@ for _ in range(5):
 out = (C.c_ulonglong * 1024)()
 e.L.qmri_debug_conv_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 assert e.L.qmri_debug_conv_stamps(e.h, out, -6) == 0
-s = np.array(out[:576], dtype=np.int64).reshape(4, 2, 9, 8)             # [workgroup][matrix / loader wave 0][layer < R_MAXL][stamp]; the last launch = the up path's eight layers
+s = np.array(out[:640], dtype=np.int64).reshape(4, 2, 10, 8)            # [workgroup][matrix / loader wave 0][layer < R_MAXL][stamp]; the last launch = the up path's: eight ResBlock layers + the tail
 us = lambda a, b: (b - a) / 100.0
 print("matrix wave 0: loop | residual operand | epilogue (split, LDS writes, stores) | wait E2 | ring fetch (poll-loads, LDS writes) | wait E3   ;   loader wave 0: E1->E2 | publish (issue) | wait E3     [us]")
 for wg in range(4):
     print(f"workgroup {wg * 50}")
-    for l in range(8):
+    nlay = int((s[wg, 0, :, 0] > 0).sum())
+    for l in range(nlay):
         m, ld = s[wg, 0, l], s[wg, 1, l]
-        if l < 7:
+        if l < nlay - 1:
             nxt = s[wg, 0, l + 1, 0]
             print(f"  layer {l}: M loop {us(m[0], m[1]):5.2f} res {us(m[1], m[2]):5.2f} epi {us(m[2], m[3]):5.2f} E2 {us(m[3], m[4]):5.2f} fetch {us(m[4], m[5]):5.2f} E3 {us(m[5], m[6]):5.2f}"
                   f" | L E2 {us(ld[0], ld[1]):5.2f} publish {us(ld[1], ld[2]):5.2f} E3 {us(ld[2], ld[6]):5.2f}"
