@@ -392,17 +392,26 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
     // (the head belongs to the down path's resident-tile launch of the full-resolution level where that applies: QMRI_RES_HEAD=0 keeps it apart)
     static const bool res_ends = !(getenv("QMRI_RES_HEAD") && atoi(getenv("QMRI_RES_HEAD")) == 0);
     static const bool res_tail = !(getenv("QMRI_RES_TAIL") && atoi(getenv("QMRI_RES_TAIL")) == 0);
-    bool head_done = false;
+    static const bool res_down = !(getenv("QMRI_RES_DOWN") && atoi(getenv("QMRI_RES_DOWN")) == 0);
+    bool head_done = false, down_done = false;
     if (res_ends && p.d_res_xbuf && !p.force_f32 && p.layers.size() >= (size_t)(2 + 2 * nb)) {
         Conv6rRun r;
         r.head = &p.layers[0]; r.head_in = &p.in32; r.res = &p.layers[1]; r.nres = 2 * nb; r.src = &p.x[0]; r.cur = &p.a[0];
-        QMRI_TRY(conv6r_try(ctx, r, B, &head_done));
-        if (head_done) li = (size_t)(1 + 2 * nb);
+        if (res_down) {                                             // ... and the level's down-sampling convolution behind them
+            r.down = &p.layers[1 + 2 * nb]; r.down_out = &p.x[1];
+            QMRI_TRY(conv6r_try(ctx, r, B, &down_done));
+            if (down_done) { head_done = true; li = (size_t)(2 + 2 * nb); }
+            r.down = nullptr; r.down_out = nullptr;
+        }
+        if (!down_done) {
+            QMRI_TRY(conv6r_try(ctx, r, B, &head_done));
+            if (head_done) li = (size_t)(1 + 2 * nb);
+        }
     }
     if (!head_done) QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.in32, p.x[0], nullptr, nullptr, 0));      // x1 = m_head(x0)
     for (int l = 0; l < 3; ++l) {                                                                          // x_{l+2} = m_down_{l+1}(x_{l+1})
         if (!(l == 0 && head_done)) QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[l], p.a[l], p.t[l], nullptr));
-        QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[l], p.x[l + 1], nullptr, nullptr, 0));
+        if (!(l == 0 && down_done)) QMRI_TRY(run_conv(ctx, p.layers[li++], B, p.a[l], p.x[l + 1], nullptr, nullptr, 0));
     }
     QMRI_TRY(run_resblocks(ctx, li, nb, B, p.x[3], p.a[3], p.t[3], &p.x[3]));                               // m_body(x4) + x4
     for (int l = 3; l > 0; --l) {                                                                          // m_up_l(x + x_{l+1})

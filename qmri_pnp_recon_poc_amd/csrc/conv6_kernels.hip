@@ -1218,7 +1218,8 @@ __global__ __launch_bounds__(NT6) void k_conv6p(const Conv6Args A) {
 // A 3x3 layer launched alone (k_conv6, one slice) is a serial chain: first operands 2 us -> 12 steps at the matrix cores' sustained rate
 // (9.4 us) -> epilogue stores 2.3 - 4 us -> kernel boundary 2 us; and the tile a workgroup writes is, but for a one-pixel ring, the tile
 // the same workgroup reads in the next layer.  Here a workgroup keeps its 18 x 18 x 64 input tile in LDS as f16 pieces (109 KB next to
-// the 36 KB of weight buffers) for all layers of a run of ResBlocks (basicblock.py:211-223), the network's head in front where it applies:
+// the 36 KB of weight buffers) for all layers of a run of ResBlocks (basicblock.py:211-223) -- with the network's head in front and the level's
+// down-sampling convolution behind on the down path, the network's tail behind on the up path, where those apply:
 //   * the loop (k_conv6's: same fragments, same MFMA order) reads activations from the resident tile; the loader waves stream WEIGHTS
 //     only, straight across layer ends (the next layer's first steps are in LDS before the previous layer's epilogue starts);
 //   * the epilogue stays in the matrix waves' registers (descale, + block input, ReLU, range check, f16 split) and writes the pieces IN
@@ -1248,6 +1249,9 @@ constexpr int R_SKIP = 4;                                   // + skip, after it
 constexpr int R_STORE = 8;                                  // the output goes to sdst[l] as fp32 (BLOCKED): a later layer's residual operand
 constexpr int R_STORE_WT = 16;                              // ... written through: the run's result
 constexpr int R_KEEP = 32;                                  // a layer follows: pieces in place into the resident tile, ring exchange
+constexpr int R_DOWN = 128;                                 // the level's strided convolution behind the ResBlocks (2x2 / stride 2, 64 -> 128: k_conv6s DOWN) from the resident tile: no ring needed
+constexpr unsigned R_DOWN_STEPB = 2 * 2 * 2 * 64 * 16;           // ... bytes of one of its weight steps (k_conv6s: 2 planes x 2 row tiles x 2 pieces x 64 lanes x 16 B)
+constexpr int R_LOCAL = 256;                                // with R_KEEP: the next layer needs no ring (R_DOWN follows): pieces in place, no exchange
 constexpr int R_TAIL = 64;                                  // the network's last layer (<= 16 output channels): first 32-row tile of the weights only, PLANAR fp32 output
 constexpr int R_IH = 18, R_IW = 18, R_IHP = 24;             // input tile with ring; LDS row pitch (= 8 mod 16 entries, as in k_conv6)
 constexpr int R_NPX = R_IHP * (R_IW - 1) + R_IH;            // LDS entries per (split, k-half) plane
@@ -1261,6 +1265,7 @@ constexpr size_t conv6r_lds() { return (size_t)(NABUF * R_AST + 4 * R_CHUNK) * 1
 struct Conv6rArgs {
     const float* src; const float* skip;                    // fbase of the run's input (BLOCKED 64 channels, or the PLANAR network input: in_planar) and of the skip tensor (or null)
     const float* radd[R_MAXL]; float* sdst[R_MAXL];         // per layer: the operand R_ADD adds, where R_STORE / R_STORE_WT store (BLOCKED fp32 tensors of the level's geometry)
+    float* dn_out; int dn_hp, dn_plane;                     // R_DOWN: the BLOCKED output tensor of the next level (fbase), its pitch and plane (elements)
     float* out; int out_hp, out_plane, out_c;               // R_TAIL: the PLANAR output tensor (fbase), its pitch and plane (elements), its channels (<= 16)
     int in_planar, in_plane;                                // the run's first layer is the network's head: src = the PLANAR input (16 channels allocated), its plane (elements)
     int nch[R_MAXL], kind[R_MAXL];                          // 16-channel chunks of the layer's input (1: the head; 4), R_* flags
@@ -1327,13 +1332,14 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
         for (int q = 0; q < NAQ; ++q) aoff[q] = (unsigned)((lt + NLD6 * q) * 16);
         // the weight stream: the steps of all layers in a row (3 per 16-channel chunk), requested four steps ahead of the step the matrix waves are in
         int rq_l = 0, rq_s = 0, rq_n = 3 * A.nch[0];
+        unsigned rq_stride = ASTB;                                  // bytes between the steps of the layer being requested (R_DOWN: 8 KB steps; its third entry repeats the first)
         u32x4 srdW = make_srd(A.wp[0]);
 #define R_REQ(ra_)                                                                                               \
         {                                                                                                        \
-            const unsigned so_ = (unsigned)rq_s * ASTB;                                                          \
-            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) bload4(ra_[q], aoff[q], srdW, so_);                  \
+            const unsigned so_ = (unsigned)rq_s * rq_stride;                                                     \
+            _Pragma("unroll") for (int q = 0; q < NAQ; ++q) bload4(ra_[q], (q == 2 && rq_stride != ASTB) ? aoff[0] : aoff[q], srdW, so_); \
             if (++rq_s == rq_n) {                                                                                \
-                if (rq_l + 1 < nl) { ++rq_l; rq_s = 0; rq_n = 3 * A.nch[rq_l]; srdW = make_srd(A.wp[rq_l]); }    \
+                if (rq_l + 1 < nl) { ++rq_l; rq_s = 0; rq_n = 3 * A.nch[rq_l]; srdW = make_srd(A.wp[rq_l]); rq_stride = (A.kind[rq_l] & R_DOWN) ? R_DOWN_STEPB : ASTB; } \
                 else rq_s = rq_n - 1;                /* past the end: the last step again (stored where nobody reads) */ \
             }                                                                                                    \
         }
@@ -1470,6 +1476,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
             }
             if (!(A.kind[l] & R_KEEP)) break;                      // (the last layer)
             lds_barrier6();                                         // E2: the matrix waves have written this layer's output into the tile
+            if (A.kind[l] & R_LOCAL) continue;                      // (the next layer reads no ring)
             R_STAMP(1, 1);
             const unsigned tag = (A.epoch + (unsigned)l + 1u) & 0xFFFFu, thi = tag << 16;
             unsigned char* xb = A.xbuf + (size_t)(l & 1) * A.xbuf_half;
@@ -1563,11 +1570,68 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                 if (T % 3 == 2) lds_barrier6();     /* end of a step (the last one: every wave is done with the tile) */ \
             }                                                                                                    \
         }
+        if (kind & R_DOWN) {
+            // The level's down-sampling convolution (Conv2d k = 2, s = 2, 64 -> 128; basicblock.py downsample_strideconv) on the resident tile: the GEMM
+            // of k_conv6s<DOWN> -- 8 x 8 output pixels, a step = (16-channel chunk, kw) with the two kh as planes, wave = (32-row tile m0, pixel block),
+            // accl += lo x hi, hi x lo; acc += hi x hi per plane -- walked for the two 64-row weight tiles in turn (9 steps each, the ninth all zero:
+            // the packed layout of k_conv6s), same order, same bits.  Output: 128 channels x 64 pixels of the next level, straight from the registers.
+            const int m0 = wave & 1, pbd = 4 * (wave >> 1);
+            const int pxd = (2 * (pbd + (li >> 3)) + 1) * IHP + 2 * (li & 7) + 1;      // LDS entry of input pixel (2 oh, 2 ow) of this lane's output pixel
+            const unsigned dpl = (unsigned)A.dn_plane * 32u;
+            const unsigned dgo = (unsigned)((((ow0 >> 1) + pbd + (li >> 3) + 1) * A.dn_hp + ((oh0 >> 1) + (li & 7)) + 1) * 32 + 16 * h2);
+            const float dh_ = A.dh[l], dl_ = A.dl[l];
+            float gmax = 0.f;
+            bool bad = false;
+            int abi = 0;                                            // A buffer of the step (the steps of all layers rotate through three)
+#pragma unroll 1
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x16 dacc, daccl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dacc[r] = 0.f; daccl[r] = 0.f; }
+#pragma unroll 1
+                for (int g = 0; g < 9; ++g) {
+                    const int c = (g >> 1) < 4 ? (g >> 1) : 3, kw = g & 1;     // (the ninth step's weights are zero: any chunk)
+                    const uint4* ab = Abuf + abi * AST + lane;
+                    const uint4* bb = Bt + c * R_CHUNK + h2 * NPX + pxd + kw * IHP;
+                    u32x4 bf[2][SP], af[2][SP];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int sp = 0; sp < SP; ++sp) {
+                            bf[t][sp] = __builtin_bit_cast(u32x4, bb[sp * 2 * NPX + t]);
+                            af[t][sp] = __builtin_bit_cast(u32x4, ab[((t * 2 + m0) * SP + sp) * 64]);
+                        }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        daccl = mfma_h(af[t][1], bf[t][0], daccl);
+                        daccl = mfma_h(af[t][0], bf[t][1], daccl);
+                        dacc = mfma_h(af[t][0], bf[t][0], dacc);
+                    }
+                    abi = (abi == 2) ? 0 : abi + 1;
+                    lds_barrier6();
+                }
+                unsigned go = dgo + (unsigned)(ct * 8 + m0 * 4) * dpl;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 x;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = __builtin_fmaf(daccl[4 * rg + j], dl_, dacc[4 * rg + j] * dh_);
+                    const float gm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+                    bad |= !(gm <= F16_RANGE);
+                    gmax = fmaxf(gmax, gm);
+                    gstore4r_sc1<0>(go, x, A.dn_out);
+                    go += dpl;
+                }
+            }
+            if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
+            act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, gmax, 4);
+            break;
+        }
         if (kind & R_TAIL) { R_LOOP(1) } else { R_LOOP(2) }          // (uniform; two copies of the code: a predicate inside the taps costs registers the loop does not have)
 #undef R_LOOP
         unsigned gpx_l = gpx;
-        int pxl_l = pxl;
-        asm volatile("" : "+v"(gpx_l), "+v"(pxl_l));           // (behind the loop: what is derived from them is then made here, not kept across the loop)
+        int pxl_l = pxl, h2_l = h2;
+        asm volatile("" : "+v"(gpx_l), "+v"(pxl_l), "+v"(h2_l));           // (behind the loop: what is derived from them is then made here, not kept across the loop)
         if (kind & R_TAIL) {
             // The network's last layer (64 -> out_c <= 16 channels, no ReLU, no operand): channels 0 .. 15 of the first 32-row tile go through LDS
             // (the tile is dead: [channel][w][h] fp32, 16 KB) to the loader waves, which store the out_c planes of the PLANAR output -- their side of
@@ -1671,7 +1735,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
                             uint2 s0, s1;
                             split_pair_h(x[0], x[1], s0.x, s1.x);
                             split_pair_h(x[2], x[3], s0.y, s1.y);
-                            unsigned char* bd = (unsigned char*)Bt + (((2 * m + (rg >> 1)) * R_CHUNK + (rg & 1) * NPX + pxl_l + IHP + 1 + 8 * n) * 16 + 8 * h2);
+                            unsigned char* bd = (unsigned char*)Bt + (((2 * m + (rg >> 1)) * R_CHUNK + (rg & 1) * NPX + pxl_l + IHP + 1 + 8 * n) * 16 + 8 * h2_l);
                             *(uint2*)bd = s0;
                             *(uint2*)(bd + 2 * NPX * 16) = s1;
                         }
@@ -1693,6 +1757,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
         R_STAMP(0, 3);
         if (!(kind & R_KEEP)) break;                                // (the last layer)
         lds_barrier6();                                             // E2
+        if (kind & R_LOCAL) continue;                               // (the next layer reads no ring)
         R_STAMP(0, 4);
         {
                 // this thread's <= 2 triples of the ring, worked out again for every layer (eight registers less across the loop; fetched by the matrix waves, which have nothing else to do between two layers -- and, unlike the loader
@@ -2660,9 +2725,9 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     NetPlan& net = ctx->net;
     static const int resident = getenv("QMRI_CONV_RESIDENT") ? atoi(getenv("QMRI_CONV_RESIDENT")) : 1;
     static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;     // (a captured launch would replay stale tags)
-    const int nres = run.nres, nl = nres + (run.head ? 1 : 0) + (run.tail ? 1 : 0);
+    const int nres = run.nres, nl = nres + (run.head ? 1 : 0) + (run.tail ? 1 : 0) + (run.down ? 1 : 0);
     if (!resident || graph_replay || net.res_off || !net.d_res_xbuf || B != 1 || nres < 2 || nl > R_MAXL || (nres & 1) || net.d_stamps) return QMRI_OK;
-    if (!run.res || !run.src || !run.cur || (run.head && (!run.head_in || run.skip)) || (run.tail && !run.tail_out)) return QMRI_OK;
+    if (!run.res || !run.src || !run.cur || (run.head && (!run.head_in || run.skip)) || (run.tail && !run.tail_out) || (run.down && (!run.down_out || run.tail || run.skip))) return QMRI_OK;
     auto is3 = [](const ConvLayer& L) { return (L.kind == CONV_3X3 || L.kind == CONV_3X3N) && L.sp6 == 2 && L.wp6 && L.n_ct6 == 1; };
     for (int l = 0; l < nres; ++l) {
         const ConvLayer& L = run.res[l];
@@ -2686,6 +2751,12 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
         if (!is3(L) || L.Cin != 64 || L.nchunk6 != 4 || L.Cout > 16 || !out.p || out.blk || out.H != src.H || out.W != src.W ||
             (size_t)out.Cal * out.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;
     }
+    if (run.down) {                                                 // 64 -> 128, 2x2 / stride 2, to the next level's BLOCKED tensor (the packed weights of k_conv6s DOWN: 2 tiles x 9 steps)
+        const ConvLayer& L = *run.down;
+        const PTensor& out = *run.down_out;
+        if (L.kind != CONV_DOWN || L.sp6 != 2 || !L.wp6 || L.Cin != 64 || L.Cout != 128 || L.nchunk6 != 9 || L.n_ct6 != 2 || !out.p || !out.blk || out.Cal < 128 ||
+            out.H * 2 != src.H || out.W * 2 != src.W || (size_t)out.Cal * out.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;
+    }
     if (src.H % 16 || src.W % 16) return QMRI_OK;
     if ((size_t)src.Cal * src.plane() * 4 >= ((size_t)1 << 31)) return QMRI_OK;       // (32-bit byte offsets)
     if (!ctx->conv_ncu) {
@@ -2699,6 +2770,7 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     A.src = run.head ? run.head_in->fbase() : src.fbase();
     A.in_planar = run.head ? 1 : 0; A.in_plane = run.head ? (int)run.head_in->plane() : 0;
     A.skip = run.skip ? run.skip->fbase() : nullptr;
+    if (run.down) { A.dn_out = run.down_out->fbase(); A.dn_hp = run.down_out->hp; A.dn_plane = (int)run.down_out->plane(); }
     if (run.tail) { A.out = run.tail_out->fbase(); A.out_hp = run.tail_out->hp; A.out_plane = (int)run.tail_out->plane(); A.out_c = run.tail->Cout; }
     int l = 0;
     auto put = [&](const ConvLayer& L, int kind, const float* radd, float* sdst) {
@@ -2714,9 +2786,11 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
         if (!(r & 1)) put(run.res[r], R_RELU | R_KEEP, nullptr, nullptr);
         else if (!last) put(run.res[r], R_ADD | R_STORE | R_KEEP, (r == 1) ? src.fbase() : cur.fbase(), cur.fbase());
         else if (run.tail) put(run.res[r], R_ADD | (run.skip ? R_SKIP : 0) | R_KEEP, (r == 1) ? src.fbase() : cur.fbase(), nullptr);   // only the tail reads it
+        else if (run.down) put(run.res[r], R_ADD | R_KEEP | R_LOCAL, (r == 1) ? src.fbase() : cur.fbase(), nullptr);               // only the down conv reads it, and no ring of it
         else put(run.res[r], R_ADD | (run.skip ? R_SKIP : 0) | R_STORE_WT, (r == 1) ? src.fbase() : cur.fbase(), cur.fbase());
     }
     if (run.tail) put(*run.tail, R_TAIL, nullptr, nullptr);
+    if (run.down) { put(*run.down, R_DOWN, nullptr, nullptr); A.nch[l - 1] = 6; }      // (18 steps of 8 KB)
     for (int k = l; k < R_MAXL; ++k) { A.wp[k] = A.wp[l - 1]; A.nch[k] = A.nch[l - 1]; A.am_layer[k] = -1; }
     A.nlayers = nl; A.hp = src.hp; A.plane = (int)src.plane(); A.tiles_h = tiles_h; A.tiles_w = tiles_w;
     A.xbuf = net.d_res_xbuf; A.xbuf_half = (size_t)tiles * R_NTRI * 64;
@@ -2735,7 +2809,7 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // (profile level 2: one pair for the launch, counted as its 64 -> 64 layers; the head and the tail -- not timed when they are launched alone -- take the
     //  share of the duration that their matrix work has: a quarter / half of a layer's)
-    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, nres, (float)nres / ((float)nres + (run.head ? 0.25f : 0.f) + (run.tail ? 0.5f : 0.f))));
+    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, nres, (float)nres / ((float)nres + (run.head ? 0.25f : 0.f) + (run.tail ? 0.5f : 0.f) + (run.down ? 0.25f : 0.f))));
     if (A.stamps) k_conv6r<true><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);
     else if (e0) hipExtLaunchKernelGGL((k_conv6r<false>), dim3(tiles), dim3(NT6), (std::uint32_t)conv6r_lds(), ctx->stream, e0, e1, 0, A);
     else k_conv6r<false><<<dim3(tiles), dim3(NT6), conv6r_lds(), ctx->stream>>>(A);

@@ -366,6 +366,7 @@ struct Conv6rRun {
     const ConvLayer* res = nullptr; int nres = 0;
     const PTensor* src = nullptr; const PTensor* cur = nullptr; const PTensor* skip = nullptr;
     const ConvLayer* tail = nullptr; const PTensor* tail_out = nullptr;   // optional last layer 64 -> out_nc writing the planar network output
+    const ConvLayer* down = nullptr; const PTensor* down_out = nullptr;   // optional last layer: the level's 2x2 / stride-2 convolution 64 -> 128 into the next level's tensor (cur is then not written)
 };
 int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done);   // *done = false: not eligible, nothing launched
 size_t conv6r_xbuf_bytes(int tiles);
