@@ -1625,6 +1625,7 @@ __global__ __launch_bounds__(NT6) void k_conv6r(const Conv6rArgs A) {
             }
             if (bad && A.range_flag) atomicOr(A.range_flag, 1u);
             act_report(ActMax{A.am_slots, A.am_count, A.am_layer[l]}, gmax, 4);
+            R_STAMP(0, 1); R_STAMP(0, 2); R_STAMP(0, 3);
             break;
         }
         if (kind & R_TAIL) { R_LOOP(1) } else { R_LOOP(2) }          // (uniform; two copies of the code: a predicate inside the taps costs registers the loop does not have)
@@ -2805,7 +2806,8 @@ int conv6r_try(qmri_ctx* ctx, const Conv6rRun& run, int B, bool* done) {
         ctx->conv6r_attr = true;
     }
     g_launch_counter.fetch_add(nl, std::memory_order_relaxed);
-    A.stamps = (unsigned long long*)net.d_res_stamps;
+    static const int stamp_which = getenv("QMRI_RES_STAMPS") ? atoi(getenv("QMRI_RES_STAMPS")) : 0;      // 1: the up path's launch, 2: the down path's (the one with the head)
+    A.stamps = (stamp_which == 2) == (run.head != nullptr) ? (unsigned long long*)net.d_res_stamps : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // (profile level 2: one pair for the launch, counted as its 64 -> 64 layers; the head and the tail -- not timed when they are launched alone -- take the
     //  share of the duration that their matrix work has: a quarter / half of a layer's)

@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-os.environ["QMRI_RES_STAMPS"] = "1"
+os.environ["QMRI_RES_STAMPS"] = sys.argv[1] if len(sys.argv) > 1 else "1"          # 1: the up path's launch (ResBlocks + tail), 2: the down path's (head + ResBlocks + down-sampling convolution)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
 
@@ -21,7 +21,7 @@ out = (C.c_ulonglong * 1024)()
 e.L.qmri_debug_conv_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 assert e.L.qmri_debug_conv_stamps(e.h, out, -6) == 0
 s = np.array(out[:640], dtype=np.int64).reshape(4, 2, 10, 8)            # [workgroup][matrix / loader wave 0][layer < R_MAXL][stamp]; the last launch = the up path's: eight ResBlock layers + the tail
-us = lambda a, b: (b - a) / 100.0
+us = lambda a, b: (b - a) / 100.0 if a > 0 and b > 0 else float('nan')      # (a phase a layer does not have leaves no stamp)
 print("matrix wave 0: loop | residual operand | epilogue (split, LDS writes, stores) | wait E2 | ring fetch (poll-loads, LDS writes) | wait E3   ;   loader wave 0: E1->E2 | publish (issue) | wait E3     [us]")
 for wg in range(4):
     print(f"workgroup {wg * 50}")
