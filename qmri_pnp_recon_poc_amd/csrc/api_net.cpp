@@ -390,11 +390,11 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
     }
     // UNetRes.forward, network_unet.py:106-117
     // (the head belongs to the down path's resident-tile launch of the full-resolution level where that applies: QMRI_RES_HEAD=0 keeps it apart)
-    static const bool res_ends = !(getenv("QMRI_RES_HEAD") && atoi(getenv("QMRI_RES_HEAD")) == 0);
+    static const bool res_head = !(getenv("QMRI_RES_HEAD") && atoi(getenv("QMRI_RES_HEAD")) == 0);
     static const bool res_tail = !(getenv("QMRI_RES_TAIL") && atoi(getenv("QMRI_RES_TAIL")) == 0);
     static const bool res_down = !(getenv("QMRI_RES_DOWN") && atoi(getenv("QMRI_RES_DOWN")) == 0);
     bool head_done = false, down_done = false;
-    if (res_ends && p.d_res_xbuf && !p.force_f32 && p.layers.size() >= (size_t)(2 + 2 * nb)) {
+    if (res_head && p.d_res_xbuf && !p.force_f32 && p.layers.size() >= (size_t)(2 + 2 * nb)) {
         Conv6rRun r;
         r.head = &p.layers[0]; r.head_in = &p.in32; r.res = &p.layers[1]; r.nres = 2 * nb; r.src = &p.x[0]; r.cur = &p.a[0];
         if (res_down) {                                             // ... and the level's down-sampling convolution behind them
