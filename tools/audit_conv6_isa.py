@@ -116,6 +116,9 @@ def audit(lines, name):
             n = int(re.search(r'vmcnt\((\d+)\)', t).group(1))
             pending = pending[-n:] if n > 0 else []
             continue
+        if t.startswith('s_branch'):                 # unconditional: what follows in the listing is another path's code, entered with that path's own requests
+            pending = []
+            continue
         if t.startswith('s_') or t.startswith('.LBB'): continue
         used = set(regs(' '.join(t.split()[1:])))
         for ln, rr in pending:
