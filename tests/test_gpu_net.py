@@ -574,3 +574,22 @@ def test_resident_tile_launch_survives_a_second_context_on_the_device(engine_mod
     assert n0 <= 1 and n1 <= 1 and e0.denoiser_scheme() == (2, 0) and e1.denoiser_scheme() == (2, 0)
     capfd.readouterr()
     e0.close(); e1.close()
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (96, 160), (240, 240), (256, 256)])
+def test_resident_tile_launch_other_image_sizes(engine_mod, synth, hw):
+    """k_conv6r on other tilings of the full-resolution level: 4 x 4, 6 x 10 (not square), 15 x 15 and 16 x 16 tiles -- the last one needs every one
+    of the chip's 256 CUs.  Same bits as one launch per layer, no hand-off time-out."""
+    H, W = hw
+    rng = np.random.default_rng(H * 1000 + W)
+    w = synth.random_weights(seed=1, gain=0.7)
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, H, W)
+    x = rng.random((H, W, 10))
+    e.conv_resident(0)
+    ref = e.denoise(x)
+    e.conv_resident(1)
+    for _ in range(3):
+        assert np.array_equal(e.denoise(x), ref)
+    assert e.conv_resident(1) == 0 and e.denoiser_scheme() == (2, 0)
+    e.close()
