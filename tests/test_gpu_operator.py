@@ -322,3 +322,20 @@ def test_admm_two_contexts_on_one_device_concurrently(engine_mod, synth, case224
     capfd.readouterr()
     for e in es:
         e.close()
+
+
+def test_admm_same_bits_with_and_without_the_resident_tile_launch(engine_mod, synth, case224):
+    """The reconstruction as a whole: eight PnP-ADMM iterations with the full-resolution ResBlocks (+ head, tail, down-sampling convolution) in the
+    resident-tile launches and with one launch per layer -- identical x and LSQR counts (the network's output is the same bit for bit, so is
+    everything behind it)."""
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, case224["dic"]["V"], case224["fp"], case224["k"])
+    e.set_denoiser(synth.structured_weights(seed=2, eps=0.02), 224, 224)
+    y = case224["y"]
+    e.conv_resident(0)
+    x0, _, l0 = e.pnp_admm(y, iters=8)
+    e.conv_resident(1)
+    x1, _, l1 = e.pnp_admm(y, iters=8)
+    assert np.array_equal(l0, l1) and np.array_equal(x0, x1)
+    assert e.conv_resident(1) == 0 and e.denoiser_scheme() == (2, 0)
+    e.close()
