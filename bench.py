@@ -16,13 +16,22 @@ one GPU and reconstructs its own slice (slices are independent: weak scaling, no
 timed region starts.  Data and weights are synthetic (seeded; the reference ships neither).
 
 The JSON line also carries
-  roofline     -- the dominant kernel (k_conv6: conv3x3 as implicit GEMM on v_mfma_f32_32x32x16_f16, every fp32 operand
-                  split into two f16 pieces (hi, scaled residual), three MFMA products per fp32-equivalent product; with
-                  QMRI_CONV_SCHEME=bf16x6: three bf16 pieces, six products): MFMA FLOP executed per launch (3 x, resp. 6 x
-                  the algorithmic 2*Cout*Cin*9*H*W) / mean launch duration measured live with HIP events on the launch
-                  stream, against the 2.5 PFLOP/s dense f16/bf16 MFMA peak; `fp32_equivalent_tflops` is the algorithmic rate;
-                  `traffic` = HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/, corrected as
-                  MI355X_MICROARCH.md section HBM prescribes; tools/pmc_traffic.py)
+  roofline     -- the dominant kernel family (the 3x3 convolutions: conv3x3 as implicit GEMM on v_mfma_f32_32x32x16_f16, every fp32
+                  operand split into two f16 pieces (hi, scaled residual), three MFMA products per fp32-equivalent product; with
+                  QMRI_DEBUG="conv_scheme=3": three bf16 pieces, six products).  Pure measurement, no apportioning: every launch
+                  of the family is timed from its own dispatch timestamps as ONE unit -- a layer launched alone (a split-K layer: from
+                  the convolution's start to the end of the reduce kernel that completes it), or a resident-tile launch of a whole run
+                  of layers with whatever else rides in it (head, tail, down-sampling convolution) -- and `achieved` = the MFMA FLOP
+                  those units execute (3 x, resp. 6 x their algorithmic 2*Cout*Cin*taps*H*W) / the sum of their durations, against
+                  the 2.5 PFLOP/s dense f16/bf16 MFMA peak.  `whole_denoiser` is the same ratio for the entire forward pass (3 x
+                  213.25 GFLOP / its duration between two stream events).  `traffic` = HBM-side bytes per launch from the committed
+                  rocprofv3 --pmc passes (profiles/, corrected as MI355X_MICROARCH.md section HBM prescribes; tools/pmc_traffic.py)
+  xupdate      -- the data-consistency stage against the HBM roofline: algorithmic bytes of one LSQR iteration in the k-space
+                  formulation (v, d, x, u(m+1:end) on the sampled k locations and u(1:m) on the samples, each read and written once,
+                  complex fp64 as the reference's arithmetic; + the sample descriptors) / the measured duration of the iteration's
+                  kernels, against 8 TB/s; and us per LSQR iteration
+  epi_batch15, cut0 -- BASELINE.json configs[2] (EPI mask, 11-channel multi-level denoiser, 15 slices advanced together) and the reference-side part
+                  of configs[4] (cut0: T = 1000, one slice): a short timed run each (value, stage split, x-update roofline)
   cpu_baseline -- the CPU oracle (a C/OpenMP restatement of the shipped algorithm, `kind: port`) timed on this
                   box's host cores on a bounded sample of the same workload (rank 0, N = 1 only): all usable threads and
                   one thread, per-stage split, diagnostics on (PnP_ADMM.m:106-109), CPU model string
@@ -51,7 +60,19 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 / f16 ma
 # profiles/r03_h_ubench_mfma_shape_f16.txt; bare MFMAs without LDS reads: 22.1 ns each = 1518, profiles/r01_g_ubench_mfma_f16x3_loop.txt)
 SUSTAINED_MFMA_TFLOPS = 1335.0
 SUSTAINED_MFMA_TFLOPS_BARE = 1518.3   # ... bare MFMAs, no LDS reads (the figure `frac_of_sustained` used up to round 2; both are reported so rounds stay comparable)
-BF16X6 = os.environ.get("QMRI_CONV_SCHEME", "") == "bf16x6"
+
+
+def debug_knob(name: str, default: int) -> int:
+    """The library's A/B switches as it reads them itself: QMRI_DEBUG="name=value,name=value" (csrc/api_core.cpp)."""
+    for kv in os.environ.get("QMRI_DEBUG", "").split(","):
+        k, _, v = kv.partition("=")
+        if k.strip() == name and v.strip().lstrip("-").isdigit():
+            return int(v)
+    return default
+
+
+BF16X6 = debug_knob("conv_scheme", 2) == 3
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s is what a float4 copy achieves)
 SPLIT_PRODUCTS = 6 if BF16X6 else 3   # MFMA products per fp32-equivalent product (conv6_kernels.hip: bf16 x 6 / f16 x 3)
 SCHEME_TEXT = ("v_mfma_f32_32x32x16_bf16, operands split 3-way into bf16, 6 products, f32 accumulate" if BF16X6 else
                "v_mfma_f32_32x32x16_f16, operands split into f16 (hi, scaled residual), 3 products, f32 accumulate")
@@ -80,6 +101,9 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-slices", action="store_true", help="workload=admm: skip the `slices` object (north_star's second metric: a fixed 120-slice batch, "
                     "100 ADMM iterations + dictionary match at K = 98 304 per slice, sharded over the ranks; ~10 s on one GPU)")
+    ap.add_argument("--no-secondary", action="store_true", help="workload=admm: skip the `epi_batch15` and `cut0` objects (BASELINE configs[2] and the reference-side "
+                    "part of configs[4]: a few seconds each)")
+    ap.add_argument("--secondary-steps", type=int, default=20, help="... ADMM iterations timed for each of them")
     ap.add_argument("--slices-total", type=int, default=120, help="... its slice count")
     ap.add_argument("--slices-iters", type=int, default=100, help="... ADMM iterations per slice (PnP_ADMM.m: param.iter = 100)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo + --one-device: rehearsal of the "
@@ -199,6 +223,126 @@ def atom_tolerance(K: int) -> float:
     return max(0.85, 1.0 - 0.01 * K / 8192.0)
 
 
+def conv_roofline(pr, B, kernel_text, traffic=None, traffic_source=None):
+    """`roofline` of the 3x3 convolution family from a level-2 profile (qmri_profile): executed MFMA flop of the timed units / their summed durations."""
+    if pr["n_conv3x3"] <= 0 or pr["ms_conv3x3"] <= 0:
+        return None
+    t3 = pr["ms_conv3x3"] * 1e-3
+    ach = SPLIT_PRODUCTS * pr["flop_conv3x3"] / t3 / 1e12
+    leq = pr["flop_conv3x3"] / (CONV3X3_FLOP * B)                   # 64 -> 64 layers (of B slices) the timed units amount to
+    nf = max(pr["n_net_forward"], 1)
+    roof = {"kernel": kernel_text, "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "timing": "every launch of the family is ONE unit, timed from its own dispatch timestamps (hipExtLaunchKernelGGL events): a split-K layer from the "
+                      "convolution's start to its reduce kernel's end, a resident-tile launch whole; achieved = executed flop of the units / sum of their durations",
+            "units_timed": int(pr["n_conv3x3"]), "units_per_forward": round(pr["n_conv3x3"] / nf, 2), "ms_timed_per_forward": round(pr["ms_conv3x3"] / nf, 4),
+            "executed_flop_per_forward": SPLIT_PRODUCTS * pr["flop_conv3x3"] / nf, "fp32_equivalent_flop_per_forward": pr["flop_conv3x3"] / nf,
+            "layer_equivalents_per_forward": round(leq / nf, 3), "us_per_layer_equivalent": round(t3 / leq * 1e6, 3),
+            "avg_launch_us": round(t3 / pr["n_conv3x3"] * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
+            "flop_per_launch": SPLIT_PRODUCTS * pr["flop_conv3x3"] / pr["n_conv3x3"],
+            "fp32_equivalent_tflops": round(pr["flop_conv3x3"] / t3 / 1e12, 3),
+            # what the chip sustains on toggling operands at its power limit (see SUSTAINED_MFMA_TFLOPS) -- not the roofline peak, reported beside it
+            "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4),
+            "sustained_mfma_tflops_bare_mfma_loop": SUSTAINED_MFMA_TFLOPS_BARE, "frac_of_sustained_bare_mfma_loop": round(ach / SUSTAINED_MFMA_TFLOPS_BARE, 4)}
+    if pr["n_conv2x2"] > 0 and pr["ms_conv2x2"] > 0:
+        tall, fall = t3 + pr["ms_conv2x2"] * 1e-3, pr["flop_conv3x3"] + pr["flop_conv2x2"]
+        roof["all_conv_launches"] = {"what": "the same ratio over every convolution launch of the forward pass (3x3 family + the 2x2 / stride-2 layers launched alone)",
+                                     "ms_per_forward": round(tall * 1e3 / nf, 4), "achieved": round(SPLIT_PRODUCTS * fall / tall / 1e12, 3),
+                                     "frac": round(SPLIT_PRODUCTS * fall / tall / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+    if pr["n_net_forward"] > 0 and pr["ms_net_forward"] > 0:
+        tf = pr["ms_net_forward"] / pr["n_net_forward"] * 1e-3
+        ex = SPLIT_PRODUCTS * DENOISER_FLOP * B
+        roof["whole_denoiser"] = {"what": "the whole forward pass between two stream events (all 64 layers, the |output| report, every launch gap): 3 x 213.25 GFLOP "
+                                          "per slice / its duration", "ms_per_forward": round(tf * 1e3, 4), "executed_flop": ex,
+                                  "achieved": round(ex / tf / 1e12, 3), "frac": round(ex / tf / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+    return roof
+
+
+def xupdate_bytes_per_lsqr_iteration(ns: int, s: int, m: int) -> int:
+    """ALGORITHMIC bytes of one LSQR iteration of the k-space formulation, per slice: the four vectors on the sampled k
+    locations (v, d, x, u(m+1:end): ns * s complex doubles each) and u(1:m) (m complex doubles) are read and written once, the sample
+    descriptors (4 bytes each) are read once."""
+    return 16 * (2 * 4 * ns * s + 2 * m) + 4 * m
+
+
+def xupdate_roofline(pr, ns, s, m, B, one_launch):
+    """`xupdate` object from a level-1 + level-2 profile of an ADMM run: stage time, LSQR iterations, and the iteration kernels alone against HBM."""
+    it = max(pr["admm_iters"], 1)
+    li = max(pr["lsqr_iters"], 1)                                   # summed over slices
+    byt = xupdate_bytes_per_lsqr_iteration(ns, s, m)
+    out = {"lsqr_iters_per_xupdate": round(pr["lsqr_iters"] / it / B, 2), "bytes_per_lsqr_iteration_per_slice": byt,
+           "form": "k_ks_persist: all iterations of a solve in one launch, the iteration's state on chip" if one_launch else
+                   "two launches per LSQR iteration (k_ks_a, k_ks_b), the state streams through HBM / Infinity Cache"}
+    if pr["n_lsqr_launches"] > 0 and pr["ms_lsqr_kernels"] > 0:
+        # per LSQR iteration of the whole batch: the iteration kernels' own dispatch timestamps; iterations = the slowest slice's count summed over
+        # the x-updates ~ lsqr_iters / B (slices of a batch iterate together)
+        us = pr["ms_lsqr_kernels"] * 1e3 / (li / B)
+        gbs = byt * B / (us * 1e-6) / 1e9
+        out.update({"us_per_lsqr_iteration": round(us, 2), "us_per_lsqr_iteration_per_slice": round(us / B, 2),
+                    "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "bytes_per_launch_pair": byt * B, "traffic": None,
+                                 "note": "algorithmic bytes of an iteration (all slices of the batch) / duration of the iteration's kernels from their own dispatch "
+                                         "timestamps" + ("; the one-launch form keeps the state on chip, so this is an effective rate, not HBM traffic" if one_launch else "")}})
+    return out
+
+
+def secondary_config(args, torch, dev, local_rank, name, T, mask, B, multi, steps):
+    """One more BASELINE configuration on the default line: a short timed PnP-ADMM run (value = slice-iterations / s on this GPU), the stage split
+    (profile level 1) and the x-update roofline (level 2), rank 0 only."""
+    import ctypes as C
+    from qmri_pnp_recon_poc_amd import engine as E, synth
+    from qmri_pnp_recon_poc_amd._lib import AdmmParams
+    N, s = 224, 10
+    dic = synth.make_dictionary(T=T, n_t1=32, n_t2=16, s=s)
+    fp, k = E.build_spiral(N, 771, T) if mask == "spiral" else E.build_epi(N, N, 1 / 65, T)
+    w = synth.structured_weights(in_nc=s + (1 if multi else 0), seed=2, eps=0.02)
+    eng = E.Engine(local_rank)
+    eng.set_operator(N, N, dic["V"], fp, k, max_batch=B)
+    eng.set_denoiser(w, N, N, in_nc=s + (1 if multi else 0), max_batch=B)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    ys = np.stack([synth.awgn_measured(eng.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=i), dic)), 30.0, seed=i) for i in range(B)])
+    d_y = torch.from_numpy(np.ascontiguousarray(ys).view(np.float64)).to(dev)
+    d_x = torch.empty((B, 2 * N * N * s), dtype=torch.float64, device=dev)
+    li = np.zeros(B * max(steps, 3), np.int32)
+    torch.cuda.synchronize()
+
+    def run(iters):
+        p = AdmmParams(0.05, iters, 1e-4, 100, 0, 1 if multi else 0, 0.01, 0)
+        eng._check(eng.L.qmri_pnp_admm_dev(eng.h, B, C.c_void_p(d_y.data_ptr()), C.byref(p), None, None, C.c_void_p(d_x.data_ptr()), None,
+                                           li.ctypes.data_as(C.POINTER(C.c_int32))))
+        eng.synchronize()
+
+    run(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.profile_get(reset=True)
+    eng.profile_enable(1)
+    run(steps)
+    p1 = eng.profile_get(reset=True)
+    eng.profile_enable(2)
+    run(steps)
+    p2 = eng.profile_get(reset=True)
+    eng.profile_enable(0)
+    it = max(p1["admm_iters"], 1)
+    ns = int(np.unique(k).size)
+    m = int(fp[-1])
+    one_launch = p2["n_lsqr_launches"] > 0 and p2["n_lsqr_launches"] <= p2["admm_iters"]      # (one k_ks_persist launch per x-update)
+    out = {"workload": name, "value": round(steps * B / dt, 3), "unit": "slice-iterations/s (ADMM iterations x slices advanced together)",
+           "ms_per_admm_iteration": round(dt / steps * 1e3, 4), "ms_per_slice_iteration": round(dt / steps / B * 1e3, 4), "steps": steps, "slices_per_launch": B,
+           "T": T, "m": m, "sampled_k_locations": ns, "mask": mask, "denoiser": "11-channel multi-level UNetRes (noise-map channel)" if multi else "10-channel UNetRes",
+           "stage_ms_per_iter": {"xupdate": round(p1["ms_xupdate"] / it, 4), "denoiser": round(p1["ms_denoiser"] / it, 4),
+                                 "elementwise": round(p1["ms_elementwise"] / it, 4)},
+           "xupdate_share_of_iteration": round(p1["ms_xupdate"] / max(p1["ms_xupdate"] + p1["ms_denoiser"] + p1["ms_elementwise"], 1e-9), 3),
+           "xupdate": xupdate_roofline({**p2, "admm_iters": p2["admm_iters"], "lsqr_iters": p2["lsqr_iters"]}, ns, s, m, B, one_launch),
+           "reference_switches": "main_recon_tsmis_FFT.m:41-49 (cut, subsampling_pattern), :75-83 (denoiser_type)"}
+    out["xupdate"]["us_per_lsqr_iteration_incl_fixed_launches"] = round(p1["ms_xupdate"] / it / max(p1["lsqr_iters"] / it / B, 1e-9) * 1e3, 2)
+    eng.close()
+    return out
+
+
 def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, iters, warmup_iters, dict_grid=(384, 256)):
     """north_star metric 2: a FIXED batch of `total` slices (120 = 8 subjects x 15, BASELINE configs[3]) sharded over the ranks in contiguous
     blocks; each rank walks its block in launches of `batch` slices (k_conv6p, batched LSQR), every slice = `iters` PnP-ADMM iterations + the
@@ -247,10 +391,15 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
         eng._check(eng.L.qmri_dict_match_dev(eng.h, C.c_void_p(d_x[j].data_ptr() + i * n * 16), N * N, C.c_void_p(d_q[j].data_ptr() + i * N * N * 8),
                                              C.c_void_p(d_pd[j].data_ptr() + i * N * N * 8), None, None))
 
+    copied = [None, None]                                      # event on the copy stream behind the copies out of buffer set j
+
     def run(count, it):
         p = params(it)
         for bi, s0 in enumerate(range(0, count, B)):
             j, cnt = bi & 1, min(B, count - s0)
+            if copied[j] is not None:                              # set j is written again: its copies (two launches ago) must be over, as in recon_worker (api_net.cpp)
+                stream.wait_event(copied[j])
+                copied[j].synchronize()                            # (... and the pinned results consumed: here they are simply dropped)
             eng._check(eng.L.qmri_pnp_admm_dev(eng.h, cnt, C.c_void_p(d_y.data_ptr() + s0 * m * 16), C.byref(p), None, None,
                                                C.c_void_p(d_x[j].data_ptr()), None, None))
             for i in range(cnt):
@@ -262,6 +411,8 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
                 h_x[j][:cnt].copy_(d_x[j][:cnt], non_blocking=True)
                 h_q[j][:cnt].copy_(d_q[j][:cnt], non_blocking=True)
                 h_pd[j][:cnt].copy_(d_pd[j][:cnt], non_blocking=True)
+                copied[j] = torch.cuda.Event()
+                copied[j].record(cstream)
 
     def barrier():
         if world > 1:
@@ -301,15 +452,9 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
             eng.synchronize()
             pr = eng.profile_get(reset=True)
             eng.profile_enable(0)
-            if pr["n_conv3x3"] > 0:
-                avg_s = pr["ms_conv3x3"] / pr["n_conv3x3"] * 1e-3
-                ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
-                traffic, tsrc = load_traffic(B)
-                out["roofline"] = {"kernel": f"k_conv6p (persistent implicit-GEMM conv3x3, {B} slices per launch, on {SCHEME_TEXT})", "bound": "mfma",
-                                   "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                                   "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
-                                   "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B, "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3),
-                                   "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4)}
+            traffic, tsrc = load_traffic(B)
+            out["roofline"] = conv_roofline(pr, B, f"3x3 convolution launches of a {B}-slice forward pass: k_conv6p (persistent implicit GEMM, every 64 -> 64 ... 512 -> 512 "
+                                                   f"layer) + the head and tail on k_conv6, on {SCHEME_TEXT}", traffic, tsrc)
             # the dictionary match of one reconstructed slice (d_x[0][0]: the first slice of an earlier launch), HIP events on the engine's stream
             with torch.cuda.stream(stream):
                 for _ in range(3):
@@ -534,31 +679,21 @@ def worker(args):
         pr = eng.profile_get(reset=True)
         eng.profile_enable(0)
         if pr["n_conv3x3"] > 0:
-            avg_s = pr["ms_conv3x3"] / pr["n_conv3x3"] * 1e-3
-            f32_path = bool(int(os.environ.get("QMRI_CONV_F32", "0")))
+            f32_path = debug_knob("conv_f32", 0) > 0
             if f32_path:
-                ach = CONV3X3_FLOP * B / avg_s / 1e12
+                t3 = pr["ms_conv3x3"] * 1e-3
+                ach = pr["flop_conv3x3"] / t3 / 1e12
                 roof = {"kernel": "k_conv<3x3> (implicit-GEMM conv3x3 on v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
-                        "flop_per_launch": CONV3X3_FLOP * B}
+                        "traffic": None, "avg_launch_us": round(t3 / pr["n_conv3x3"] * 1e6, 2), "launches_timed": int(pr["n_conv3x3"]),
+                        "flop_per_launch": pr["flop_conv3x3"] / pr["n_conv3x3"]}
             else:
-                ach = SPLIT_PRODUCTS * CONV3X3_FLOP * B / avg_s / 1e12
                 traffic, tsrc = load_traffic(B)
-                resident = os.environ.get("QMRI_CONV_RESIDENT", "1") != "0"
-                roof = {"kernel": (f"k_conv6 + k_conv6r (implicit-GEMM conv3x3 on {SCHEME_TEXT}; per LAYER: the 16 full-resolution ResBlock layers of a forward "
-                                   "pass run as two resident-tile launches of eight layers, each timed as one dispatch and counted as eight)") if resident
-                        else f"k_conv6 (implicit-GEMM conv3x3 on {SCHEME_TEXT})",
-                        "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
-                        "avg_launch_us": round(avg_s * 1e6, 2),
-                        "launches_timed": int(pr["n_conv3x3"]), "flop_per_launch": SPLIT_PRODUCTS * CONV3X3_FLOP * B,
-                        "fp32_equivalent_tflops": round(CONV3X3_FLOP * B / avg_s / 1e12, 3), "fp32_equivalent_flop_per_launch": CONV3X3_FLOP * B,
-                        # what the chip sustains on toggling operands at its power limit (see SUSTAINED_MFMA_TFLOPS) -- not the roofline peak,
-                        # reported beside it
-                        "sustained_mfma_tflops_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_MFMA_TFLOPS, 4),
-                        "sustained_mfma_tflops_bare_mfma_loop": SUSTAINED_MFMA_TFLOPS_BARE,
-                        "frac_of_sustained_bare_mfma_loop": round(ach / SUSTAINED_MFMA_TFLOPS_BARE, 4)}
+                resident = debug_knob("conv_resident", 1) != 0 and B == 1
+                roof = conv_roofline(pr, B, (f"3x3 convolution launches of a forward pass on {SCHEME_TEXT}: k_conv6 (one launch per layer; the 28 x 28 level's split-K "
+                                             "layers with their reduce kernel) + k_conv6r (the 16 full-resolution ResBlock layers with the head, the tail and the level's "
+                                             "down-sampling convolution as TWO resident-tile launches)") if resident else
+                                     f"3x3 convolution launches of a forward pass (k_conv6 / k_conv6p, split-K layers with their reduce kernel) on {SCHEME_TEXT}", traffic, tsrc)
         # stage split of one more run of the SAME workload (profile level 1 synchronises per stage; not part of the timed region): all
         # args.steps iterations, because the x-update is not uniform over a reconstruction -- LSQR needs 16 iterations in the first
         # x-updates and 5-8 in the later ones (lsqr_iters_mean)
@@ -570,6 +705,18 @@ def worker(args):
             it = max(pr["admm_iters"], 1)
             result_extra["stage_ms_per_iter"] = {"xupdate": round(pr["ms_xupdate"] / it, 4), "denoiser": round(pr["ms_denoiser"] / it, 4),
                                                  "elementwise": round(pr["ms_elementwise"] / it, 4), "over_admm_iters": int(it)}
+            if roof is not None and pr["ms_denoiser"] > 0:        # the denoiser stage of the ADMM loop itself (stage timer), beside the level-2 figure
+                ex = SPLIT_PRODUCTS * DENOISER_FLOP
+                roof["whole_denoiser_in_admm_loop"] = {"ms": round(pr["ms_denoiser"] / it, 4), "achieved": round(ex / (pr["ms_denoiser"] / it * 1e-3) / 1e12, 3),
+                                                       "frac": round(ex / (pr["ms_denoiser"] / it * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+            # the x-update against the HBM roofline: one more run of the same steps at profile level 2 (the LSQR kernels' own dispatch timestamps)
+            eng.profile_enable(2)
+            run(max(args.steps, 1))
+            p2 = eng.profile_get(reset=True)
+            eng.profile_enable(0)
+            ns_k = int(np.unique(k).size)
+            result_extra["xupdate"] = xupdate_roofline(p2, ns_k, s, int(fp[-1]), 1, p2["n_lsqr_launches"] <= p2["admm_iters"])
+            result_extra["xupdate"]["us_per_lsqr_iteration_incl_fixed_launches"] = round(pr["ms_xupdate"] / it / max(pr["lsqr_iters"] / it, 1e-9) * 1e3, 2)
 
     # ---- CPU baseline + parity: the oracle on this box's host cores, bounded sample -----------------------
     cpu = None
@@ -624,6 +771,37 @@ def worker(args):
         yg, yo_ = e2.denoise(xin), O.Net(wsens).denoise(xin)
         parity["net_rel_l2_random_weights"] = float(np.linalg.norm((yg - yo_).ravel()) / np.linalg.norm(yo_.ravel()))
         parity["net_random_weights_scheme"] = list(e2.denoiser_scheme())
+        # ... and TIMED with them: the bench network's interior layers sit at 1.5e-4 of its output, i.e. their f16 pieces barely
+        # toggle; a trained DRUNet's activations do.  Same call path and the same input for both weight sets: 10 forward passes at profile level 2
+        # (ms_net_forward: the whole pass between two stream events).
+        if args.workload == "admm":
+            d_rin = torch.from_numpy(np.ascontiguousarray(synth.golden224_input(10).transpose(0, 2, 1))).to(dev)      # [c][w][h] fp32, the device layout
+            d_rout = torch.empty(s * N * N, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+
+            def forward_ms(e):
+                for _ in range(3):
+                    e._check(e.L.qmri_net_forward_dev(e.h, C.c_void_p(d_rin.data_ptr()), 1, C.c_void_p(d_rout.data_ptr())))
+                e.profile_get(reset=True)
+                e.profile_enable(2)
+                for _ in range(10):
+                    e._check(e.L.qmri_net_forward_dev(e.h, C.c_void_p(d_rin.data_ptr()), 1, C.c_void_p(d_rout.data_ptr())))
+                q = e.profile_get(reset=True)
+                e.profile_enable(0)
+                return q["ms_net_forward"] / max(q["n_net_forward"], 1), conv_roofline(q, 1, "")
+
+            ms_s, roof_s = forward_ms(eng)
+            ms_r, roof_r = forward_ms(e2)
+            ms_step = dt / max(args.steps, 1) * 1e3
+            result_extra["denoiser_weights_timing"] = {
+                "what": "one 224 x 224 forward pass, same input, same call path (qmri_net_forward_dev, profile level 2), with the bench network "
+                        "(structured_weights(eps=0.02): ADMM-stable, interior layers at 1.5e-4 of the output) and with random_weights(seed=1, gain=0.7), under "
+                        "which every layer's activations are of order one -- what a trained DRUNet resembles",
+                "denoiser_ms_structured_weights": round(ms_s, 4), "denoiser_ms_random_weights": round(ms_r, 4),
+                "conv3x3_frac_structured_weights": roof_s["frac"] if roof_s else None, "conv3x3_frac_random_weights": roof_r["frac"] if roof_r else None,
+                "random_over_structured": round(ms_r / max(ms_s, 1e-9), 4),
+                "implied_admm_iters_per_s_with_random_weights": round(1e3 / max(ms_step - ms_s + ms_r, 1e-9) * world, 2),
+                "scheme_random_weights": list(e2.denoiser_scheme())}
         e2.close()
         if args.workload == "admm" and n_cpu <= len(li):
             parity["lsqr_iteration_counts_identical"] = bool(np.array_equal(li[:n_cpu], lio[:n_cpu]))
@@ -632,6 +810,13 @@ def worker(args):
     slices_obj = None
     if args.workload == "admm" and not args.no_slices and args.slices_total > 0:
         slices_obj = slices_phase(args, rank, local_rank, world, dev, torch, dist, args.slices_total, args.batch, args.slices_iters, 2)
+    # ---- the other single-GPU configurations of BASELINE.json on the same line (rank 0; the other ranks wait at the final barrier) ----------------
+    secondary = {}
+    if args.workload == "admm" and not args.no_secondary and rank == 0:
+        secondary["epi_batch15"] = secondary_config(args, torch, dev, local_rank, "BASELINE configs[2]: cut3, EPI mask (m = 134 400), 15 slices advanced together, "
+                                                    "PnP-ADMM + 11-channel multi-level UNetRes", 200, "epi", 15, True, args.secondary_steps)
+        secondary["cut0"] = secondary_config(args, torch, dev, local_rank, "BASELINE configs[4] as far as the reference goes: cut0 (T = 1000, m = 618 000), spiral mask, one "
+                                             "slice, PnP-ADMM + 10-channel UNetRes", 1000, "spiral", 1, False, args.secondary_steps)
     if rank == 0:
         strong = args.workload == "slices" and args.total_slices > 0
         if args.workload == "admm":
@@ -655,6 +840,7 @@ def worker(args):
         out.update(result_extra)
         if slices_obj is not None:
             out["slices"] = slices_obj
+        out.update(secondary)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -230,23 +230,33 @@ int qmri_recon_batch(int ndev, const int* devs, int nslices, const qmri_problem*
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------ */
 typedef struct {
     double ms_xupdate, ms_denoiser, ms_elementwise, ms_diag, ms_match;   /* hipEvent time per stage */
-    double ms_conv3x3;          /* summed duration of the dominant kernel's launches */
-    int64_t n_conv3x3;          /* number of those launches */
+    double ms_conv3x3;          /* level 2: summed duration of the 3x3 convolution launches, each taken from its own dispatch timestamps: one
+                                 * launch per layer (a split-K layer: from the convolution's start to its reduce kernel's end), or one
+                                 * resident-tile launch of a whole run of layers (with whatever else rides in it) as ONE unit */
+    int64_t n_conv3x3;          /* number of those units */
     int64_t lsqr_iters;         /* LSQR iterations executed */
     int64_t admm_iters;
     double ms_tv_iter;          /* LRTV: summed duration of the prox_tv iteration kernel's launches (level 2) */
     int64_t n_tv_iter;
+    double flop_conv3x3;        /* fp32-equivalent algorithmic work of the units in ms_conv3x3: 2 Cout Cin taps Hout Wout B per layer inside them */
+    double ms_conv2x2;          /* level 2: the 2x2 / stride-2 (transposed) convolutions launched on their own */
+    int64_t n_conv2x2;
+    double flop_conv2x2;
+    double ms_lsqr_kernels;     /* level 2: the LSQR iteration kernels alone (k_ks_a start -> k_ks_b end per iteration, or a whole k_ks_persist launch) */
+    int64_t n_lsqr_launches;
+    double ms_net_forward;      /* level 2: whole forward passes of the network, first launch to last (stream events) */
+    int64_t n_net_forward;
 } qmri_profile;
 int qmri_profile_enable(qmri_ctx* ctx, int level);   /* 0 off, 1 per stage, 2 also per conv3x3 launch */
 int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset);
 
 /* Diagnostics (no counterpart in the reference): in-kernel 100 MHz phase stamps, recorded only when the library was
- * started with QMRI_LSQR_STAMPS=1 / QMRI_CONV_STAMPS=1 (otherwise QMRI_ERR_STATE).  `out` receives 2*512*16 and 4096*11
+ * started with the knobs lsqr_stamps / conv_stamps set (qmri_debug_knob, QMRI_DEBUG; otherwise QMRI_ERR_STATE).  `out` receives 2*512*16 and 4096*11
  * 64-bit values; layouts are those read by tools/lsqr_stamps.py and tools/conv6_stamps.py. */
 int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out);
 int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int reserved);
 /* Test / A-B hook: the LSQR x-update (PnP_ADMM.m:102) runs all its iterations in ONE launch where the operator's work units are resident at
- * once (default; same bits as the two-launch iteration); on = 0 selects the two-launch iteration (also QMRI_LSQR_PERSIST=0); on = 2 makes
+ * once (default; same bits as the two-launch iteration); on = 0 selects the two-launch iteration (also the knob lsqr_persist = 0); on = 2 makes
  * the one-launch kernel lose a partial sum on purpose: its waits time out, the library reports it on stderr and repeats the solve with the
  * two-launch iteration (the recovery path, tested). */
 int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on);
@@ -256,10 +266,16 @@ int qmri_debug_lsqr_persist(qmri_ctx* ctx, int on);
  * margin is from the first wrong answer. */
 int qmri_debug_dict_filter(qmri_ctx* ctx, int on, float margin_scale);
 /* Test / A-B hook for the denoiser's convolutions: on = 1 (default) runs the ResBlocks of the full-resolution level of a one-slice forward pass as
- * ONE launch with LDS-resident tiles (same bits as one launch per layer); on = 0 selects one launch per layer (also QMRI_CONV_RESIDENT=0); on = 2
+ * ONE launch with LDS-resident tiles (same bits as one launch per layer); on = 0 selects one launch per layer (also the knob conv_resident = 0); on = 2
  * makes one tile withhold its hand-off on purpose: its neighbours' waits time out, the library reports it on stderr, repeats the call with one
  * launch per layer and keeps the resident form off (the recovery path, tested).  timeouts_out (or NULL): hand-off time-outs seen so far. */
 int qmri_debug_conv_resident(qmri_ctx* ctx, int on, int* timeouts_out);
+/* The one entry point of the process-wide A/B and diagnostic switches ("knobs": tile configurations, the fused launches, in-kernel stamps of the
+ * diagnostic builds ...; names and defaults: csrc/api_core.cpp g_knob_defs).  The same switches can be set at start-up through the library's
+ * only environment variable, QMRI_DEBUG="name=value,name=value".  Every default is the product's behaviour; an unknown name is
+ * QMRI_ERR_INVALID_ARG (message: qmri_last_error(NULL)).  Knobs are read when a plan is made or a launch is issued: set them before
+ * qmri_set_operator / qmri_set_denoiser. */
+int qmri_debug_knob(const char* name, int value);
 
 #ifdef __cplusplus
 }

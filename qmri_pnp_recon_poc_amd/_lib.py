@@ -21,7 +21,8 @@ SYMBOLS = [
     "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
-    "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_debug_conv_resident", "qmri_onnx_read_unetres",
+    "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_debug_conv_resident", "qmri_debug_knob",
+    "qmri_onnx_read_unetres",
     "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi", "qmri_synthesize_tsmi_complex",
 ]
 
@@ -58,7 +59,9 @@ class Profile(C.Structure):
     _fields_ = [("ms_xupdate", C.c_double), ("ms_denoiser", C.c_double), ("ms_elementwise", C.c_double),
                 ("ms_diag", C.c_double), ("ms_match", C.c_double), ("ms_conv3x3", C.c_double),
                 ("n_conv3x3", C.c_int64), ("lsqr_iters", C.c_int64), ("admm_iters", C.c_int64),
-                ("ms_tv_iter", C.c_double), ("n_tv_iter", C.c_int64)]
+                ("ms_tv_iter", C.c_double), ("n_tv_iter", C.c_int64),
+                ("flop_conv3x3", C.c_double), ("ms_conv2x2", C.c_double), ("n_conv2x2", C.c_int64), ("flop_conv2x2", C.c_double),
+                ("ms_lsqr_kernels", C.c_double), ("n_lsqr_launches", C.c_int64), ("ms_net_forward", C.c_double), ("n_net_forward", C.c_int64)]
 
 
 def build(force: bool = False) -> str:
@@ -128,6 +131,7 @@ def lib() -> C.CDLL:
     L.qmri_dict_match_xfit.argtypes = [vp, vp, i, fp, fp, fp, ip, fp]
     L.qmri_dict_match_xfit_dev.argtypes = [vp, vp, i, vp, vp, vp, vp, vp]
     L.qmri_recon_batch.argtypes = [i, C.POINTER(i), i, C.POINTER(Problem), vp, vp, fp, fp, C.c_char_p, C.c_size_t]
+    L.qmri_debug_knob.argtypes = [C.c_char_p, i]
     L.qmri_profile_enable.argtypes = [vp, i]
     L.qmri_profile_get.argtypes = [vp, C.POINTER(Profile), i]
     if L.qmri_abi_version() != 1:

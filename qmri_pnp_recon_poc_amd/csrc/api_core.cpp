@@ -5,11 +5,63 @@
 #include "qmri_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 static thread_local std::string g_create_err;
+
+// ---------------------------------------------------------------------------------------------------
+// knobs (qmri_internal.h QmriKnob): A/B and diagnostic switches behind ONE environment variable and one entry point
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct KnobDef { const char* name; int dflt; };
+const KnobDef g_knob_defs[K_COUNT] = {
+    {"conv_scheme", 2}, {"conv_f32", 0}, {"conv_wt", 1}, {"conv_xcd", 1}, {"conv_persist", 1}, {"conv_splitk", 1},
+    {"conv_midcfg", 3}, {"conv_deepcfg", 3}, {"conv_deepks", 4},
+    {"conv_resident", 1}, {"res_head", 1}, {"res_tail", 1}, {"res_down", 1}, {"res_delay", 24}, {"res_rearm", 64},
+    {"res_stamps", 0}, {"conv_stamps", 0}, {"conv_stamp_launch", -1}, {"lsqr_stamps", 0},
+    {"conv_mt2", 1024}, {"conv_occ", 2},
+    {"fuse_ew", 1}, {"lsqr_persist", 1}, {"dictw_lsp", 2}, {"verbose", 0},
+};
+std::atomic<int> g_knob_val[K_COUNT];
+std::once_flag g_knob_once;
+
+int knob_index(const char* name, size_t len) {
+    for (int k = 0; k < K_COUNT; ++k)
+        if (strlen(g_knob_defs[k].name) == len && strncmp(g_knob_defs[k].name, name, len) == 0) return k;
+    return -1;
+}
+void knob_init() {
+    for (int k = 0; k < K_COUNT; ++k) g_knob_val[k].store(g_knob_defs[k].dflt, std::memory_order_relaxed);
+    const char* e = getenv("QMRI_DEBUG");                          // the library's only environment variable
+    while (e && *e) {
+        const char* end = strchr(e, ',');
+        const size_t len = end ? (size_t)(end - e) : strlen(e);
+        const char* eq = (const char*)memchr(e, '=', len);
+        const int k = eq ? knob_index(e, (size_t)(eq - e)) : -1;
+        if (k >= 0) g_knob_val[k].store(atoi(eq + 1), std::memory_order_relaxed);
+        else if (len) fprintf(stderr, "libqmri: QMRI_DEBUG: unknown or malformed entry '%.*s' ignored\n", (int)len, e);
+        e = end ? end + 1 : nullptr;
+    }
+}
+}  // namespace
+
+int qmri_knob(QmriKnob k) {
+    std::call_once(g_knob_once, knob_init);
+    return g_knob_val[k].load(std::memory_order_relaxed);
+}
+
+extern "C" int qmri_debug_knob(const char* name, int value) {
+    std::call_once(g_knob_once, knob_init);
+    const int k = name ? knob_index(name, strlen(name)) : -1;
+    if (k < 0) { qmri_set_error(nullptr, "qmri_debug_knob: unknown knob '%s'", name ? name : "(null)"); return QMRI_ERR_INVALID_ARG; }
+    g_knob_val[k].store(value, std::memory_order_relaxed);
+    return QMRI_OK;
+}
 
 void qmri_set_error(qmri_ctx* ctx, const char* fmt, ...) {
     char buf[1024];
@@ -379,9 +431,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     QMRI_TRY(dev_alloc(ctx, &ks.zhat, B * n));
     QMRI_TRY(dev_alloc(ctx, &ks.xhat_out, B * n));
     ks.stamps = nullptr;
-    if (const char* e = getenv("QMRI_LSQR_STAMPS")) {
-        if (atoi(e) > 0) { QMRI_TRY(dev_alloc(ctx, &ks.stamps, (size_t)2 * 512 * 16)); QMRI_HIP(ctx, hipMemset(ks.stamps, 0, 2 * 512 * 16 * 8)); }
-    }
+    if (qmri_knob(K_LSQR_STAMPS) > 0) { QMRI_TRY(dev_alloc(ctx, &ks.stamps, (size_t)2 * 512 * 16)); QMRI_HIP(ctx, hipMemset(ks.stamps, 0, 2 * 512 * 16 * 8)); }
     QMRI_TRY(dev_alloc(ctx, &ls.yk, B * (size_t)m));
     QMRI_TRY(dev_alloc(ctx, &o.d_x, B * n));
     QMRI_TRY(dev_alloc(ctx, &o.d_u, B * n));
@@ -571,7 +621,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     // two sums per iteration are in-kernel hand-offs instead of kernel boundaries); the two-launch iteration otherwise (EPI masks,
     // cut0, slice batches) and after a time-out of the persistent kernel (never seen; the inputs are untouched then).
     bool persisted = false;
-    if (ctx->ks_persist < 0) ctx->ks_persist = (getenv("QMRI_LSQR_PERSIST") && atoi(getenv("QMRI_LSQR_PERSIST")) == 0) ? 0 : 1;
+    if (ctx->ks_persist < 0) ctx->ks_persist = qmri_knob(K_LSQR_PERSIST) ? 1 : 0;
     if (ctx->ks_persist > 0 && maxit >= 1) {
         if (!ctx->d_ks_gran) {
             const size_t nb = ks_gran_bytes(ks.G, o.maxB);
@@ -674,7 +724,7 @@ extern "C" int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double 
     }
     QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_x, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return QMRI_OK;
+    return qmri_prof_chain_finish(ctx);
 }
 
 // test / A-B hook: 1 = all LSQR iterations in one launch where the grid is resident (default), 0 = the two-launch iteration
@@ -696,7 +746,11 @@ extern "C" int qmri_debug_lsqr_stamps(qmri_ctx* ctx, unsigned long long* out) {
     return QMRI_OK;
 }
 
-int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers, float share) {
+// profile level 2: the next (start, stop) event pair of the current chain.  The events take the timestamps of a kernel's own dispatch packet
+// (hipExtLaunchKernelGGL) -- the duration rocprofv3 --kernel-trace reports -- or, with start on one launch and stop on a later one, the span
+// from the first kernel's start to the last one's end (a split-K layer: convolution + reduce).  `kind` says which accumulator of qmri_profile
+// the duration goes to, `flop` is the pair's fp32-equivalent algorithmic work (convolutions).
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int kind, double flop) {
     *start = *stop = nullptr;
     if (ctx->prof_level < 2) return QMRI_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -708,23 +762,29 @@ int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layer
     }
     *start = ctx->chain[ctx->chain_n];
     *stop = ctx->chain[ctx->chain_n + 1];
-    if (ctx->chain_w.size() < ctx->chain_n / 2 + 1) ctx->chain_w.resize(ctx->chain_n / 2 + 1, 1);
-    ctx->chain_w[ctx->chain_n / 2] = layers;
-    if (ctx->chain_s.size() < ctx->chain_n / 2 + 1) ctx->chain_s.resize(ctx->chain_n / 2 + 1, 1.f);
-    ctx->chain_s[ctx->chain_n / 2] = share;
+    const size_t i = ctx->chain_n / 2;
+    if (ctx->chain_kind.size() < i + 1) { ctx->chain_kind.resize(i + 1, PROF_CONV3); ctx->chain_flop.resize(i + 1, 0.0); }
+    ctx->chain_kind[i] = kind;
+    ctx->chain_flop[i] = flop;
     ctx->chain_n += 2;
     return QMRI_OK;
 }
 
-int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv, long count) {
+// synchronises and adds the chain's durations to the profile; count >= 0: only the first `count` pairs (the others are dropped)
+int qmri_prof_chain_finish(qmri_ctx* ctx, long count) {
     if (ctx->prof_level < 2 || ctx->chain_n == 0) return QMRI_OK;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i + 1 < ctx->chain_n; i += 2) {
         if (count >= 0 && (long)(i / 2) >= count) break;
         float ms = 0.f;
         QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->chain[i], ctx->chain[i + 1]));
-        if (tv) { ctx->prof.ms_tv_iter += ms; ctx->prof.n_tv_iter += 1; }
-        else { ctx->prof.ms_conv3x3 += ms * ((i / 2 < ctx->chain_s.size()) ? ctx->chain_s[i / 2] : 1.f); ctx->prof.n_conv3x3 += (i / 2 < ctx->chain_w.size()) ? ctx->chain_w[i / 2] : 1; }
+        const double flop = ctx->chain_flop[i / 2];
+        switch (ctx->chain_kind[i / 2]) {
+            case PROF_TV: ctx->prof.ms_tv_iter += ms; ctx->prof.n_tv_iter += 1; break;
+            case PROF_LSQR: ctx->prof.ms_lsqr_kernels += ms; ctx->prof.n_lsqr_launches += 1; break;
+            case PROF_CONV2: ctx->prof.ms_conv2x2 += ms; ctx->prof.n_conv2x2 += 1; ctx->prof.flop_conv2x2 += flop; break;
+            default: ctx->prof.ms_conv3x3 += ms; ctx->prof.n_conv3x3 += 1; ctx->prof.flop_conv3x3 += flop; break;
+        }
     }
     ctx->chain_n = 0;
     return QMRI_OK;

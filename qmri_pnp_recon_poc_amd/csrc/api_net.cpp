@@ -42,7 +42,6 @@ void qmri_free_net(qmri_ctx* ctx) {
     for (float* b : p.allocs) if (b) (void)hipFree(b);
     if (p.d_counter) (void)hipFree(p.d_counter);
     if (p.d_stamps) (void)hipFree(p.d_stamps);
-    for (hipGraphExec_t g : p.fwd_graph) if (g) (void)hipGraphExecDestroy(g);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
     if (p.d_res_xbuf) (void)hipFree(p.d_res_xbuf);
     if (p.d_res_stamps) (void)hipFree(p.d_res_stamps);
@@ -107,7 +106,6 @@ static int net_set_scheme(qmri_ctx* ctx, int sp) {
         w += (size_t)L.Cin * L.Cout * ((L.kind == CONV_3X3 || L.kind == CONV_3X3N) ? 9 : 4);
     }
     p.sp6 = sp;
-    for (hipGraphExec_t& g : p.fwd_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }   // captured launches name the old kernels
     return QMRI_OK;
 }
 
@@ -126,13 +124,19 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
     if (p.h_range_flag) std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
     tripped = true;
-    if (f & 4u) {                                                   // (never seen) a hand-off of the resident-tile launch timed out: its results are garbage, and so
-        fprintf(stderr, "libqmri: a tile hand-off of the resident-tile convolution launch timed out; repeating with one launch per layer\n");   // may the other bits be
+    if (f & 4u) {                                                   // a hand-off of the resident-tile launch timed out: its results are garbage, and so
+        // may the other bits be.  Co-residency of its workgroups is assumed from tiles <= CUs; another stream, context or process on the device can break
+        // it for a while (tests/test_gpu_net.py: two contexts).  The call is repeated with one launch per layer; the resident form is tried again after
+        // res_rearm clean passes (knob, default 64) -- unless it has timed out three times since qmri_set_denoiser: then it stays off.
         p.res_off = true;
         p.res_timeouts += 1;
+        p.res_clean = 0;
+        if (p.res_timeouts <= 3)
+            fprintf(stderr, "libqmri: a tile hand-off of the resident-tile convolution launch timed out (%d since set-up); repeating with one launch per layer%s\n",
+                    p.res_timeouts, p.res_timeouts >= 3 ? ", the resident form stays off" : "");
         return QMRI_OK;
     }
-    if (getenv("QMRI_CALIB_VERBOSE")) fprintf(stderr, "libqmri: range guard of the f16 scheme tripped (flag %u: 1 overflow, 2 a layer collapsed): the network moves to the bf16 scheme\n", f);
+    if (qmri_knob(K_VERBOSE)) fprintf(stderr, "libqmri: range guard of the f16 scheme tripped (flag %u: 1 overflow, 2 a layer collapsed): the network moves to the bf16 scheme\n", f);
     QMRI_TRY(net_set_scheme(ctx, 3));
     p.fallbacks += 1;
     return QMRI_OK;
@@ -203,7 +207,7 @@ static int net_calibrate_scheme(qmri_ctx* ctx) {
 #else
         const bool ok = flag == 0 && std::isfinite(ref_max) && std::isfinite(diff_max) && diff_max <= 2e-5f * ref_max;
 #endif
-        if (getenv("QMRI_CALIB_VERBOSE"))
+        if (qmri_knob(K_VERBOSE))
             fprintf(stderr, "libqmri: calibration probe: max |out| %.3g, max |f16 - f32| %.3g, overflow flag %u -> %s scheme\n", ref_max, diff_max, flag,
                     ok ? "f16 x 3" : "bf16 x 6");
         if (!ok) {
@@ -281,7 +285,7 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
             QMRI_TRY(dev_alloc(ctx, &p.d_res_xbuf, conv6r_xbuf_bytes(p.res_tiles)));
             QMRI_HIP(ctx, hipMemset(p.d_res_xbuf, 0, conv6r_xbuf_bytes(p.res_tiles)));
             p.res_epoch = 0; p.res_off = false;
-            if (getenv("QMRI_RES_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_res_stamps, 1024 * sizeof(unsigned long long))); QMRI_HIP(ctx, hipMemset(p.d_res_stamps, 0, 1024 * sizeof(unsigned long long))); }
+            if (qmri_knob(K_RES_STAMPS)) { QMRI_HIP(ctx, hipMalloc(&p.d_res_stamps, 1024 * sizeof(unsigned long long))); QMRI_HIP(ctx, hipMemset(p.d_res_stamps, 0, 1024 * sizeof(unsigned long long))); }
         }
     } else {
         const int width = desc->nc[0];
@@ -305,7 +309,7 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     p.interior_fmt = -1;
     QMRI_TRY(dev_alloc(ctx, &p.d_counter, (size_t)1));
     QMRI_HIP(ctx, hipMemset(p.d_counter, 0, sizeof(unsigned)));
-    if (getenv("QMRI_CONV_STAMPS")) { QMRI_HIP(ctx, hipMalloc(&p.d_stamps, 4096 * 11 * sizeof(unsigned long long))); }
+    if (qmri_knob(K_CONV_STAMPS)) { QMRI_HIP(ctx, hipMalloc(&p.d_stamps, 4096 * 11 * sizeof(unsigned long long))); }
     p.counter_base = 0;
     p.ready = true;
     if (p.sp6 == 2) QMRI_TRY(net_calibrate_scheme(ctx));
@@ -345,7 +349,7 @@ static int net_forward_layers(qmri_ctx* ctx, int B);
 static int net_forward_padded(qmri_ctx* ctx, int B) {
     {
         // Interior tensors (everything between the head's input and the tail's output) are BLOCKED when every layer runs on the
-        // matrix-core kernels (PTensor::blk), planar otherwise (the f32-MFMA kernels of the calibration pass, QMRI_CONV_F32, odd
+        // matrix-core kernels (PTensor::blk), planar otherwise (the f32-MFMA kernels of the calibration pass, knob conv_f32, odd
         // channel counts).  The two formats put the zero halo at different addresses: a change of format re-zeroes the tensors.
         NetPlan& p = ctx->net;
         const bool blk = p.blk_ok && !p.force_f32 && conv6_enabled();
@@ -357,20 +361,23 @@ static int net_forward_padded(qmri_ctx* ctx, int B) {
                 if (ts[i]->p) QMRI_HIP(ctx, hipMemsetAsync(ts[i]->p, 0, ((size_t)p.maxB * ts[i]->batch_stride() + 8192) * sizeof(float), ctx->stream));
         }
         p.interior_fmt = blk ? 1 : 0;
-        // The ResBlocks' intermediate tensors can hold f16 PIECES in the f16 scheme (PTensor::pcs, QMRI_CONV_PIECES=1): bit-identical results
-        // (tests/test_gpu_net.py::test_pieces_tensors_change_no_bit) -- and, measured on one box (profiles/r04_k_*), no faster: 16.5-16.9 us per
-        // single-slice launch either way, 159.7 -> 161.4 us per 15-slice layer (the producer's epilogue, which the loader waves also run, pays
-        // what the consumer's loader saves).  OFF by default; kept as the measured answer to "store the pieces instead" (DESIGN.md 5.1 round 4).
-        // Zero bytes are zero pieces: the halo needs no re-zeroing when the format changes.
-        static const bool pieces_on = getenv("QMRI_CONV_PIECES") && atoi(getenv("QMRI_CONV_PIECES")) != 0;
-        const bool pcs = blk && pieces_on && p.sp6 == 2 && p.desc.arch == QMRI_ARCH_UNETRES && !p.d_stamps;
-        for (int l = 0; l < 4; ++l) { p.x[l].blk = blk; p.a[l].blk = blk; p.t[l].blk = blk; p.t[l].pcs = pcs; }
+        for (int l = 0; l < 4; ++l) { p.x[l].blk = blk; p.a[l].blk = blk; p.t[l].blk = blk; }
     }
     const bool report = !ctx->net.force_f32;                        // (the calibration's f32 pass reports nothing)
+    const bool timed = ctx->prof_level >= 2;                        // profile level 2: the whole pass between two stream events (besides the per-launch pairs)
+    if (timed) QMRI_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (report) QMRI_TRY(conv6_act_begin(ctx, (int)ctx->net.layers.size()));
     QMRI_TRY(net_forward_layers(ctx, B));
     if (report) QMRI_TRY(conv6_act_end(ctx));                       // low-magnitude guard of the f16 scheme (conv6_kernels.hip, ACT_LOW)
-    return qmri_prof_chain_finish(ctx);
+    if (timed) QMRI_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    QMRI_TRY(qmri_prof_chain_finish(ctx));                          // (level 2: synchronises)
+    if (timed) {
+        float ms = 0.f;
+        QMRI_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+        QMRI_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        ctx->prof.ms_net_forward += ms; ctx->prof.n_net_forward += 1;
+    }
+    return QMRI_OK;
 }
 
 static int net_forward_layers(qmri_ctx* ctx, int B) {
@@ -389,10 +396,8 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
         return QMRI_OK;
     }
     // UNetRes.forward, network_unet.py:106-117
-    // (the head belongs to the down path's resident-tile launch of the full-resolution level where that applies: QMRI_RES_HEAD=0 keeps it apart)
-    static const bool res_head = !(getenv("QMRI_RES_HEAD") && atoi(getenv("QMRI_RES_HEAD")) == 0);
-    static const bool res_tail = !(getenv("QMRI_RES_TAIL") && atoi(getenv("QMRI_RES_TAIL")) == 0);
-    static const bool res_down = !(getenv("QMRI_RES_DOWN") && atoi(getenv("QMRI_RES_DOWN")) == 0);
+    // (the head belongs to the down path's resident-tile launch of the full-resolution level where that applies: knob res_head = 0 keeps it apart)
+    const bool res_head = qmri_knob(K_RES_HEAD) != 0, res_tail = qmri_knob(K_RES_TAIL) != 0, res_down = qmri_knob(K_RES_DOWN) != 0;
     bool head_done = false, down_done = false;
     if (res_head && p.d_res_xbuf && !p.force_f32 && p.layers.size() >= (size_t)(2 + 2 * nb)) {
         Conv6rRun r;
@@ -429,26 +434,17 @@ static int net_forward_layers(qmri_ctx* ctx, int B) {
     return QMRI_OK;
 }
 
-// The forward pass is a fixed sequence of ~65 dependent launches with fixed arguments.  With QMRI_GRAPH=1 it is captured
-// into a hipGraph per batch size after one ordinary call (which performs every lazy allocation and attribute call) and
-// replayed.  Off by default: measured on MI355X the replay is not faster (413.7 vs 413.8 ADMM it/s) -- the 3-4 us between
-// dependent kernels are spent on the device (command processor, cache maintenance), not on the host.
+// (A hipGraph replay of the forward pass -- ~65 dependent launches with fixed arguments -- was measured in round 1 and is not faster: 413.7 vs 413.8
+//  ADMM it/s; the 3-4 us between dependent kernels are spent on the device, not on the host.  The capture path is gone since round 5.)
 static int net_forward(qmri_ctx* ctx, int B) {
     NetPlan& p = ctx->net;
-    static const bool use_graph = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;
-    if (!use_graph || B > 8 || ctx->prof_level >= 2 || p.d_stamps) return net_forward_padded(ctx, B);
-    if (p.fwd_graph[B]) { QMRI_HIP(ctx, hipGraphLaunch(p.fwd_graph[B], ctx->stream)); return QMRI_OK; }
-    if (p.fwd_calls[B]++ == 0) return net_forward_padded(ctx, B);
-    hipGraph_t graph = nullptr;
-    QMRI_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     const int st = net_forward_padded(ctx, B);
-    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-    if (st != QMRI_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
-    QMRI_HIP(ctx, e);
-    QMRI_HIP(ctx, hipGraphInstantiate(&p.fwd_graph[B], graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    QMRI_HIP(ctx, hipGraphLaunch(p.fwd_graph[B], ctx->stream));
-    return QMRI_OK;
+    // the resident-tile launch is switched off by a hand-off time-out (net_range_tripped); after K_RES_REARM clean forward passes it is tried again
+    if (st == QMRI_OK && p.res_off && p.res_timeouts > 0 && p.res_timeouts < 3 && !p.res_forced_off && ++p.res_clean >= std::max(1, qmri_knob(K_RES_REARM))) {
+        p.res_off = false;
+        p.res_clean = 0;
+    }
+    return st;
 }
 
 extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, float* d_out) {
@@ -462,16 +458,20 @@ extern "C" int qmri_net_forward_dev(qmri_ctx* ctx, const float* d_in, int B, flo
         const char *a = (const char*)d_in, *b = (const char*)d_out;
         QMRI_CHECK_ARG(ctx, a + hw * p.desc.in_nc <= b || b + hw * p.desc.out_nc <= a, "qmri_net_forward_dev: d_in and d_out must not overlap");
     }
-    for (int attempt = 0; attempt < 2; ++attempt) {        // (second pass only after the f16 range guard switched the scheme)
+    // A pass is repeated for two separate reasons -- a hand-off time-out of the resident-tile launch (then one launch per layer), the f16 range guard
+    // (then the bf16 scheme) -- and one may follow the other: up to three passes, and a call that still wants another one is an error, not QMRI_OK.
+    bool again = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {
         QMRI_TRY(ew_launch_pack(ctx, B, p.desc.in_nc, p.H, p.W, d_in, 0, p.in32));
         QMRI_TRY(net_forward(ctx, B));
         QMRI_TRY(ew_launch_unpack(ctx, B, p.desc.out_nc, p.H, p.W, p.out32, p.in32, 0, d_out, 0));
+        again = false;
         if (p.sp6 != 2) break;                              // (the bf16 scheme has no range to guard: stays asynchronous)
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        bool again = false;
         QMRI_TRY(net_range_tripped(ctx, again));
         if (!again) break;
     }
+    if (again) { qmri_set_error(ctx, "the network's guards asked for a fourth pass (resident-tile hand-off / f16 range): giving up"); return QMRI_ERR_HIP; }
     return QMRI_OK;
 }
 
@@ -482,6 +482,8 @@ extern "C" int qmri_debug_conv_resident(qmri_ctx* ctx, int on, int* timeouts_out
     if (timeouts_out) *timeouts_out = p.res_timeouts;
     if (!p.ready) return QMRI_OK;
     p.res_off = (on == 0);
+    p.res_forced_off = (on == 0);                                   // (a caller's choice is not re-armed behind its back)
+    if (on) { p.res_timeouts = std::min(p.res_timeouts, 2); p.res_clean = 0; }
     p.res_drop = (on == 2) ? 1 : 0;
     return QMRI_OK;
 }
@@ -525,8 +527,9 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
     double* d_io = nullptr;
     QMRI_HIP(ctx, hipMalloc((void**)&d_io, std::max(nin, nout) * sizeof(double)));
     int st = QMRI_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {        // (second pass only after the f16 range guard switched the scheme)
-        bool again = false;
+    bool again = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {        // (further passes only after a guard changed the plan: see qmri_net_forward_dev)
+        again = false;
         do {
             if (hipMemcpyAsync(d_io, in, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = QMRI_ERR_HIP; break; }
             if ((st = ew_launch_pack(ctx, B, C, H, W, d_io, 1, p.in32, in_scale)) != QMRI_OK) break;   // im2single: :72-77
@@ -538,6 +541,7 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
         } while (0);
         if (st != QMRI_OK || !again) break;
     }
+    if (st == QMRI_OK && again) { qmri_set_error(ctx, "the network's guards asked for a fourth pass (resident-tile hand-off / f16 range): giving up"); st = QMRI_ERR_HIP; }
     (void)hipFree(d_io);
     if (st == QMRI_ERR_HIP && ctx->err.empty()) qmri_set_error(ctx, "HIP failure in qmri_denoise");
     return st;
@@ -617,16 +621,14 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         QMRI_HIP(ctx, hipHostMalloc((void**)&o.h_ring, cap * sizeof(LsqrState), hipHostMallocDefault));
         o.h_ring_cap = cap;
     }
-    // Round 4: the small launches around the network are folded into their neighbours (LSQR solver; QMRI_FUSE_EW=0 restores the separate kernels
+    // Round 4: the small launches around the network are folded into their neighbours (LSQR solver; knob fuse_ew = 0 restores the separate kernels
     // for A/Bs): un-normalise + dual update + z + the h-pass of z's transform + the forward pass's |output| report = ONE launch (k_dual_fwd_h);
     // the w-pass of z rides in the solve's first kernel (k_ks_init_a<FWDW>); the min / max of real(x + u) come out of the solve's last h-pass.
-    static const bool fuse_ew = !(getenv("QMRI_FUSE_EW") && atoi(getenv("QMRI_FUSE_EW")) == 0);
-    static const bool graph_replay = getenv("QMRI_GRAPH") && atoi(getenv("QMRI_GRAPH")) > 0;
-    const bool fused = fuse_ew && prm->solver == QMRI_SOLVER_LSQR;
+    const bool fused = qmri_knob(K_FUSE_EW) != 0 && prm->solver == QMRI_SOLVER_LSQR;
     const int hb = dc_hpass_blocks(op);
     bool z_in_tmp = false;                                 // o.d_tmp holds the h-pass of z (and ls.pz hb partial sums per slice)
     struct DeferGuard { NetPlan& n; ~DeferGuard() { n.act_defer = false; n.act_pending_valid = false; } } defer_guard{net};
-    net.act_defer = fused && !graph_replay;
+    net.act_defer = fused;
     for (int it = 0; it < prm->iters; ++it) {
         // Step 1 (PnP_ADMM.m:102): x = argmin ||y - Ax||^2 + r ||x - (v - uold)||^2
         tm.start();
@@ -689,6 +691,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     if (prm->want_diag && diag_out && prm->iters > 0 && !range_trip)
         QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    QMRI_TRY(qmri_prof_chain_finish(ctx));                         // (profile level 2: the LSQR launches since the last forward pass)
     if (prm->solver == QMRI_SOLVER_LSQR && !range_trip) {          // LSQR counts of the iterations whose state was deferred; a timed-out one-launch kernel
         bool timed_out = false;
         for (int it = 0; it < prm->iters; ++it) {
@@ -1013,7 +1016,7 @@ extern "C" int qmri_recon_batch(int ndev, const int* devs, int nslices, const qm
 
 // diagnostic: copy the per-workgroup stamps of the most recent conv launch (see conv_kernels.hip) to the host
 extern "C" int qmri_debug_conv_stamps(qmri_ctx* ctx, unsigned long long* out, int nwg) {
-    if (ctx && nwg == -6 && ctx->net.d_res_stamps) {                // (the resident-tile launch's stamps: 1024 values, QMRI_RES_STAMPS=1)
+    if (ctx && nwg == -6 && ctx->net.d_res_stamps) {                // (the resident-tile launch's stamps: 1024 values, knob res_stamps)
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
         QMRI_HIP(ctx, hipMemcpy(out, ctx->net.d_res_stamps, (size_t)1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return QMRI_OK;

@@ -72,7 +72,7 @@ struct ConvArgs {
     int nch, ntiles, relu_out;
     unsigned* counter;                // monotonic tile-queue counter shared by all launches of a context
     unsigned base;                    // its value when this launch starts (launches are stream ordered)
-    unsigned long long* stamps;       // diagnostic build only (QMRI_CONV_STAMPS): per-workgroup timing stamps
+    unsigned long long* stamps;       // diagnostic build only (knob conv_stamps): per-workgroup timing stamps
 };
 
 template <int KIND, int MT>
@@ -368,7 +368,7 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
     // two MFMA row tiles per wave when the layer still has several tiles per workgroup slot that way
     const long t2 = (long)(n32 / 2) * n_pt * B;
     const bool is3 = (KIND == CONV_3X3 || KIND == CONV_3X3N);           // the six 2x2 layers always run one row tile per wave
-    static const long mt2_min = getenv("QMRI_CONV_MT2") ? atol(getenv("QMRI_CONV_MT2")) : 1024;
+    const long mt2_min = qmri_knob(K_CONV_MT2);
     const int MT = (is3 && n32 % 2 == 0 && t2 >= mt2_min) ? 2 : 1;
     const int n_ctiles = n32 / MT, ntiles = n_ctiles * n_pt * B;
     if (L.tab_B != B || L.tab_MT != MT || !L.d_tab) {                  // tile table: cout tile fastest (shared input tile -> L2 hits)
@@ -394,7 +394,7 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
     A.add2_bs = add2 ? (long)add2->Cal * add2->plane() : 0;
     A.nch = L.cin_pad / G_::CC; A.ntiles = ntiles; A.relu_out = relu_out;
     A.counter = ctx->net.d_counter;
-    static const bool stamps6 = getenv("QMRI_CONV_STAMP_LAUNCH") != nullptr;   // the buffer then belongs to k_conv6
+    const bool stamps6 = qmri_knob(K_CONV_STAMP_LAUNCH) >= 0;   // the buffer then belongs to k_conv6
     A.stamps = stamps6 ? nullptr : (unsigned long long*)ctx->net.d_stamps;
     // persistent grid: exactly as many workgroups as are resident at once (measured occupancy x CU count)
     // (per context, not function-local statics: qmri_recon_batch runs one host thread + context per device)
@@ -409,12 +409,12 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         int nb = 0;
         if (MT == 2) QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2>, NT, 0));
         else QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_conv<KIND, 1>, NT, 0));
-        static const int occ_cap = getenv("QMRI_CONV_OCC") ? atoi(getenv("QMRI_CONV_OCC")) : 2;
+        const int occ_cap = qmri_knob(K_CONV_OCC);
         occ[MT - 1] = std::max(1, std::min(nb, occ_cap));
     }
     const int grid = std::min(ntiles, ncu * occ[MT - 1]);
     // every workgroup issues (tiles it processes + 2) fetches, so a launch advances the counter by ntiles + 2*grid and the
-    // host can mirror its value.  Inside a stream capture (QMRI_GRAPH=1) the arguments are frozen, so the queue is reset by
+    // host can mirror its value.  Inside a stream capture (a caller capturing its own stream) the arguments are frozen, so the queue is reset by
     // a memset node instead.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(ctx->stream, &cap);
@@ -427,7 +427,11 @@ int launch_kind(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
         ctx->net.counter_base += (unsigned)(ntiles + 2 * grid);
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;                  // profile level 2: the kernel's own dispatch timestamps
-    if ((KIND == CONV_3X3 || KIND == CONV_3X3N) && L.Cin >= 64 && L.Cout >= 64) QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
+    {
+        const bool k3 = (KIND == CONV_3X3 || KIND == CONV_3X3N);
+        const double hw = k3 ? (double)in.H * in.W : (KIND == CONV_DOWN ? (double)(in.H / 2) * (in.W / 2) : (double)(2 * in.H) * (2 * in.W));
+        QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, k3 ? PROF_CONV3 : PROF_CONV2, 2.0 * L.Cout * L.Cin * (k3 ? 9.0 : (KIND == CONV_DOWN ? 4.0 : 1.0)) * hw * B));
+    }
     if (e0 && MT == 2) hipExtLaunchKernelGGL((k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2>), dim3(grid), dim3(NT), 0, ctx->stream, e0, e1, 0, A);
     else if (e0) hipExtLaunchKernelGGL((k_conv<KIND, 1>), dim3(grid), dim3(NT), 0, ctx->stream, e0, e1, 0, A);
     else if (MT == 2) k_conv<(KIND == CONV_3X3N ? CONV_3X3N : CONV_3X3), 2><<<dim3(grid), dim3(NT), 0, ctx->stream>>>(A);

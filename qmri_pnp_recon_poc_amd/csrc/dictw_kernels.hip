@@ -224,7 +224,7 @@ int dictw_launch(qmri_ctx* ctx, const double2* d_X, int Npix, float* d_qmap, flo
     // shape of the XCD super-tile (QMRI_DICTW_LSP for A/Bs): 4 pixel tiles x 16 atom parts.  Measured at s = 1000, K = 98 304 (profiles/r04_i_*): the
     // launch time does not depend on it (144 - 147 ms: the kernel is compute-bound), the bytes leaving the L2s do -- FETCH_SIZE as counted 167 GB (64 x 1),
     // 124 GB (8 x 8), 50 GB (4 x 16), 55 GB (2 x 32): X tiles (8 bytes per pixel and channel) are the larger operand, so more parts per pixel tile pay.
-    static const int lsp_env = getenv("QMRI_DICTW_LSP") ? atoi(getenv("QMRI_DICTW_LSP")) : 2;
+    const int lsp_env = qmri_knob(K_DICTW_LSP);
     const int lsp = std::max(0, std::min(6, lsp_env)), lsa = 6 - lsp;
     const int nsuper = ((PT + (1 << lsp) - 1) >> lsp) * ((P + (1 << lsa) - 1) >> lsa);
     const unsigned grid = 8u * 64u * (unsigned)((nsuper + 7) / 8);

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "dc_device.h"
+#include <hip/hip_ext.h>
 
 using namespace dcdev;
 
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     int conv_iter = -1;
     bool aborted = false;
 
-// (diagnostic, QMRI_LSQR_STAMPS=1: 100 MHz stamps of iteration 50, read by tools/lsqr_persist_stamps.py)
+// (diagnostic, knob lsqr_stamps = 1: 100 MHz stamps of iteration 50, read by tools/lsqr_persist_stamps.py)
 #define PS(k) do { if (ks.stamps && ii == 50 && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 512) ks.stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
     for (int ii = 1; ii <= ks.maxit; ++ii) {
         const unsigned tagA = tag0 + 2u * (unsigned)ii, tagB = tagA + 1u;
@@ -954,8 +955,15 @@ int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const
 // LSQR iteration ks.ii (1-based)
 int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
     const size_t vb = (size_t)ks.vcap * 8;
-    k_ks_a<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
-    k_ks_b<false><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+    hipEvent_t e0 = nullptr, e1 = nullptr;                          // profile level 2: one unit per iteration, k_ks_a's start to k_ks_b's end
+    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, PROF_LSQR));
+    if (e0) {
+        hipExtLaunchKernelGGL(k_ks_a, dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, nullptr, 0, op, ks);
+        hipExtLaunchKernelGGL(k_ks_b<false>, dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, nullptr, e1, 0, op, ks);
+    } else {
+        k_ks_a<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+        k_ks_b<false><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+    }
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -983,7 +991,10 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, vo
     KsGran* gu = (KsGran*)gran;
     KsGran* gv = gu + (size_t)B * 4 * ks.G;
     int* sticky = (int*)(gu + (size_t)ctx->op.maxB * 6 * ks.G);                         // (the word behind the granules: ks_gran_bytes)
-    k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0, sticky);
+    hipEvent_t e0 = nullptr, e1 = nullptr;                          // profile level 2: the whole solve's iterations as one unit
+    QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, PROF_LSQR));
+    if (e0) hipExtLaunchKernelGGL(k_ks_persist, dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, e1, 0, op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0, sticky);
+    else k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0, sticky);
     QMRI_HIP(ctx, hipGetLastError());
     *ran = true;
     return QMRI_OK;

@@ -260,7 +260,7 @@ int tv_prox_dev(qmri_ctx* ctx, TvWork& w, const double* d_b, int R, int C, doubl
             told = t;
             const int in = launched & 1;
             hipEvent_t e0 = nullptr, e1 = nullptr;                        // profile level 2: the kernel's own dispatch timestamps
-            QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1));
+            QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, PROF_TV));
             if (e0) hipExtLaunchKernelGGL(k_tv_iter, grid, dim3(TVT), 0, ctx->stream, e0, e1, 0, d_b, (const double*)w.r[in], (const double*)w.s[in], w.r[in ^ 1],
                                           w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st, R, C, gamma, mom, tol, maxit, launched);
             else k_tv_iter<<<grid, dim3(TVT), 0, ctx->stream>>>(d_b, w.r[in], w.s[in], w.r[in ^ 1], w.s[in ^ 1], w.pold, w.qold, d_sol, w.partials, w.st,
@@ -270,7 +270,7 @@ int tv_prox_dev(qmri_ctx* ctx, TvWork& w, const double* d_b, int R, int C, doubl
         QMRI_HIP(ctx, hipMemcpyAsync(&h, w.st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
         // profile: launches 0 .. iter-1 performed an iteration; the later ones only evaluated the rule or returned at once
-        QMRI_TRY(qmri_prof_chain_finish(ctx, true, std::max(0, std::min(n, (h.done ? h.iter : launched) - chunk_start))));
+        QMRI_TRY(qmri_prof_chain_finish(ctx, std::max(0, std::min(n, (h.done ? h.iter : launched) - chunk_start))));
         if (h.done) break;
     }
     *iters = h.iter; *obj = h.obj[h.iter & 1];

@@ -39,6 +39,33 @@ void qmri_set_error(qmri_ctx* ctx, const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------
+// A/B and diagnostic switches ("knobs").  ONE environment variable, QMRI_DEBUG="name=value,name=value" (read once per process), and
+// one entry point, qmri_debug_knob(name, value) (include/qmri.h), set them; every default is the product's behaviour.  The table of
+// names and defaults is in api_core.cpp (g_knob_defs, same order as this enum).
+// ---------------------------------------------------------------------------------------------------
+enum QmriKnob {
+    K_CONV_SCHEME,        // 2: f16 x 3 products (default), 3: bf16 x 6 products from the start
+    K_CONV_F32,           // 1: every layer on the f32-MFMA kernels (conv_kernels.hip)
+    K_CONV_WT,            // write-through (sc1) output stores of the conv kernels
+    K_CONV_XCD,           // XCD-aware tile order
+    K_CONV_PERSIST,       // k_conv6p for slice batches
+    K_CONV_SPLITK,        // split-K at the deep levels
+    K_CONV_MIDCFG, K_CONV_DEEPCFG, K_CONV_DEEPKS,   // tile configuration of the 56 x 56 / 28 x 28 level, largest K split of the latter
+    K_CONV_RESIDENT,      // k_conv6r: the full-resolution level's layers as one launch with resident tiles
+    K_RES_HEAD, K_RES_TAIL, K_RES_DOWN,             // ... with the head / tail / down-sampling convolution inside
+    K_RES_DELAY,          // ... pause before the ring fetch, in units of 64 clocks
+    K_RES_REARM,          // ... clean one-launch-per-layer passes after a hand-off time-out before the resident form is tried again
+    K_RES_STAMPS, K_CONV_STAMPS, K_CONV_STAMP_LAUNCH, K_LSQR_STAMPS,   // diagnostic builds' in-kernel stamps
+    K_CONV_MT2, K_CONV_OCC,                         // f32-MFMA fallback kernels: tile / occupancy choices
+    K_FUSE_EW,            // the fused launches between the network and the solve
+    K_LSQR_PERSIST,       // k_ks_persist: all LSQR iterations of a solve in one launch
+    K_DICTW_LSP,
+    K_VERBOSE,            // calibration / guard decisions on stderr
+    K_COUNT
+};
+int qmri_knob(QmriKnob k);
+
+// ---------------------------------------------------------------------------------------------------
 // forward operator (struct F): device-side description
 // ---------------------------------------------------------------------------------------------------
 struct KEntry {          // one sample of the k-sorted measurement list
@@ -151,9 +178,6 @@ struct PTensor {
     // interior format of the matrix-core conv kernels (conv6_kernels.hip: 8 channels of a pixel = 32 contiguous bytes = two 16-byte
     // requests).  Same allocation either way (Cal % 8 == 0); a property of the current forward pass, set by net_forward_padded.
     bool blk = false;
-    // PIECES (round 4, conv6_kernels.hip pieces8): a BLOCKED tensor whose 32-byte items hold the f16 pieces of the 8 channels, [8 x hi][8 x lo'],
-    // instead of 8 floats -- the ResBlocks' intermediate tensors in the f16 scheme, written by one convolution's epilogue and copied by the next one's loader
-    bool pcs = false;
     float* base1() const { return p + (h0 - 1); }
     float* fbase() const { return p + (size_t)(h0 - 1) * (blk ? 8 : 1); }      // halo origin of row 0 in the tensor's current format
     size_t plane() const { return (size_t)hp * (W + 2); }
@@ -174,9 +198,7 @@ struct NetPlan {
     std::vector<float*> allocs;
     unsigned* d_counter = nullptr;   // tile-queue counter of the persistent conv kernels
     unsigned counter_base = 0;       // host mirror of its value after the launches issued so far
-    bool counter_by_memset = false;  // graph mode: the queue is reset before every launch instead
-    hipGraphExec_t fwd_graph[9] = {};  // captured forward pass per batch size 1..8 (index B), null until the second call
-    int fwd_calls[9] = {};
+    bool counter_by_memset = false;  // a launch under a stream capture: the queue is reset before every launch instead
     bool force_f32 = false;             // calibration (qmri_set_denoiser): run the f32-MFMA kernels whatever the scheme
     unsigned* d_range_flag = nullptr;   // f16 scheme: raised by a conv kernel whose output leaves the f16-splittable range
     unsigned* h_range_flag = nullptr;   // pinned host words written by k_act_check at the end of every forward pass: [0] overflow bit, [1 + layer] low-magnitude bit
@@ -196,16 +218,18 @@ struct NetPlan {
     std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
-    void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (QMRI_CONV_STAMPS=1)
+    void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (knob conv_stamps = 1)
     // resident-tile ResBlock runs (conv6_kernels.hip k_conv6r): the exchange buffer of the tiles' edge pixels (two layer parities x tiles x 23.5 KB), the
     // running tag of its granules (never reset), and the switch a timed-out hand-off turns off for the life of the plan
     unsigned char* d_res_xbuf = nullptr;
     int res_tiles = 0;
     unsigned res_epoch = 0;
     bool res_off = false;
-    int res_timeouts = 0;
+    bool res_forced_off = false;     // ... by qmri_debug_conv_resident(ctx, 0, ..): never re-armed
+    int res_timeouts = 0;            // hand-off time-outs since qmri_set_denoiser (three: the form stays off)
+    int res_clean = 0;               // clean one-launch-per-layer passes since the last one (K_RES_REARM of them re-arm the form)
     int res_drop = 0;                // test hook: bit 0 = tile 0 withholds its hand-off
-    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (QMRI_RES_STAMPS=1), 4 x 2 x R_MAXL (10) x 8 of 1024 values
+    void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (knob res_stamps), 4 x 2 x R_MAXL (10) x 8 of 1024 values
     bool ready = false;
 };
 
@@ -279,15 +303,14 @@ struct qmri_ctx {
     // without putting extra packets between dependent kernels (event records in the stream add 3-5 us per kernel)
     std::vector<hipEvent_t> chain;      // pairs: [2i] start, [2i+1] stop
     size_t chain_n = 0;                 // events handed out in the current forward
-    std::vector<int> chain_w;           // layers a pair stands for (1; a resident-tile launch: all its layers)
-    std::vector<float> chain_s;         // share of the pair's duration that belongs to those layers (a resident-tile launch with the head / tail inside: their matrix work's share is left out)
+    std::vector<int> chain_kind;        // which accumulator of qmri_profile a pair's duration goes to (PROF_*)
+    std::vector<double> chain_flop;     // fp32-equivalent algorithmic flop of the launch(es) a pair brackets (convolutions)
     bool conv6_attr[4][2] = {};         // dynamic LDS size of k_conv6<CFG, SP> allowed
     bool conv6p_attr[2][3] = {{false, false, false}, {false, false, false}};   // ... of k_conv6p<CFG, NRES>
-    bool conv6i_attr[4] = {false, false, false, false};   // ... of k_conv6i<CFG> (PIECES input)
     bool conv6r_attr = false;           // ... of k_conv6r
     bool ks_lds_attr[2] = {false, false};   // large dynamic LDS allowed for the k-space LSQR kernels
     int lsqr_pred = 20;                 // predicted LSQR iteration count for launch chunking
-    int ks_persist = -1;                // k_ks_persist (all LSQR iterations in one launch): -1 = QMRI_LSQR_PERSIST (default on), 0 / 1 set by qmri_debug_lsqr_persist
+    int ks_persist = -1;                // k_ks_persist (all LSQR iterations in one launch): -1 = knob lsqr_persist (default on), 0 / 1 set by qmri_debug_lsqr_persist
     int ks_persist_cap = -1;            // ... workgroups of it the device holds at once (occupancy query, first use)
     void* d_ks_gran = nullptr;          // ... its tagged partial sums (granules)
     unsigned ks_tag = 16;               // ... tag of the next solve's first granule (tags are unique across solves)
@@ -349,12 +372,13 @@ int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTe
                 const PTensor* add2, int relu_out);
 int conv_cin_pad(ConvKind kind, int Cin);
 // bf16 x 6 path of the 3x3 layers (conv6_kernels.hip)
-int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int layers = 1, float share = 1.f);   // profile level 2: next event pair of the forward (else nullptrs)
-int qmri_prof_chain_finish(qmri_ctx* ctx, bool tv = false, long count = -1);   // count >= 0: only the first `count` pairs are accumulated   // synchronises, adds the pairs' durations to prof.ms_conv3x3 / n_conv3x3 (tv: ms_tv_iter / n_tv_iter)
+enum { PROF_CONV3 = 0, PROF_CONV2 = 1, PROF_LSQR = 2, PROF_TV = 3 };
+int qmri_prof_pair(qmri_ctx* ctx, hipEvent_t* start, hipEvent_t* stop, int kind = PROF_CONV3, double flop = 0.0);   // profile level 2: next event pair (else nullptrs)
+int qmri_prof_chain_finish(qmri_ctx* ctx, long count = -1);   // synchronises, adds the pairs' durations to the profile; count >= 0: only the first `count` pairs
 bool conv6_enabled();
 int conv6_act_begin(qmri_ctx* ctx, int nlayers);           // f16 scheme: start / finish the per-layer |output| report of a forward pass
 int conv6_act_end(qmri_ctx* ctx);
-int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (QMRI_CONV_SCHEME=bf16x6)
+int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (knob conv_scheme = 3)
 bool conv6_weights_fit_f16(const float* w, size_t n);
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,

@@ -314,7 +314,7 @@ def test_admm_224_full_length_100_iterations(engine_mod, oracle, synth, case224,
 def test_fused_small_launches_equal_separate_kernels(tmp_path):
     """Round 4 folds the launches between the network and the solve into their neighbours (k_dual_fwd_h, k_ks_init_a<FWDW>, min / max in k_adj_h).
     The arithmetic of x, u, z is the same; only the partial sums of |z|^2 (the solve's stop threshold) are added in another fixed order.  With
-    QMRI_FUSE_EW=0 (read once per process: two child processes) the separate kernels run: after 8 ADMM iterations at 224 x 224 -- single slice
+    QMRI_DEBUG="fuse_ew=0" (two child processes) the separate kernels run: after 8 ADMM iterations at 224 x 224 -- single slice
     and a batch of 3, single- and multi-level denoiser -- the LSQR iteration counts must be identical and x equal to rounding (1e-12)."""
     import os
     import subprocess
@@ -347,7 +347,7 @@ def test_fused_small_launches_equal_separate_kernels(tmp_path):
     res = {}
     for flag in ("1", "0"):
         path = str(tmp_path / f"fuse_{flag}.npz")
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, QMRI_FUSE_EW=flag), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, QMRI_DEBUG="fuse_ew=" + flag), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         res[flag] = np.load(path)
     for k in res["1"].files:

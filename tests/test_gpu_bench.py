@@ -21,7 +21,7 @@ def _run(args, timeout=900):
 
 def test_bench_two_ranks_without_a_launcher():
     """`bench.py --gpus 2` alone: two worker processes (here both on device 0 over gloo: one-GPU box), one line, n_gpus 2."""
-    out = _run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "4", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
+    out = _run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "4", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-secondary",
                 "--slices-total", "5", "--slices-iters", "2", "--batch", "2"])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
     assert out["scaling"] == "weak" and out["config"]["parallelism"].startswith("slice-parallel x2")
@@ -29,8 +29,21 @@ def test_bench_two_ranks_without_a_launcher():
     assert sl["n_gpus"] == 2 and sl["total_slices"] == 5 and sl["slices_on_rank0"] == 3 and sl["value"] > 0 and sl["scaling"] == "strong"
 
 
+def test_bench_many_ranks_rehearsed_on_one_device():
+    """The driver's N = 8 run rehearsed on the one-GPU box, as far as the box allows: its process guard admits six GPU processes at once and this
+    test session is one of them, so FIVE ranks share device 0 over gloo (10 slices -> 2 per rank, one batch of 2 each).  What the 8-GPU run adds
+    over the two-rank test is exercised: a rendezvous of many ranks started by a parent that never touches the GPU, a shard per rank, many contexts
+    on one device at once -- both co-residency kernels (k_ks_persist, k_conv6r) must run or fall back cleanly when they do not get the chip to
+    themselves -- and the max-over-ranks line.  (N = 8 itself: tests/test_dist_gloo.py, --plumbing-only, on the CPU.)"""
+    out = _run(["--gpus", "5", "--backend", "gloo", "--one-device", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-secondary",
+                "--slices-total", "10", "--slices-iters", "2", "--batch", "2"], timeout=1200)
+    assert out["n_gpus"] == 5 and out["steps"] == 3 and out["value"] > 0 and out["config"]["parallelism"].startswith("slice-parallel x5")
+    sl = out["slices"]
+    assert sl["n_gpus"] == 5 and sl["total_slices"] == 10 and sl["slices_on_rank0"] == 2 and sl["value"] > 0 and sl["scaling"] == "strong"
+
+
 def test_bench_line_has_roofline_cpu_baseline_and_parity():
-    out = _run(["--steps", "6", "--warmup", "2", "--cpu-iters", "6", "--slices-total", "6", "--slices-iters", "3", "--batch", "3"])
+    out = _run(["--steps", "6", "--warmup", "2", "--cpu-iters", "6", "--slices-total", "6", "--slices-iters", "3", "--batch", "3", "--secondary-steps", "4"])
     assert out["n_gpus"] == 1 and out["unit"] == "ADMM iters/s" and out["dtype"] == "f32"
     # north_star's second metric rides in the same line (default: 120 slices x 100 iterations; here 6 x 3): slices/s, the batched conv
     # kernel's roofline and the dictionary match against the f16 pipe it runs on (a fraction <= 1)
@@ -41,6 +54,24 @@ def test_bench_line_has_roofline_cpu_baseline_and_parity():
     assert 0 < dmr["frac"] < 1 and dmr["peak"] == 2500.0 and sl["dict_match"]["ms_per_slice"] > 0
     rf, cb, pa = out["roofline"], out["cpu_baseline"], out["parity"]
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # the roofline is a pure measurement: executed flop of the timed units / the sum of their durations; a forward pass has 2 resident-tile launches
+    # + 40 one-launch layers (8 of them with their split-K reduce inside the unit) = 42 units worth ~58 layer-equivalents (head, tail, down conv included)
+    assert abs(rf["achieved"] - rf["executed_flop_per_forward"] / (rf["ms_timed_per_forward"] * 1e-3) / 1e12) < 0.02 * rf["achieved"]
+    assert 41.5 <= rf["units_per_forward"] <= 42.5 and 56 < rf["layer_equivalents_per_forward"] < 58
+    wdn = rf["whole_denoiser"]
+    assert 0 < wdn["frac"] <= rf["frac"] and abs(wdn["executed_flop"] - 3 * 213253619712) < 1 and rf["all_conv_launches"]["frac"] <= rf["frac"] * 1.02
+    xu = out["xupdate"]                                              # the data-consistency stage against the HBM roofline
+    assert xu["roofline"]["bound"] == "hbm" and xu["roofline"]["peak"] == 8000.0 and 0 < xu["roofline"]["frac"] and xu["us_per_lsqr_iteration"] > 0
+    assert xu["bytes_per_lsqr_iteration_per_slice"] == 16 * (8 * 11051 * 10 + 2 * 123604) + 4 * 123604
+    dw = out["denoiser_weights_timing"]
+    assert dw["denoiser_ms_structured_weights"] > 0 and dw["denoiser_ms_random_weights"] > 0 and dw["implied_admm_iters_per_s_with_random_weights"] > 0
+    # BASELINE configs[2] and cut0 on the same line
+    ep, c0 = out["epi_batch15"], out["cut0"]
+    assert ep["slices_per_launch"] == 15 and ep["m"] == 134400 and ep["sampled_k_locations"] == 224 * 224 and ep["value"] > 0
+    assert c0["slices_per_launch"] == 1 and c0["T"] == 1000 and c0["m"] > 600000 and c0["value"] > 0
+    for o in (ep, c0):
+        assert set(o["stage_ms_per_iter"]) == {"xupdate", "denoiser", "elementwise"} and 0 < o["xupdate_share_of_iteration"] < 1
+        assert o["xupdate"]["roofline"]["bound"] == "hbm" and 0 < o["xupdate"]["roofline"]["frac"] < 1 and o["xupdate"]["us_per_lsqr_iteration"] > 0
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["one_thread_value"] > 0 and cb["cpu_model"]
     assert set(cb["stage_ms_per_iter"]) == {"xupdate", "diagnostics", "denoiser", "elementwise"}
     # parity of the timed slice after the 6 iterations both sides ran (tolerances: DESIGN.md section 7)

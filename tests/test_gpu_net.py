@@ -94,7 +94,7 @@ def test_raw_forward_entry_point_is_guarded_too(engine_mod):
 
 
 def test_bf16x6_scheme_selectable():
-    """QMRI_CONV_SCHEME=bf16x6 (read once per process) runs the six-product kernels: same golden vector, own process."""
+    """QMRI_DEBUG="conv_scheme=3" (the knob is read when the plan is made) runs the six-product kernels: same golden vector, own process."""
     import subprocess
     import sys
     code = (
@@ -107,7 +107,7 @@ def test_bf16x6_scheme_selectable():
         "y = e.denoise(g['x'].transpose(1, 2, 0).astype(np.float64)).transpose(2, 0, 1)\n"
         "print(float(np.linalg.norm(y - g['y']) / np.linalg.norm(g['y'])))\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(GOLDEN, "unetres_tiny_11ch.npz"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, QMRI_CONV_SCHEME="bf16x6"), timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, QMRI_DEBUG="conv_scheme=3"), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert float(r.stdout.strip().splitlines()[-1]) < 2e-5
 
@@ -436,18 +436,17 @@ def tile_oracle(synth, sensitive_net):
     return np.stack([ys[0]] + ys, axis=3)                          # [single-slice call, the three slices of the batched call]
 
 
-@pytest.mark.parametrize("cfg", ["", "QMRI_CONV_MIDCFG=0 QMRI_CONV_DEEPCFG=0 QMRI_CONV_DEEPKS=8", "QMRI_CONV_MIDCFG=1 QMRI_CONV_DEEPCFG=1",
-                                 "QMRI_CONV_MIDCFG=2 QMRI_CONV_DEEPCFG=2 QMRI_CONV_DEEPKS=2", "QMRI_CONV_SPLITK=0", "QMRI_CONV_PERSIST=0"],
+@pytest.mark.parametrize("cfg", ["", "conv_midcfg=0,conv_deepcfg=0,conv_deepks=8", "conv_midcfg=1,conv_deepcfg=1",
+                                 "conv_midcfg=2,conv_deepcfg=2,conv_deepks=2", "conv_splitk=0", "conv_persist=0"],
                          ids=["default", "tiles256_splitK8", "tiles128_splitK", "tiles64", "no_splitK", "no_persistent"])
 def test_every_tile_configuration_matches_the_oracle(tile_oracle, cfg):
-    """The tuning switches select other tile shapes / K splits for the deep levels (conv6_launch).  Each configuration -- the default
-    included -- runs the full-size network with the SENSITIVE weights (every level matters) in a fresh process (the switches are
-    read once) and is compared with the ORACLE, single-slice call and a batch of three, at the parity tolerance 2e-5."""
+    """The tuning knobs (QMRI_DEBUG) select other tile shapes / K splits for the deep levels (conv6_launch).  Each configuration -- the default
+    included -- runs the full-size network with the SENSITIVE weights (every level matters) in a fresh process and is compared with the ORACLE, single-slice call and a batch of three, at the parity tolerance 2e-5."""
     import subprocess, sys, tempfile
     with tempfile.TemporaryDirectory() as d:
         env = dict(os.environ)
-        for kv in cfg.split():
-            k, v = kv.split("="); env[k] = v
+        if cfg:
+            env["QMRI_DEBUG"] = cfg
         out = os.path.join(d, "y.npy")
         subprocess.run([sys.executable, "-c", _TILE_CODE, out], check=True, env=env, timeout=300)
         y = np.load(out)
@@ -455,40 +454,6 @@ def test_every_tile_configuration_matches_the_oracle(tile_oracle, cfg):
     for j in range(4):
         err = rel_err(y[..., j], tile_oracle[..., j])
         assert err < 2e-5, (cfg, j, err)
-
-
-def test_pieces_tensors_change_no_bit(tmp_path):
-    """Round 4: the ResBlocks' intermediate tensors hold the f16 PIECES of their values (written by the first convolution's epilogue, copied by the
-    second one's loader) instead of floats that every consuming tile splits again.  The pieces are what the split makes of the stored value either
-    way: the network's output must be IDENTICAL, bit for bit, with QMRI_CONV_PIECES=0 (read once per process: two child processes) -- one slice
-    (k_conv6 at all four levels, split-K reduce at 28 x 28), a batch of 5 (k_conv6p), and a 64 x 64 input (tiles that overhang the image)."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np\n"
-        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
-        "from qmri_pnp_recon_poc_amd import engine as E, synth\n"
-        "w = synth.random_weights(seed=1, gain=0.7)\n"
-        "rng = np.random.default_rng(3)\n"
-        "out = {}\n"
-        "for N, B in ((224, 1), (224, 5), (64, 2)):\n"
-        "    e = E.Engine(0)\n"
-        "    e.set_denoiser(w, N, N, max_batch=B)\n"
-        "    x = rng.random((N, N, 10, B))\n"
-        "    out[f'y{N}_{B}'] = e.denoise(x if B > 1 else x[..., 0])\n"
-        "    assert e.denoiser_scheme() == (2, 0)\n"
-        "    e.close()\n"
-        "np.savez(sys.argv[1], **out)\n")
-    res = {}
-    for flag in ("1", "0"):
-        path = str(tmp_path / f"pieces_{flag}.npz")
-        env = dict(os.environ, QMRI_CONV_PIECES=flag)
-        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[flag] = np.load(path)
-    for k in res["1"].files:
-        a, b = res["1"][k], res["0"][k]
-        assert np.all(np.isfinite(a)) and np.array_equal(a, b), (k, float(np.abs(a - b).max()))
 
 
 def test_resident_tile_launch_changes_no_bit(engine_mod, synth):

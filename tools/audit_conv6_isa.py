@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Audit the gfx950 ISA of k_conv6's loader waves: between an inline-asm global_load and the counted s_waitcnt that
 releases it, no instruction may touch the load's destination registers (the compiler does not know they are in flight).
-Usage: tools/audit_conv6_isa.py  (compiles conv6_kernels.hip to assembly with hipcc; CPU only)"""
+Usage: tools/audit_conv6_isa.py  (compiles the four conv6*_kernels.hip files to assembly with hipcc; CPU only)"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'qmri_pnp_recon_poc_amd', 'csrc', 'conv6_kernels.hip')
+SRCS = [os.path.join(ROOT, 'qmri_pnp_recon_poc_amd', 'csrc', f) for f in ('conv6_kernels.hip', 'conv6p_kernels.hip', 'conv6r_kernels.hip', 'conv6s_kernels.hip')]
 
 
 def regs(tok):
@@ -131,10 +131,12 @@ def audit(lines, name):
 
 
 def main():
+    text = []
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, 'c6.s')
-        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-fno-slp-vectorize', '-S', '--cuda-device-only', SRC, '-o', out])   # (flags of csrc/Makefile)
-        text = open(out).read().split('\n')
+        for k, src in enumerate(SRCS):
+            out = os.path.join(d, 'c6_%d.s' % k)
+            subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-fno-slp-vectorize', '-S', '--cuda-device-only', src, '-o', out])   # (flags of csrc/Makefile)
+            text += open(out).read().split('\n')
     total = 0
     cur, name = [], None
     for l in text:

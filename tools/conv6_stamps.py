@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""Barrier-arrival timeline of k_conv6 (QMRI_CONV_STAMPS=1) for the last conv launch of a UNetRes forward.  GPU only."""
+"""Barrier-arrival timeline of k_conv6 (knob conv_stamps = 1) for the last conv launch of a UNetRes forward.  GPU only."""
 import ctypes as C
 import os
 import sys
 
-os.environ['QMRI_CONV_STAMPS'] = '1'
-os.environ.setdefault('QMRI_CONV_STAMP_LAUNCH', '-1')
+os.environ['QMRI_DEBUG'] = 'conv_stamps=1,conv_stamp_launch=' + os.environ.get('STAMP_LAUNCH', '-1')
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -5,7 +5,7 @@ barrier, and what a loader step spends its time on.  GPU only.
     python tools/conv6p_stamps.py [B=15] [launch=60]
 
 The diagnostic build (template parameter STAMP) is launched in place of the production kernel for ONE launch
-(QMRI_CONV_STAMP_LAUNCH: running number of k_conv6 / k_conv6p launches of the process; with one context, launches 0..57 are the
+(knob conv_stamp_launch: running number of k_conv6 / k_conv6p launches of the process; with one context, launches 0..57 are the
 calibration forward of qmri_set_denoiser, 58 the head layer of the first real forward, 59 / 60 the first ResBlock's two 3x3 layers
 at the 224 x 224 level).  Its run time is NOT the production kernel's: read the shares, not the length."""
 import ctypes as C
@@ -13,8 +13,7 @@ import os
 import sys
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 15
-os.environ['QMRI_CONV_STAMPS'] = '1'
-os.environ['QMRI_CONV_STAMP_LAUNCH'] = sys.argv[2] if len(sys.argv) > 2 else '60'
+os.environ['QMRI_DEBUG'] = 'conv_stamps=1,conv_stamp_launch=' + (sys.argv[2] if len(sys.argv) > 2 else '60')
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

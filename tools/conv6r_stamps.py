@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase times inside the resident-tile ResBlock launch (k_conv6r, QMRI_RES_STAMPS=1): 100 MHz stamps of four workgroups (matrix wave 0 and loader
+"""Phase times inside the resident-tile ResBlock launch (k_conv6r, knob res_stamps): 100 MHz stamps of four workgroups (matrix wave 0 and loader
 wave 0), per layer, of the LAST launch of a forward pass (the up path's run)."""
 import ctypes as C
 import os
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-os.environ["QMRI_RES_STAMPS"] = sys.argv[1] if len(sys.argv) > 1 else "1"          # 1: the up path's launch (ResBlocks + tail), 2: the down path's (head + ResBlocks + down-sampling convolution)
+os.environ["QMRI_DEBUG"] = "res_stamps=" + (sys.argv[1] if len(sys.argv) > 1 else "1")          # 1: the up path's launch (ResBlocks + tail), 2: the down path's (head + ResBlocks + down-sampling convolution)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: where and when do the persistent conv workgroups run?  (QMRI_CONV_STAMPS=1; the stamps are those of
+"""Diagnostic: where and when do the persistent conv workgroups run?  (knob conv_stamps = 1; the stamps are those of
 the LAST conv launch, so this runs a 2-layer SEQ_CONV net whose last layer is the shape of interest.)
     python tools/conv_census.py CHANNELS IMAGE_SIZE"""
 import ctypes as C
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["QMRI_CONV_STAMPS"] = "1"
+os.environ["QMRI_DEBUG"] = "conv_stamps=1"
 from qmri_pnp_recon_poc_amd import engine as E, synth  # noqa: E402
 
 C_, HW = int(sys.argv[1]), int(sys.argv[2])

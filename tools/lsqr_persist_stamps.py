@@ -1,5 +1,5 @@
 import os, sys, ctypes
-os.environ['QMRI_LSQR_STAMPS'] = '1'
+os.environ['QMRI_DEBUG'] = 'lsqr_stamps=1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from qmri_pnp_recon_poc_amd import synth, engine as E

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Phase breakdown of the fused LSQR kernels from in-kernel stamps (QMRI_LSQR_STAMPS=1).  GPU only."""
+"""Phase breakdown of the fused LSQR kernels from in-kernel stamps (knob lsqr_stamps = 1).  GPU only."""
 import os, sys, ctypes
-os.environ['QMRI_LSQR_STAMPS'] = '1'
+os.environ['QMRI_DEBUG'] = 'lsqr_stamps=1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from qmri_pnp_recon_poc_amd import synth, engine as E

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """100 LSQR iterations per x-update (tol far below reach) on the headline operator, a few times: run under rocprofv3 --kernel-trace --stats to read
-the per-iteration cost of k_ks_persist (one launch = 100 iterations) or of k_ks_a + k_ks_b (QMRI_LSQR_PERSIST=0)."""
+the per-iteration cost of k_ks_persist (one launch = 100 iterations) or of k_ks_a + k_ks_b (QMRI_DEBUG="lsqr_persist=0")."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
