@@ -148,6 +148,13 @@ int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_params* p, const
 int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* p, const void* d_x0,
                       const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out);
 
+/* A slice stack from HOST buffers through one context: y nslices x m, x0 / gt nslices x N*M*s or NULL, x_out nslices x N*M*s (slice-major =
+ * the columns of a MATLAB m x S matrix / the 4th dimension of an N x M x s x S array), advanced slices_per_launch at a time
+ * (<= max_batch of qmri_set_operator and qmri_set_denoiser).  diag_out: nslices x iters x 2 or NULL; lsqr_iters_out: nslices x iters or NULL.
+ * What `PnP_ADMM_hip(Y, param)` calls for a measurement matrix; qmri_recon_batch is the pipelined multi-GPU form. */
+int qmri_pnp_admm_batch(qmri_ctx* ctx, int nslices, int slices_per_launch, const void* y, const qmri_admm_params* p, const void* x0,
+                        const void* gt, void* x_out, double* diag_out, int32_t* lsqr_iters_out);
+
 /* ---- LRTV option: x = FISTA_deep(data, param), main_recon_tsmis_FFT.m:273-282 -------------------------- */
 /* FISTA with backtracking on 0.5 |y - F.forward(x)|^2 + K |x|_TV (FISTA_deep.m:31-104); the TV prox is unlocbox's
  * prox_tv (prox_tv.m:99-203) on the stacked image [real(x); imag(x)] of 2N rows x M*s columns (FISTA_deep.m:66,75). */

@@ -19,7 +19,7 @@ SYMBOLS = [
     "qmri_abi_version", "qmri_create", "qmri_destroy", "qmri_last_error", "qmri_set_stream", "qmri_synchronize",
     "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
     "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
-    "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_set_dictionary", "qmri_dict_match",
+    "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_pnp_admm_batch", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_debug_conv_resident", "qmri_debug_knob",
     "qmri_onnx_read_unetres",
@@ -120,6 +120,7 @@ def lib() -> C.CDLL:
     L.qmri_denoiser_scheme.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.qmri_pnp_admm.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_pnp_admm_dev.argtypes = [vp, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
+    L.qmri_pnp_admm_batch.argtypes = [vp, i, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_lrtv.argtypes = [vp, vp, C.POINTER(LrtvParams), vp, C.POINTER(LrtvInfo)]
     L.qmri_prox_tv.argtypes = [vp, dp, i, i, C.c_double, C.c_double, i, dp, ip, dp]
     L.qmri_norm_tv.argtypes = [vp, dp, i, i, dp]

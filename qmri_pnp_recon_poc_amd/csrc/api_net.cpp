@@ -755,6 +755,45 @@ extern "C" int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_param
     return st;
 }
 
+// A slice stack from host buffers through ONE context (the MATLAB route for `PnP_ADMM_hip(Y, param)` with a measurement matrix): the slices
+// advance slices_per_launch at a time through qmri_pnp_admm_dev.  Plain and synchronous -- copy in, reconstruct, copy out per launch;
+// qmri_recon_batch is the pipelined, multi-device form of the same work.
+extern "C" int qmri_pnp_admm_batch(qmri_ctx* ctx, int nslices, int slices_per_launch, const void* y, const qmri_admm_params* p, const void* x0,
+                                   const void* gt, void* x_out, double* diag_out, int32_t* lsqr_iters_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    OpHost& o = ctx->op;
+    if (!o.ready) { qmri_set_error(ctx, "operator not set: call qmri_set_operator first"); return QMRI_ERR_STATE; }
+    if (!ctx->net.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, y && p && x_out && nslices >= 1 && slices_per_launch >= 1, "y / params / x_out must not be NULL, nslices and slices_per_launch >= 1");
+    const int spl = std::min(slices_per_launch, nslices);
+    QMRI_CHECK_ARG(ctx, spl <= o.maxB && spl <= ctx->net.maxB, "slices_per_launch exceeds max_batch of the operator or the denoiser");
+    const size_t n = (size_t)o.N * o.M * o.s, m = (size_t)o.m, it = (size_t)std::max(p->iters, 0);
+    double2 *dY = nullptr, *dX = nullptr, *dX0 = nullptr, *dGT = nullptr;
+    int st = QMRI_OK;
+    auto fail = [&](const char* what) { qmri_set_error(ctx, "%s failed in qmri_pnp_admm_batch", what); st = QMRI_ERR_HIP; };
+    do {
+        if (hipMalloc((void**)&dY, spl * m * sizeof(double2)) != hipSuccess || hipMalloc((void**)&dX, spl * n * sizeof(double2)) != hipSuccess ||
+            (x0 && hipMalloc((void**)&dX0, spl * n * sizeof(double2)) != hipSuccess) || (gt && hipMalloc((void**)&dGT, spl * n * sizeof(double2)) != hipSuccess)) {
+            qmri_set_error(ctx, "hipMalloc failed in qmri_pnp_admm_batch"); st = QMRI_ERR_NOMEM; break;
+        }
+        for (int s0 = 0; s0 < nslices && st == QMRI_OK; s0 += spl) {
+            const size_t cnt = (size_t)std::min(spl, nslices - s0);
+            if (hipMemcpyAsync(dY, (const double2*)y + (size_t)s0 * m, cnt * m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
+            if (x0 && hipMemcpyAsync(dX0, (const double2*)x0 + (size_t)s0 * n, cnt * n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
+            if (gt && hipMemcpyAsync(dGT, (const double2*)gt + (size_t)s0 * n, cnt * n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { fail("H2D copy"); break; }
+            st = qmri_pnp_admm_dev(ctx, (int)cnt, dY, p, dX0, dGT, dX, diag_out ? diag_out + (size_t)s0 * it * 2 : nullptr,
+                                   lsqr_iters_out ? lsqr_iters_out + (size_t)s0 * it : nullptr);
+            if (st != QMRI_OK) break;
+            if (hipMemcpyAsync((double2*)x_out + (size_t)s0 * n, dX, cnt * n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { fail("D2H copy"); break; }
+        }
+    } while (0);
+    void* ptrs[] = {dY, dX, dX0, dGT};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // dictionary
 // ---------------------------------------------------------------------------------------------------

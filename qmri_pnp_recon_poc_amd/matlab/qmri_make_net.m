@@ -26,5 +26,7 @@ else
     out_nc = arch.out_nc;
     qmri_mex('set_denoiser', single(weights(:)), out_nc + extra, out_nc, double(arch.nc(:).'), arch.nb, double(residual_noise), imsize(1), imsize(2));
 end
+% The handle takes H x W x C or H x W x C x N, as the reference's does (denoiseImage_PnP_ADMM.m:13-17): a batch larger than the current
+% plan makes the gateway re-plan for it (one-off cost of a weight re-pack), no argument needed here.
 net = @(x) qmri_mex('denoise', double(x), out_nc);
 end

@@ -6,15 +6,47 @@
 // mexAtExit.  Every libqmri status != 0 becomes mexErrMsgIdAndTxt('qmri:<code>', qmri_last_error(ctx)), which is how
 // the reference's plugins report errors (MATLAB exceptions, denoiseImage_PnP_ADMM.m:123-135).
 // The MATLAB wrappers in ../matlab give these commands the reference's own signatures.
+//
+// Batches and devices (round 5).  The reference's denoiser handle takes H x W x C x N batches (denoiseImage_PnP_ADMM.m:13-17) and north_star
+// shards a slice batch over the GPUs of a node.  The gateway therefore
+//   * keeps persistent copies of what defines the plans (V / frame_ptr / kidx, the denoiser's weights and shape, the dictionary), so that
+//   * a call that brings more slices than the current plan holds re-plans by itself: 'denoise' with a 4-D array of N > max_batch slices,
+//     'pnp_admm' with a measurement MATRIX (m x S) -- the plan then grows to min(S, 15) slices per launch;
+//   * 'device' selects the GPU of the single-context commands;
+//   * 'recon_batch' hands a whole slice stack to qmri_recon_batch: one worker (host thread + context) per entry of `devs`, slices_per_launch
+//     slices advanced together on each (k_conv6p, batched LSQR), x and the T1 / T2 / PD maps of every slice back.
+// tests/cpp/mex_mock.cpp is a small stand-in for the MATLAB runtime's C API under which this file is compiled, LINKED against libqmri.so and
+// driven command by command on the GPU box (tests/test_gpu_mex.py); with MATLAB's own mex.h nothing here changes.
 #include "mex.h"
 #include "qmri.h"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 static qmri_ctx* g_ctx = nullptr;
+static int g_device = 0;
 
-static void cleanup() { if (g_ctx) { qmri_destroy(g_ctx); g_ctx = nullptr; } }
+// what the current plans were made from (persistent mxArrays: they survive the call that brought them)
+struct OperatorSpec { mxArray* V = nullptr; mxArray* fp = nullptr; mxArray* kidx = nullptr; int N = 0, M = 0, max_batch = 0; };
+struct DenoiserSpec { mxArray* w = nullptr; qmri_net_desc d{}; int H = 0, W = 0, max_batch = 0; };
+struct DictSpec { mxArray* D = nullptr; mxArray* normD = nullptr; mxArray* lut = nullptr; };
+static OperatorSpec g_op;
+static DenoiserSpec g_net;
+static DictSpec g_dict;
+static const int DEFAULT_SLICES_PER_LAUNCH = 15;       // what a measurement matrix grows the plans to (the batched kernels' design point)
+
+static void drop(mxArray*& a) { if (a) { mxDestroyArray(a); a = nullptr; } }
+static mxArray* keep(const mxArray* a) { mxArray* c = mxDuplicateArray(a); mexMakeArrayPersistent(c); return c; }
+
+static void cleanup() {
+    if (g_ctx) { qmri_destroy(g_ctx); g_ctx = nullptr; }
+    drop(g_op.V); drop(g_op.fp); drop(g_op.kidx); g_op = OperatorSpec();
+    drop(g_net.w); g_net = DenoiserSpec();
+    drop(g_dict.D); drop(g_dict.normD); drop(g_dict.lut);
+}
 
 static void check(int st) {
     if (st == QMRI_OK) return;
@@ -25,10 +57,10 @@ static void check(int st) {
 
 static qmri_ctx* ctx() {
     if (!g_ctx) {
-        int st = qmri_create(0, &g_ctx);
+        int st = qmri_create(g_device, &g_ctx);
         if (st != QMRI_OK) mexErrMsgIdAndTxt("qmri:create", "%s", qmri_last_error(nullptr));
-        mexAtExit(cleanup);
-        mexLock();
+        static bool registered = false;
+        if (!registered) { mexAtExit(cleanup); mexLock(); registered = true; }
     }
     return g_ctx;
 }
@@ -38,40 +70,101 @@ static double scalar_field(const mxArray* s, const char* name, double dflt) {
     return f ? mxGetScalar(f) : dflt;
 }
 
+static void need(int nrhs, int n, const char* usage) {
+    if (nrhs < n) mexErrMsgIdAndTxt("qmri:usage", "%s", usage);
+}
+
+// (re-)make the plans from the kept specifications
+static void plan_operator(int max_batch) {
+    const int T = (int)mxGetM(g_op.V), s = (int)mxGetN(g_op.V);
+    check(qmri_set_operator(ctx(), g_op.N, g_op.M, s, T, mxGetDoubles(g_op.V), (const int32_t*)mxGetData(g_op.fp), (const int32_t*)mxGetData(g_op.kidx), max_batch));
+    g_op.max_batch = max_batch;
+}
+static void plan_denoiser(int max_batch) {
+    check(qmri_set_denoiser(ctx(), &g_net.d, (const float*)mxGetData(g_net.w), mxGetNumberOfElements(g_net.w) * 4, g_net.H, g_net.W, max_batch));
+    g_net.max_batch = max_batch;
+}
+static void plan_dictionary() {
+    check(qmri_set_dictionary(ctx(), (int)mxGetM(g_dict.D), (int)mxGetN(g_dict.D), (int)mxGetN(g_dict.lut), (const float*)mxGetData(g_dict.D),
+                              (const float*)mxGetData(g_dict.normD), (const float*)mxGetData(g_dict.lut)));
+}
+// a call brings B slices: grow the plans that hold fewer
+static void reserve(int B, bool op, bool net) {
+    if (op && g_op.V && B > g_op.max_batch) plan_operator(B);
+    if (net && g_net.w && B > g_net.max_batch) plan_denoiser(B);
+}
+
+static qmri_admm_params admm_params(const mxArray* P, bool want_diag) {
+    qmri_admm_params p;
+    p.gamma = scalar_field(P, "gamma", 0.05);
+    p.iters = (int)scalar_field(P, "iter", 100);
+    p.cg_tol = scalar_field(P, "cg_tol", 1e-4);
+    p.cg_maxit = 100;                                               // literal in PnP_ADMM.m:102
+    p.solver = (int)scalar_field(P, "solver", QMRI_SOLVER_LSQR);
+    p.denoiser_type = (int)scalar_field(P, "multi_level", 0);
+    p.noise_std = scalar_field(P, "noise_std", 0.01);
+    p.want_diag = want_diag ? 1 : 0;
+    return p;
+}
+
+static void set_denoiser_from(const mxArray* w, const qmri_net_desc& d, int H, int W, int max_batch) {
+    if (!mxIsSingle(w) || mxIsComplex(w)) mexErrMsgIdAndTxt("qmri:set_denoiser:type", "the weights must be a real single vector");
+    drop(g_net.w);
+    g_net.w = keep(w); g_net.d = d; g_net.H = H; g_net.W = W;
+    plan_denoiser(std::max(1, max_batch));
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("qmri:usage", "first argument must be a command string");
     char cmd[64];
     mxGetString(prhs[0], cmd, sizeof cmd);
     const std::string c(cmd);
 
-    if (c == "set_operator") {                       // qmri_mex('set_operator', N, M, V, frame_ptr(int32), kidx(int32))
-        const int N = (int)mxGetScalar(prhs[1]), M = (int)mxGetScalar(prhs[2]);
-        const mxArray* V = prhs[3];
-        const int T = (int)mxGetM(V), s = (int)mxGetN(V);
-        check(qmri_set_operator(ctx(), N, M, s, T, mxGetDoubles(V), (const int32_t*)mxGetData(prhs[4]),
-                                (const int32_t*)mxGetData(prhs[5]), 1));
-    } else if (c == "build_spiral" || c == "build_epi") {   // [frame_ptr, kidx] = qmri_mex('build_spiral', N, S, T)
+    if (c == "device") {                             // qmri_mex('device', d): the GPU of the single-context commands (plans are re-made on it)
+        need(nrhs, 2, "qmri_mex('device', d)");
+        const int d = (int)mxGetScalar(prhs[1]);
+        if (d != g_device || !g_ctx) {
+            if (g_ctx) { qmri_destroy(g_ctx); g_ctx = nullptr; }
+            g_device = d;
+            (void)ctx();
+            if (g_op.V) plan_operator(std::max(1, g_op.max_batch));
+            if (g_net.w) plan_denoiser(std::max(1, g_net.max_batch));
+            if (g_dict.D) plan_dictionary();
+        }
+        if (nlhs > 0) plhs[0] = mxCreateDoubleScalar((double)g_device);
+    } else if (c == "set_operator") {                // qmri_mex('set_operator', N, M, V, frame_ptr(int32), kidx(int32) [, max_batch])
+        need(nrhs, 6, "qmri_mex('set_operator', N, M, V, frame_ptr, kidx [, max_batch])");
+        if (!mxIsDouble(prhs[3]) || mxIsComplex(prhs[3])) mexErrMsgIdAndTxt("qmri:set_operator:type", "V must be a real double T x s matrix");
+        drop(g_op.V); drop(g_op.fp); drop(g_op.kidx);
+        g_op.N = (int)mxGetScalar(prhs[1]); g_op.M = (int)mxGetScalar(prhs[2]);
+        g_op.V = keep(prhs[3]); g_op.fp = keep(prhs[4]); g_op.kidx = keep(prhs[5]);
+        plan_operator(nrhs > 6 ? std::max(1, (int)mxGetScalar(prhs[6])) : 1);
+    } else if (c == "build_spiral" || c == "build_epi") {   // [frame_ptr, kidx] = qmri_mex('build_spiral', N, S, T)   (host integer code: no GPU needed)
+        need(nrhs, 4, "[frame_ptr, kidx] = qmri_mex('build_spiral', N, S, T) | qmri_mex('build_epi', N, M, pct, T)");
         const int N = (int)mxGetScalar(prhs[1]);
-        int m = 0;
+        int m = 0, st;
         if (c == "build_spiral") {
             const int S = (int)mxGetScalar(prhs[2]), T = (int)mxGetScalar(prhs[3]);
             plhs[0] = mxCreateNumericMatrix(T + 1, 1, mxINT32_CLASS, mxREAL);
             mxArray* k = mxCreateNumericMatrix((size_t)S * T, 1, mxINT32_CLASS, mxREAL);
-            check(qmri_build_spiral(ctx(), N, S, T, (int32_t*)mxGetData(plhs[0]), (int32_t*)mxGetData(k), S * T, &m));
+            st = qmri_build_spiral(nullptr, N, S, T, (int32_t*)mxGetData(plhs[0]), (int32_t*)mxGetData(k), S * T, &m);
             mxSetM(k, m);
             plhs[1] = k;
         } else {
+            need(nrhs, 5, "[frame_ptr, kidx] = qmri_mex('build_epi', N, M, pct, T)");
             const int M = (int)mxGetScalar(prhs[2]);
             const double pct = mxGetScalar(prhs[3]);
             const int T = (int)mxGetScalar(prhs[4]);
             const int cap = N * M * T;
             plhs[0] = mxCreateNumericMatrix(T + 1, 1, mxINT32_CLASS, mxREAL);
             mxArray* k = mxCreateNumericMatrix((size_t)cap, 1, mxINT32_CLASS, mxREAL);
-            check(qmri_build_epi(ctx(), N, M, pct, T, (int32_t*)mxGetData(plhs[0]), (int32_t*)mxGetData(k), cap, &m));
+            st = qmri_build_epi(nullptr, N, M, pct, T, (int32_t*)mxGetData(plhs[0]), (int32_t*)mxGetData(k), cap, &m);
             mxSetM(k, m);
             plhs[1] = k;
         }
+        if (st != QMRI_OK) mexErrMsgIdAndTxt("qmri:mask", "%s", qmri_last_error(nullptr));
     } else if (c == "forward") {                     // y = qmri_mex('forward', x)   (F.forward, main_recon_tsmis_FFT.m:228)
+        need(nrhs, 2, "y = qmri_mex('forward', x)");
         int m = 0;
         check(qmri_operator_m(ctx(), &m));
         plhs[0] = mxCreateDoubleMatrix(m, 1, mxCOMPLEX);
@@ -79,21 +172,23 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         check(qmri_forward(ctx(), cx ? (const void*)mxGetComplexDoubles(prhs[1]) : (const void*)mxGetDoubles(prhs[1]), cx,
                            mxGetComplexDoubles(plhs[0])));
     } else if (c == "adjoint") {                     // x = qmri_mex('adjoint', y, [N M s])   (F.adjoint, :229)
+        need(nrhs, 3, "x = qmri_mex('adjoint', y, [N M s])");
         const double* d = mxGetDoubles(prhs[2]);
         const mwSize dims[3] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2]};
         plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
         check(qmri_adjoint(ctx(), mxGetComplexDoubles(prhs[1]), mxGetComplexDoubles(plhs[0])));
-    } else if (c == "set_denoiser") {                // qmri_mex('set_denoiser', weights(single), in_nc, out_nc, nc(1x4), nb, residual_noise, H, W)
+    } else if (c == "set_denoiser") {                // qmri_mex('set_denoiser', weights(single), in_nc, out_nc, nc(1x4), nb, residual_noise, H, W [, max_batch])
+        need(nrhs, 9, "qmri_mex('set_denoiser', weights, in_nc, out_nc, nc, nb, residual_noise, H, W [, max_batch])");
         qmri_net_desc d;
         d.arch = QMRI_ARCH_UNETRES;
         d.in_nc = (int)mxGetScalar(prhs[2]); d.out_nc = (int)mxGetScalar(prhs[3]);
         const double* nc = mxGetDoubles(prhs[4]);
         for (int i = 0; i < 4; ++i) d.nc[i] = (int)nc[i];
         d.nb = (int)mxGetScalar(prhs[5]); d.residual_noise = (int)mxGetScalar(prhs[6]);
-        check(qmri_set_denoiser(ctx(), &d, (const float*)mxGetData(prhs[1]), mxGetNumberOfElements(prhs[1]) * 4,
-                                (int)mxGetScalar(prhs[7]), (int)mxGetScalar(prhs[8]), 1));
-    } else if (c == "load_onnx") {                   // [in_nc, out_nc] = qmri_mex('load_onnx', denoiser_path, residual_noise, H, W)
+        set_denoiser_from(prhs[1], d, (int)mxGetScalar(prhs[7]), (int)mxGetScalar(prhs[8]), nrhs > 9 ? (int)mxGetScalar(prhs[9]) : 1);
+    } else if (c == "load_onnx") {                   // [in_nc, out_nc] = qmri_mex('load_onnx', denoiser_path, residual_noise, H, W [, max_batch])
         // the weight-loading half of `Net = importONNXNetwork(denoiser_path, ...)` (main_recon_tsmis_FFT.m:138) + set_denoiser
+        need(nrhs, 5, "[in_nc, out_nc] = qmri_mex('load_onnx', denoiser_path, residual_noise, H, W [, max_batch])");
         char path[4096];
         if (mxGetString(prhs[1], path, sizeof path)) mexErrMsgIdAndTxt("qmri:usage", "denoiser_path must be a char vector");
         qmri_net_desc d;
@@ -102,42 +197,97 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         mxArray* w = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
         if (qmri_onnx_read_unetres(path, &d, (float*)mxGetData(w), n, &n) != QMRI_OK) mexErrMsgIdAndTxt("qmri:onnx", "%s", qmri_last_error(nullptr));
         d.residual_noise = (int)mxGetScalar(prhs[2]);
-        check(qmri_set_denoiser(ctx(), &d, (const float*)mxGetData(w), n * 4, (int)mxGetScalar(prhs[3]), (int)mxGetScalar(prhs[4]), 1));
+        set_denoiser_from(w, d, (int)mxGetScalar(prhs[3]), (int)mxGetScalar(prhs[4]), nrhs > 5 ? (int)mxGetScalar(prhs[5]) : 1);
         mxDestroyArray(w);
         plhs[0] = mxCreateDoubleScalar((double)d.in_nc);
         if (nlhs > 1) plhs[1] = mxCreateDoubleScalar((double)d.out_nc);
-    } else if (c == "denoise") {                     // I = qmri_mex('denoise', A, out_nc)   (param.net, :164)
+    } else if (c == "denoise") {                     // I = qmri_mex('denoise', A, out_nc)   (param.net, :164): A is H x W x C or H x W x C x N (denoiseImage_PnP_ADMM.m:13-17)
+        need(nrhs, 3, "I = qmri_mex('denoise', A, out_nc)");
         const mwSize* dm = mxGetDimensions(prhs[1]);
         const int nd = (int)mxGetNumberOfDimensions(prhs[1]);
         if (mxIsComplex(prhs[1]) || !mxIsDouble(prhs[1]) || nd > 4)
             mexErrMsgIdAndTxt("images:denoiseImage:invalidImageFormat", "A must be a real double H x W x C (x N) array");
         const int H = (int)dm[0], W = (int)dm[1], C = nd > 2 ? (int)dm[2] : 1, B = nd > 3 ? (int)dm[3] : 1;
+        reserve(B, false, true);                                    // a batch larger than the plan: re-planned, as the reference's handle takes any N
         const mwSize od[4] = {(mwSize)H, (mwSize)W, (mwSize)mxGetScalar(prhs[2]), (mwSize)B};
-        plhs[0] = mxCreateNumericArray(4, od, mxDOUBLE_CLASS, mxREAL);
+        plhs[0] = mxCreateNumericArray(B > 1 ? 4 : 3, od, mxDOUBLE_CLASS, mxREAL);
         check(qmri_denoise(ctx(), mxGetDoubles(prhs[1]), H, W, C, B, mxGetDoubles(plhs[0])));
     } else if (c == "pnp_admm") {                    // [x, diag, lsqr_iters] = qmri_mex('pnp_admm', y, param_struct, X0, gt, [N M s])
-        const mxArray* P = prhs[2];
-        qmri_admm_params p;
-        p.gamma = scalar_field(P, "gamma", 0.05);
-        p.iters = (int)scalar_field(P, "iter", 100);
-        p.cg_tol = scalar_field(P, "cg_tol", 1e-4);
-        p.cg_maxit = 100;                                           // literal in PnP_ADMM.m:102
-        p.solver = (int)scalar_field(P, "solver", QMRI_SOLVER_LSQR);
-        p.denoiser_type = (int)scalar_field(P, "multi_level", 0);
-        p.noise_std = scalar_field(P, "noise_std", 0.01);
-        p.want_diag = nlhs > 1;
+        // y: m x 1 -> x is N x M x s;  y: m x S (a slice stack) -> x is N x M x s x S, diag 2 x iter x S, lsqr_iters iter x S: the slices advance together
+        // through the batched kernels, slices_per_launch = min(S, 15) at a time, on the current device (X0 / gt: N x M x s x S or empty)
+        need(nrhs, 6, "[x, diag, lsqr_iters] = qmri_mex('pnp_admm', y, param, X0, gt, [N M s])");
+        const qmri_admm_params p = admm_params(prhs[2], nlhs > 1);
         const double* d = mxGetDoubles(prhs[5]);
-        const mwSize dims[3] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2]};
-        plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
-        mxArray* diag = mxCreateDoubleMatrix(2, p.iters > 0 ? p.iters : 1, mxREAL);
-        mxArray* li = mxCreateNumericMatrix(p.iters > 0 ? p.iters : 1, 1, mxINT32_CLASS, mxREAL);
-        const void* x0 = mxIsEmpty(prhs[3]) ? nullptr : (const void*)mxGetComplexDoubles(prhs[3]);
-        const void* gt = mxIsEmpty(prhs[4]) ? nullptr : (const void*)mxGetComplexDoubles(prhs[4]);
-        check(qmri_pnp_admm(ctx(), mxGetComplexDoubles(prhs[1]), &p, x0, gt, mxGetComplexDoubles(plhs[0]),
-                            p.want_diag ? mxGetDoubles(diag) : nullptr, (int32_t*)mxGetData(li)));
+        const size_t S = mxGetN(prhs[1]), m = mxGetM(prhs[1]), n = (size_t)d[0] * (size_t)d[1] * (size_t)d[2];
+        const int it = p.iters > 0 ? p.iters : 1;
+        const mwSize dims[4] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2], (mwSize)S};
+        plhs[0] = mxCreateNumericArray(S > 1 ? 4 : 3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
+        const mwSize ddims[3] = {2, (mwSize)it, (mwSize)S};
+        mxArray* diag = mxCreateNumericArray(S > 1 ? 3 : 2, ddims, mxDOUBLE_CLASS, mxREAL);
+        mxArray* li = mxCreateNumericMatrix(it, S, mxINT32_CLASS, mxREAL);
+        const mxComplexDouble* y = mxGetComplexDoubles(prhs[1]);
+        const mxComplexDouble* x0 = mxIsEmpty(prhs[3]) ? nullptr : mxGetComplexDoubles(prhs[3]);
+        const mxComplexDouble* gt = mxIsEmpty(prhs[4]) ? nullptr : mxGetComplexDoubles(prhs[4]);
+        if (x0 && mxGetNumberOfElements(prhs[3]) != n * S) mexErrMsgIdAndTxt("qmri:pnp_admm:size", "X0 must hold N x M x s values per slice");
+        if (gt && mxGetNumberOfElements(prhs[4]) != n * S) mexErrMsgIdAndTxt("qmri:pnp_admm:size", "gt_tsmi must hold N x M x s values per slice");
+        if (S == 1) {
+            check(qmri_pnp_admm(ctx(), y, &p, x0, gt, mxGetComplexDoubles(plhs[0]), p.want_diag ? mxGetDoubles(diag) : nullptr, (int32_t*)mxGetData(li)));
+        } else {
+            // several slices on this device: the plans grow to the launch size, then qmri_pnp_admm_batch walks the stack
+            const int spl = (int)std::min<size_t>(S, DEFAULT_SLICES_PER_LAUNCH);
+            reserve(spl, true, true);
+            check(qmri_pnp_admm_batch(ctx(), (int)S, spl, y, &p, x0, gt, mxGetComplexDoubles(plhs[0]), p.want_diag ? mxGetDoubles(diag) : nullptr,
+                                      (int32_t*)mxGetData(li)));
+        }
+        (void)m;
         if (nlhs > 1) plhs[1] = diag; else mxDestroyArray(diag);
         if (nlhs > 2) plhs[2] = li; else mxDestroyArray(li);
+    } else if (c == "recon_batch") {                 // [X, qmap, pd] = qmri_mex('recon_batch', Y(m x S), param_struct, devs, slices_per_launch, [N M s])
+        // north_star's batch path: S independent slices sharded over the GPUs in `devs` (one worker = host thread + context per entry; an id may
+        // repeat), slices_per_launch advanced together on each; 100 PnP-ADMM iterations + dictionary match per slice (the match only when a dictionary
+        // is set and maps are asked for).  Uses the operator / denoiser / dictionary given to 'set_operator' / 'set_denoiser' / 'set_dictionary'.
+        need(nrhs, 6, "[X, qmap, pd] = qmri_mex('recon_batch', Y, param, devs, slices_per_launch, [N M s])");
+        if (!g_op.V || !g_net.w) mexErrMsgIdAndTxt("qmri:recon_batch:state", "set_operator and set_denoiser (or load_onnx) must come first");
+        const size_t S = mxGetN(prhs[1]);
+        const double* d = mxGetDoubles(prhs[5]);
+        const size_t npix = (size_t)d[0] * (size_t)d[1];
+        std::vector<int> devs(mxGetNumberOfElements(prhs[3]));
+        for (size_t i = 0; i < devs.size(); ++i) devs[i] = (int)mxGetDoubles(prhs[3])[i];
+        if (devs.empty()) mexErrMsgIdAndTxt("qmri:recon_batch:devs", "devs must name at least one device");
+        const bool maps = nlhs > 1 && g_dict.D;
+        qmri_problem pb;
+        std::memset(&pb, 0, sizeof pb);
+        pb.N = g_op.N; pb.M = g_op.M; pb.T = (int)mxGetM(g_op.V); pb.s = (int)mxGetN(g_op.V);
+        pb.V = mxGetDoubles(g_op.V); pb.frame_ptr = (const int32_t*)mxGetData(g_op.fp); pb.kidx = (const int32_t*)mxGetData(g_op.kidx);
+        pb.net = &g_net.d; pb.weights = (const float*)mxGetData(g_net.w); pb.weights_nbytes = mxGetNumberOfElements(g_net.w) * 4;
+        if (maps) {
+            pb.K = (int)mxGetM(g_dict.D); pb.Q = (int)mxGetN(g_dict.lut);
+            pb.D = (const float*)mxGetData(g_dict.D); pb.normD = (const float*)mxGetData(g_dict.normD); pb.lut = (const float*)mxGetData(g_dict.lut);
+        }
+        pb.admm = admm_params(prhs[2], false);
+        pb.slices_per_launch = std::max(1, (int)mxGetScalar(prhs[4]));
+        const mwSize xd[4] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2], (mwSize)S};
+        plhs[0] = mxCreateNumericArray(4, xd, mxDOUBLE_CLASS, mxCOMPLEX);
+        mxArray *qm = nullptr, *pd = nullptr;
+        if (maps) {
+            const mwSize qd[4] = {(mwSize)d[0], (mwSize)d[1], (mwSize)pb.Q, (mwSize)S};
+            const mwSize pdd[3] = {(mwSize)d[0], (mwSize)d[1], (mwSize)S};
+            qm = mxCreateNumericArray(4, qd, mxSINGLE_CLASS, mxREAL);
+            pd = mxCreateNumericArray(3, pdd, mxSINGLE_CLASS, mxCOMPLEX);
+        }
+        (void)npix;
+        char err[1024] = "";
+        const int st = qmri_recon_batch((int)devs.size(), devs.data(), (int)S, &pb, mxGetComplexDoubles(prhs[1]), mxGetComplexDoubles(plhs[0]),
+                                        qm ? (float*)mxGetData(qm) : nullptr, pd ? (float*)mxGetData(pd) : nullptr, err, sizeof err);
+        if (st != QMRI_OK) {
+            char id[32];
+            snprintf(id, sizeof id, "qmri:err%d", -st);
+            mexErrMsgIdAndTxt(id, "%s", err);
+        }
+        if (nlhs > 1) plhs[1] = qm ? qm : mxCreateNumericMatrix(0, 0, mxSINGLE_CLASS, mxREAL);
+        if (nlhs > 2) plhs[2] = pd ? pd : mxCreateNumericMatrix(0, 0, mxSINGLE_CLASS, mxCOMPLEX); else if (pd) mxDestroyArray(pd);
     } else if (c == "lrtv") {                        // [x, info] = qmri_mex('lrtv', y, param_struct, [N M s])   (FISTA_deep, main_recon_tsmis_FFT.m:273-282)
+        need(nrhs, 4, "[x, info] = qmri_mex('lrtv', y, param, [N M s])");
         const mxArray* P = prhs[2];
         qmri_lrtv_params p;
         p.K = scalar_field(P, "K", 4e-5);
@@ -165,9 +315,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                 mexErrMsgIdAndTxt("qmri:set_dictionary:type", "D, normD and lut must be real single arrays (argument %d is not)", a);
         if (mxGetNumberOfElements(prhs[2]) != mxGetM(prhs[1]) || mxGetM(prhs[3]) != mxGetM(prhs[1]))
             mexErrMsgIdAndTxt("qmri:set_dictionary:size", "normD must have K elements and lut K rows (K = rows of D)");
-        check(qmri_set_dictionary(ctx(), (int)mxGetM(prhs[1]), (int)mxGetN(prhs[1]), (int)mxGetN(prhs[3]),
-                                  (const float*)mxGetData(prhs[1]), (const float*)mxGetData(prhs[2]), (const float*)mxGetData(prhs[3])));
+        drop(g_dict.D); drop(g_dict.normD); drop(g_dict.lut);
+        g_dict.D = keep(prhs[1]); g_dict.normD = keep(prhs[2]); g_dict.lut = keep(prhs[3]);
+        plan_dictionary();
     } else if (c == "dict_match") {                  // [qmap, pd, mt, dm, xfit] = qmri_mex('dict_match', X(Npix x s complex double), Q)
+        need(nrhs, 3, "[qmap, pd, mt, dm, xfit] = qmri_mex('dict_match', X, Q)");
         const int npix = (int)mxGetM(prhs[1]), Q = (int)mxGetScalar(prhs[2]);
         mxArray* xfit = (nlhs > 4) ? mxCreateNumericMatrix(npix, mxGetN(prhs[1]), mxSINGLE_CLASS, mxCOMPLEX) : nullptr;   // out.Xfit, mrf_dtm_cpu.m:129-134
         plhs[0] = mxCreateNumericMatrix(npix, Q, mxSINGLE_CLASS, mxREAL);

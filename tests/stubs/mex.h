@@ -3,9 +3,10 @@
  *
  * The build image has no MATLAB (no mex.h), so qmri_pnp_recon_poc_amd/mex/qmri_mex.cpp could never go through a compiler.
  * This file declares -- from MathWorks' published C Matrix API / MEX API documentation (R2018a interleaved-complex API) -- the
- * handful of types and functions the shim uses, so that tests/test_host_logic.py::test_mex_shim_compiles_against_stub_header can
- * run `g++ -fsyntax-only` on it: a SYNTAX AND TYPE CHECK of our own gateway code, nothing more.  Nothing here is implemented
- * or linked; a real build uses MATLAB's own mex.h (`mex -R2018a`).
+ * handful of types and functions the shim uses, so that (1) tests/test_host_logic.py::test_mex_shim_compiles_against_stub_header can
+ * run `g++ -fsyntax-only` on it, and (2) tests/cpp/mex_mock.cpp can IMPLEMENT them as a small in-process stand-in for the MATLAB runtime,
+ * under which the gateway is compiled, linked against libqmri.so and driven command by command (tests/test_mex_mock.py on the CPU,
+ * tests/test_gpu_mex.py on the GPU box).  Test infrastructure for OUR gateway only; a real build uses MATLAB's own mex.h (`mex -R2018a`).
  */
 #ifndef QMRI_TEST_STUB_MEX_H
 #define QMRI_TEST_STUB_MEX_H
@@ -36,6 +37,8 @@ mxArray* mxCreateNumericArray(mwSize ndim, const mwSize* dims, mxClassID classid
 mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID classid, mxComplexity flag);
 mxArray* mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char** fieldnames);
 void mxDestroyArray(mxArray* pm);
+mxArray* mxDuplicateArray(const mxArray* in);
+void mexMakeArrayPersistent(mxArray* pm);
 mxComplexDouble* mxGetComplexDoubles(const mxArray* pa);
 mxDouble* mxGetDoubles(const mxArray* pa);
 void* mxGetData(const mxArray* pm);

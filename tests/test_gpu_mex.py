@@ -1,0 +1,119 @@
+"""GPU: the MATLAB gateway (mex/qmri_mex.cpp) driven command by command under the mock MEX runtime (tests/mexmock.py) -- the call sequences
+of matlab/qmri_make_F.m, qmri_make_net.m, PnP_ADMM_hip.m, mrf_dtm_hip.m and qmri_recon_batch.m, with MATLAB's array layouts -- against the
+Python host side over the same C ABI (bit for bit) and the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import rel_err  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mex():
+    import mexmock
+    yield mexmock
+    mexmock.mex_exit()
+
+
+def _plan(mex, dic, fp, k, w, N, s, nc, nb, multi=0):
+    """qmri_make_F + qmri_make_net + mrf_dtm_hip(dict, [], []) as the .m wrappers issue them."""
+    mex.qmri_mex("set_operator", float(N), float(N), np.asarray(dic["V"], np.float64), fp.astype(np.int32), k.astype(np.int32))
+    mex.qmri_mex("set_denoiser", w.astype(np.float32), float(s + multi), float(s), np.array([nc], np.float64), float(nb), 0.0, float(N), float(N))
+    mex.qmri_mex("set_dictionary", np.asarray(dic["D"], np.float32), np.asarray(dic["normD"], np.float32), np.asarray(dic["lut"], np.float32))
+
+
+def test_single_slice_commands_equal_the_python_host_side(mex, engine_mod, oracle, synth):
+    """F.forward / F.adjoint / param.net / PnP_ADMM_hip / mrf_dtm_hip for one slice through the gateway == Engine (same C ABI) bit for bit."""
+    E = engine_mod
+    N, T, s, S = 32, 24, 6, 120
+    nc, nb = (8, 16, 16, 32), 2
+    dic = synth.make_dictionary(T=T, n_t1=24, n_t2=16, s=s)
+    fp, k = mex.qmri_mex("build_spiral", float(N), float(S), float(T), nargout=2)
+    fp, k = fp.ravel(), k.ravel()
+    w = synth.structured_weights(in_nc=s, out_nc=s, nc=nc, nb=nb, seed=3, eps=0.05)
+    _plan(mex, dic, fp, k, w, N, s, nc, nb)
+    e = E.Engine(0)
+    e.set_operator(N, N, dic["V"], fp, k)
+    e.set_denoiser(w, N, N, in_nc=s, out_nc=s, nc=nc, nb=nb)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=0), dic)
+    y = mex.qmri_mex("forward", np.asarray(X0, np.float64), nargout=1)
+    assert y.shape == (e.m, 1) and np.array_equal(y.ravel(), e.forward(X0))
+    y = synth.awgn_measured(y.ravel(), 30.0, seed=0)
+    xa = mex.qmri_mex("adjoint", y.astype(np.complex128), np.array([N, N, s], np.float64), nargout=1)
+    assert xa.shape == (N, N, s) and np.array_equal(xa, e.adjoint(y))
+    img = np.random.default_rng(1).random((N, N, s))
+    assert np.array_equal(mex.qmri_mex("denoise", img, float(s), nargout=1), e.denoise(img))
+    prm = {"gamma": 0.05, "iter": 5, "cg_tol": 1e-4, "multi_level": 0, "noise_std": 0.01}
+    x, diag, li = mex.qmri_mex("pnp_admm", y.astype(np.complex128), prm, np.zeros((0, 0)), np.asarray(X0, np.complex128), np.array([N, N, s], np.float64), nargout=3)
+    xe, de, le = e.pnp_admm(y, iters=5, gt=X0, want_diag=True)
+    assert x.shape == (N, N, s) and np.array_equal(x, xe) and np.array_equal(li.ravel(), le) and np.array_equal(diag.T, de)
+    qmap, pd, mt, dm = mex.qmri_mex("dict_match", x.reshape((N * N, s), order="F"), 2.0, nargout=4)
+    me = e.dict_match(x)
+    assert np.array_equal(qmap.reshape((N, N, 2), order="F"), me["qmap"]) and np.array_equal(dm.ravel().reshape((N, N), order="F"), me["dm"])
+    assert np.array_equal(pd.ravel().reshape((N, N), order="F"), me["pd"])
+    e.close()
+
+
+def test_batches_through_the_gateway(mex, engine_mod, oracle, synth):
+    """The reference's handle takes H x W x C x N batches (denoiseImage_PnP_ADMM.m:13-17): `param.net(x4d)` with N = 3 on a plan made for one
+    slice re-plans by itself and equals three single calls; `PnP_ADMM_hip(Y, param)` with a measurement matrix (m x 4) advances the slices
+    together and equals four single-slice calls (the batched kernels are bit-identical per slice); LSQR counts per slice come back iter x S."""
+    E = engine_mod
+    N, T, s, S = 32, 24, 6, 120
+    nc, nb = (8, 16, 16, 32), 2
+    dic = synth.make_dictionary(T=T, n_t1=24, n_t2=16, s=s)
+    fp, k = E.build_spiral(N, S, T)
+    w = synth.structured_weights(in_nc=s, out_nc=s, nc=nc, nb=nb, seed=3, eps=0.05)
+    _plan(mex, dic, fp, k, w, N, s, nc, nb)
+    imgs = np.random.default_rng(2).random((N, N, s, 3))
+    out4 = mex.qmri_mex("denoise", imgs, float(s), nargout=1)
+    assert out4.shape == (N, N, s, 3)
+    for b in range(3):
+        assert np.array_equal(out4[..., b], mex.qmri_mex("denoise", imgs[..., b], float(s), nargout=1))
+    op = oracle.Operator(N, N, dic["V"], fp, k)
+    ys = np.stack([synth.awgn_measured(op.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=sl), dic)), 30.0, seed=sl) for sl in range(4)], axis=1)
+    prm = {"gamma": 0.05, "iter": 4, "cg_tol": 1e-4, "multi_level": 0, "noise_std": 0.01}
+    dims = np.array([N, N, s], np.float64)
+    X, diag, li = mex.qmri_mex("pnp_admm", ys.astype(np.complex128), prm, np.zeros((0, 0)), np.zeros((0, 0)), dims, nargout=3)
+    assert X.shape == (N, N, s, 4) and li.shape == (4, 4) and diag.shape == (2, 4, 4)
+    net = oracle.Net(w, in_nc=s, out_nc=s, nc=nc, nb=nb)
+    for sl in range(4):
+        x1, _, l1 = mex.qmri_mex("pnp_admm", ys[:, sl].astype(np.complex128), prm, np.zeros((0, 0)), np.zeros((0, 0)), dims, nargout=3)
+        assert np.array_equal(li[:, sl], l1.ravel()) and rel_err(X[..., sl], x1) < 1e-12
+        xo, _, lo = oracle.pnp_admm(op, net, ys[:, sl], iters=4)
+        assert rel_err(X[..., sl], xo) < 1e-4 and np.array_equal(li[:, sl], lo)
+
+
+def test_recon_batch_through_the_gateway_30_slices_two_workers(mex, engine_mod, oracle, synth, case224):
+    """north_star's batch path from the reference's side: `[X, qmap, pd] = qmri_recon_batch(Y, param, [0 0], 8)` -- 30 cut3 slices
+    at 224 x 224, two workers (one per GPU on a node, both on device 0 here), 8 slices per launch, 2 ADMM iterations + dictionary match -- through the
+    GATEWAY's own code path (persistent copies of V / masks / weights / dictionary -> qmri_problem -> qmri_recon_batch) must equal
+    batch.recon_batch (the Python host side over the same C ABI) BIT FOR BIT: x, T1 / T2 maps and PD of every slice."""
+    from qmri_pnp_recon_poc_amd import batch
+    dic, op = case224["dic"], case224["op"]
+    fp, k = case224["fp"], case224["k"]
+    w = synth.structured_weights(seed=2, eps=0.3)
+    nsl = 30
+    ys = np.stack([synth.awgn_measured(op.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(224, seed=100 + sl), dic)), 30.0, seed=100 + sl)
+                   for sl in range(nsl)])
+    _plan(mex, dic, fp, k, w, 224, 10, (64, 128, 256, 512), 4)
+    assert mex.qmri_mex("device", 0.0, nargout=1) == 0
+    prm = {"gamma": 0.05, "iter": 2, "cg_tol": 1e-4, "multi_level": 0, "noise_std": 0.01}
+    X, qmap, pd = mex.qmri_mex("recon_batch", np.ascontiguousarray(ys.T).astype(np.complex128), prm, np.array([0.0, 0.0]), 8.0, np.array([224.0, 224.0, 10.0]), nargout=3)
+    assert X.shape == (224, 224, 10, nsl) and qmap.shape == (224, 224, 2, nsl) and pd.shape == (224, 224, nsl)
+    res = batch.recon_batch([0, 0], ys, N=224, M=224, V=dic["V"], frame_ptr=fp, kidx=k, weights=w, dictionary=dic, iters=2, slices_per_launch=8)
+    for sl in range(nsl):
+        assert np.array_equal(X[..., sl], res["X"][sl]), sl
+        assert np.array_equal(qmap[..., sl], res["qmap"][sl]) and np.array_equal(pd[..., sl], res["pd"][sl]), sl
+    # without output arguments for the maps no match runs, and an unknown device is a MATLAB error carrying the library's message
+    X1 = mex.qmri_mex("recon_batch", np.ascontiguousarray(ys[:2].T).astype(np.complex128), prm, np.array([0.0]), 2.0, np.array([224.0, 224.0, 10.0]), nargout=1)
+    assert np.array_equal(X1[..., 1], res["X"][1])
+    with pytest.raises(mex.MexError) as e:
+        mex.qmri_mex("recon_batch", np.ascontiguousarray(ys[:2].T).astype(np.complex128), prm, np.array([99.0]), 2.0, np.array([224.0, 224.0, 10.0]), nargout=1)
+    assert "device" in e.value.msg

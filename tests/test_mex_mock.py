@@ -1,0 +1,50 @@
+"""CPU: the MATLAB gateway (mex/qmri_mex.cpp) compiled, linked against libqmri.so and RUN under the mock MEX runtime (tests/cpp/mex_mock.cpp,
+tests/mexmock.py) -- the commands that need no GPU: the mask builders, usage errors, and the loud failure of everything else without a device."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import mexmock  # noqa: E402
+from mexmock import MexError, qmri_mex  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_gateway_links_against_libqmri_and_builds_the_masks_of_the_reference():
+    """`[fp, k] = qmri_mex('build_spiral', N, S, T)` / `('build_epi', N, M, pct, T)` run on the host (no context): they must equal the fixtures
+    of the independent restatement of setup_subsampling_*.m (tests/golden/matlab_rows_*.npz) bit for bit, as int32 column vectors."""
+    for name, cmd, size in (("spiral", "build_spiral", 64), ("spiral", "build_spiral", 224), ("epi", "build_epi", 32), ("epi", "build_epi", 224)):
+        g = np.load(os.path.join(GOLDEN, f"matlab_rows_{name}_{size}.npz"))
+        N, T, prm = int(g["N"]), int(g["T"]), float(g["param"])        # (param: S of the spiral / the EPI sampling rate)
+        args = (N, prm, T) if name == "spiral" else (N, N, prm, T)
+        fp, k = qmri_mex(cmd, *[float(a) for a in args], nargout=2)
+        assert fp.dtype == np.int32 and k.dtype == np.int32 and fp.shape == (T + 1, 1) and k.shape == (int(g["frame_ptr"][-1]), 1)
+        assert np.array_equal(fp.ravel(), g["frame_ptr"]) and np.array_equal(k.ravel(), g["kidx"])
+
+
+def test_gateway_usage_errors_are_matlab_errors():
+    with pytest.raises(MexError) as e:
+        qmri_mex("no_such_command")
+    assert e.value.id == "qmri:usage" and "no_such_command" in e.value.msg
+    with pytest.raises(MexError) as e:
+        qmri_mex("build_spiral", 64.0)                              # too few arguments: a usage error, not a crash
+    assert e.value.id == "qmri:usage"
+    with pytest.raises(MexError) as e:
+        qmri_mex("recon_batch", np.zeros((4, 2), np.complex128), {"iter": 1}, np.array([0.0]), 1.0, np.array([2.0, 2.0, 1.0]), nargout=1)
+    assert e.value.id == "qmri:recon_batch:state"                  # nothing planned yet
+    with pytest.raises(MexError) as e:
+        qmri_mex("set_dictionary", np.zeros((8, 2), np.complex64), np.ones(8, np.float32), np.ones((8, 2), np.float32))
+    assert e.value.id == "qmri:set_dictionary:type"                # complex atoms are refused on this route too
+
+
+def test_gateway_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(MexError) as e:
+        qmri_mex("forward", np.zeros((8, 8, 2)), nargout=1)
+    assert e.value.id == "qmri:create" and "no CPU fallback" in e.value.msg
+    mexmock.mex_exit()
