@@ -355,41 +355,60 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         // Units of similar sample count, about one per CU.  The one-launch iteration (k_ks_persist) is paced by its slowest workgroup, and two
         // workgroups that share a CU are the slow ones: where the caps allow, the cut is repeated with fewer, larger units until at most
         // 250 result (263 at the headline operator with the first cut: 7 CUs held two).
-        int want = 256;
-        for (int attempt = 0; attempt < 8; ++attempt, want -= 8) {
-        bslot.clear(); gptr.clear(); grp.clear();
-        const int target = std::max(1, (m + want - 1) / want);
-        int j = 0;
-        while (j < ns) {
-            const int first = j, e0 = sptr[j];
-            int ngr = 0;
-            bslot.push_back(first);
-            gptr.push_back((int32_t)grp.size());
-            while (j < ns) {
-                const int cnt = sptr[j + 1] - sptr[j], gj = (cnt + DC_GCAP - 1) / DC_GCAP;
-                if (cnt > KS_ECAP || cnt > 65535) { qmri_set_error(ctx, "a k location is sampled %d times; at most %d are supported", cnt, KS_ECAP); return QMRI_ERR_UNSUPPORTED; }
-                const int have = sptr[j] - e0;
-                if (j > first && (j - first >= KS_SCAP || have + cnt > KS_ECAP || ngr + gj > KS_GCAPB || have + cnt / 2 > target)) break;
-                sgrp[j] = (int32_t)grp.size();
-                for (int e = sptr[j]; e < sptr[j + 1]; e += DC_GCAP) {
-                    KsGroup g;
-                    g.ls = (uint16_t)(j - first); g.b = (uint16_t)(e - e0); g.e = (uint16_t)(std::min(e + DC_GCAP, sptr[j + 1]) - e0); g.pad = 0;
-                    grp.push_back(g);
+        // Round 5: three unit shapes (KS_CAPS).  A mask that samples every k a few times (EPI: 784 units of the first shape) or few k very often
+        // (cut0: 604) gets the shape under which <= 250 units result, so that a single slice runs the one-launch iteration too.  Plans for slice
+        // batches keep the first shape: their grids (units x slices) never fit the chip at once, and small units fill it more evenly.
+        auto cut = [&](const KsCapsHost& cp) -> int {
+            int want = 256;
+            for (int attempt = 0; attempt < 8; ++attempt, want -= 8) {
+                bslot.clear(); gptr.clear(); grp.clear();
+                const int target = std::max(1, (m + want - 1) / want);
+                int j = 0;
+                while (j < ns) {
+                    const int first = j, e0 = sptr[j];
+                    int ngr = 0;
+                    bslot.push_back(first);
+                    gptr.push_back((int32_t)grp.size());
+                    while (j < ns) {
+                        const int cnt = sptr[j + 1] - sptr[j], gj = (cnt + DC_GCAP - 1) / DC_GCAP;
+                        if (cnt > cp.ecap || cnt > 65535) return -cnt;
+                        const int have = sptr[j] - e0;
+                        if (j > first && (j - first >= cp.scap || have + cnt > cp.ecap || ngr + gj > cp.gcapb || have + cnt / 2 > target)) break;
+                        sgrp[j] = (int32_t)grp.size();
+                        for (int e = sptr[j]; e < sptr[j + 1]; e += DC_GCAP) {
+                            KsGroup g;
+                            g.ls = (uint16_t)(j - first); g.b = (uint16_t)(e - e0); g.e = (uint16_t)(std::min(e + DC_GCAP, sptr[j + 1]) - e0); g.pad = 0;
+                            grp.push_back(g);
+                        }
+                        for (int e = sptr[j]; e < sptr[j + 1]; ++e) { es[e].ls = (uint16_t)(j - first); es[e].t = o.ent_h[e].t; }
+                        ngr += gj;
+                        ++j;
+                    }
                 }
-                for (int e = sptr[j]; e < sptr[j + 1]; ++e) { es[e].ls = (uint16_t)(j - first); es[e].t = o.ent_h[e].t; }
-                ngr += gj;
-                ++j;
+                if ((int)bslot.size() <= 250 || (int)bslot.size() > 320) break;     // (> 320: an operator with many more units than CUs; nothing to gain)
             }
+            return (int)bslot.size();
+        };
+        ks.vcap = ((T * s + 10 + 15) / 16) * 16;       // (+10: the channel loops of the kernels are unrolled to 10)
+        ks.caps = 0;
+        int nunits = cut(KS_CAPS[0]);
+        if (max_batch == 1 && s == 10 && (nunits > 320 || nunits < 0)) {
+            for (int c = 1; c <= 2; ++c) {
+                bool fits = false;
+                QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, c, &fits));
+                if (!fits) continue;
+                const int nu = cut(KS_CAPS[c]);
+                if (nu > 0 && nu <= 250) { ks.caps = c; nunits = nu; break; }
+            }
+            if (ks.caps == 0) nunits = cut(KS_CAPS[0]);
         }
-        if ((int)bslot.size() <= 250 || (int)bslot.size() > 320) break;     // (> 320: an operator with many more units than CUs; nothing to gain)
-        }
+        if (nunits < 0) { qmri_set_error(ctx, "a k location is sampled %d times; at most %d are supported", -nunits, KS_CAPS[2].ecap); return QMRI_ERR_UNSUPPORTED; }
         bslot.push_back(ns);
         gptr.push_back((int32_t)grp.size());
         sgrp[ns] = (int32_t)grp.size();
         ks.ns = ns; ks.G = (int)bslot.size() - 1;
-        ks.vcap = ((T * s + 10 + 15) / 16) * 16;       // (+10: the channel loops of the kernels are unrolled to 10)
         bool v_fits = false;
-        QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, &v_fits));
+        QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, ks.caps, &v_fits));
         if (!v_fits) {     // T = 1000, s = 10 (cut0, main_recon_tsmis_FFT.m:41-44) needs 80 KB of the CU's 160 KB; T*s <~ 14 900 fits
             qmri_set_error(ctx, "V (T=%d x s=%d) does not fit the on-chip budget of the LSQR kernels", T, s);
             return QMRI_ERR_UNSUPPORTED;

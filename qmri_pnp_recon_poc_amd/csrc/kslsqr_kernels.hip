@@ -36,9 +36,24 @@ namespace {
 
 constexpr int KT = 256;          // threads of every kernel in this file
 constexpr int SL = 8;            // lanes sharing one scatter group
-constexpr int NEQ = (KS_SCAP * DC_MAXS + KT - 1) / KT;   // (slot, channel) elements per thread
-constexpr int NSQ = KS_ECAP / KT;                          // samples per thread
-constexpr int NGQ = KS_GCAPB * SL / KT;                    // scatter groups per 8 lanes
+// Capacities of a work unit (round 5): the iteration kernels are instantiated for three shapes of unit, chosen when the operator is planned
+// (api_core.cpp, KS_CAPS in qmri_internal.h) so that a single slice's units fit the chip at once and the one-launch iteration applies:
+//   0  64 slots x 1024 samples   the spiral masks of cut1 ... cut3 (11 051 sampled k, ~11 samples each at T = 200): ~250 units
+//   1  256 slots x 1024 samples  masks that sample EVERY k a few times (EPI: 50 176 k x 2.7 samples): 196 - 250 units instead of 784
+//   2  64 slots x 2560 samples   few k, many samples each (spiral cut0, T = 1000: 56 per k): ~248 units instead of 604
+template <int ID_, int SCAP_, int ECAP_> struct KsCaps {
+    static constexpr int ID = ID_, SCAP = SCAP_, ECAP = ECAP_, GCAPB = ECAP_ / DC_GCAP + SCAP_;
+    static constexpr int NEQ = (SCAP_ * DC_MAXS + KT - 1) / KT;    // (slot, channel) elements per thread
+    static constexpr int NSQ = (ECAP_ + KT - 1) / KT;              // samples per thread
+    static constexpr int NGQ = (GCAPB * SL + KT - 1) / KT;         // scatter groups per 8 lanes
+    static constexpr int MINW = (ID_ == 0) ? 2 : 1;                // workgroups per CU the register budget is planned for
+};
+typedef KsCaps<0, 64, 1024> Caps0;
+typedef KsCaps<1, 256, 1024> Caps1;
+typedef KsCaps<2, 64, 2560> Caps2;
+static_assert(Caps0::SCAP == KS_CAPS[0].scap && Caps0::ECAP == KS_CAPS[0].ecap && Caps0::GCAPB == KS_CAPS[0].gcapb, "unit capacities: host table");
+static_assert(Caps1::SCAP == KS_CAPS[1].scap && Caps1::ECAP == KS_CAPS[1].ecap && Caps1::GCAPB == KS_CAPS[1].gcapb, "unit capacities: host table");
+static_assert(Caps2::SCAP == KS_CAPS[2].scap && Caps2::ECAP == KS_CAPS[2].ecap && Caps2::GCAPB == KS_CAPS[2].gcapb, "unit capacities: host table");
 constexpr int NVQ = 8;                                     // V values per thread requested up front (8 * 256 = 2048)
 constexpr int KS_GRAN_MAXG = 320;                          // k_ks_persist: most work units per slice (its all-reduce holds 2G granules in 64 x 10 registers)
 
@@ -180,8 +195,10 @@ __global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks, const doub
 // v is stored un-normalised; 1/alpha is applied on the fly.  u(m+1:end) is only normed here (k_ks_b stores it).
 // partial sums: pu[ii&1][g] = |u(m+1:end)|^2 ,  pu[ii&1][G + g] = |u(1:m)|^2
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KT, 2) void k_ks_a(OpDev op, KsDev ks) {
-    __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]
+template <class CP>
+__global__ __launch_bounds__(KT, CP::MINW) void k_ks_a(OpDev op, KsDev ks) {
+    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ;
+    __shared__ cd vl[CP::SCAP * DC_MAXS];                  // v of the unit's slots, [slot][c]
     __shared__ double red[2 * KT / 64];
     extern __shared__ __align__(16) unsigned char smem[];
     double* vlds = (double*)smem;
@@ -261,12 +278,13 @@ __global__ __launch_bounds__(KT, 2) void k_ks_a(OpDev op, KsDev ks) {
 // B'u on a slot = sum over its samples of V(t,c) u(t,k)  +  sqrt(r) u(m+1:end).
 // partial sums: pv[ii&1][g] = |v|^2 of the unit
 // ---------------------------------------------------------------------------------------------------------------
-template <bool INIT>
-__global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
-    __shared__ double2 ulds[KS_ECAP];
-    __shared__ cd part[KS_GCAPB * DC_MAXS];
-    __shared__ unsigned short tlds[KS_ECAP];
-    __shared__ int sgl[KS_SCAP + 1];
+template <class CP, bool INIT>
+__global__ __launch_bounds__(KT, CP::MINW) void k_ks_b(OpDev op, KsDev ks) {
+    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ;
+    __shared__ double2 ulds[CP::ECAP];
+    __shared__ cd part[CP::GCAPB * DC_MAXS];
+    __shared__ unsigned short tlds[CP::ECAP];
+    __shared__ int sgl[CP::SCAP + 1];
     __shared__ double red[2 * KT / 64];
     extern __shared__ __align__(16) unsigned char smem[];
     double* vlds = (double*)smem;
@@ -296,7 +314,10 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
     KsGroup rg[NGQ];
 #pragma unroll
     for (int q = 0; q < NGQ; ++q) { const int gi = (tid + KT * q) / SL; rg[q] = ks.grp[g0 + ((gi < ng) ? gi : 0)]; }
-    const int rsg = ks.sgrp[s0 + ((tid <= nsl) ? tid : 0)] - g0;
+    constexpr int NGS = (CP::SCAP + KT) / KT;              // first-group entries per thread (SCAP + 1 of them)
+    int rsg[NGS];
+#pragma unroll
+    for (int q = 0; q < NGS; ++q) { const int i = tid + KT * q; rsg[q] = ks.sgrp[s0 + ((i <= nsl) ? i : 0)] - g0; }
     double rv[NVQ];
     load_v(op, rv);
     if (done) return;
@@ -314,7 +335,8 @@ __global__ __launch_bounds__(KT, 2) void k_ks_b(OpDev op, KsDev ks) {
     }
 #pragma unroll
     for (int q = 0; q < NSQ; ++q) { const int j = tid + KT * q; if (j < nsamp) { ulds[j] = rut[q]; tlds[j] = res[q].t; } }
-    if (tid <= nsl) sgl[tid] = rsg;
+#pragma unroll
+    for (int q = 0; q < NGS; ++q) { const int i = tid + KT * q; if (i <= nsl) sgl[i] = rsg[q]; }
     store_v(op, rv, vlds);
     lds_barrier();
     const double pa = red[0], pb = red[1], pc = red[2];
@@ -527,12 +549,14 @@ __device__ __forceinline__ void ks_tell_host(LsqrState* h, unsigned seq) {
     if (h) __hip_atomic_store(&h->pad, (int32_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop, int* sticky) {
-    __shared__ cd vl[KS_SCAP * DC_MAXS];                   // v of the unit's slots, [slot][c]   (k_ks_a)
-    __shared__ double2 ulds[KS_ECAP];                      // u(1:m) of the unit's samples        (k_ks_b)
-    __shared__ cd part[KS_GCAPB * DC_MAXS];
-    __shared__ unsigned short tlds[KS_ECAP];
-    __shared__ int sgl[KS_SCAP + 1];
+template <class CP>
+__global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop, int* sticky) {
+    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ;
+    __shared__ cd vl[CP::SCAP * DC_MAXS];                  // v of the unit's slots, [slot][c]   (k_ks_a)
+    __shared__ double2 ulds[CP::ECAP];                     // u(1:m) of the unit's samples        (k_ks_b)
+    __shared__ cd part[CP::GCAPB * DC_MAXS];
+    __shared__ unsigned short tlds[CP::ECAP];
+    __shared__ int sgl[CP::SCAP + 1];
     __shared__ double red[2 * KT / 64 + 4];
     __shared__ int abort_flag;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -567,7 +591,10 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     KsGroup rg[NGQ];
 #pragma unroll
     for (int q = 0; q < NGQ; ++q) { const int gi = (tid + KT * q) / SL; rg[q] = ks.grp[g0 + ((gi < ng) ? gi : 0)]; }
-    const int rsg = ks.sgrp[s0 + ((tid <= nsl) ? tid : 0)] - g0;
+    constexpr int NGS = (CP::SCAP + KT) / KT;
+    int rsg[NGS];
+#pragma unroll
+    for (int q = 0; q < NGS; ++q) { const int i = tid + KT * q; rsg[q] = ks.sgrp[s0 + ((i <= nsl) ? i : 0)] - g0; }
     double rv[NVQ];
     load_v(op, rv);
     LsqrScalars O = st->sc[0];                                      // written by k_ks_b<INIT>
@@ -586,7 +613,8 @@ __global__ __launch_bounds__(KT, 2) void k_ks_persist(OpDev op, KsDev ks, KsGran
     }
 #pragma unroll
     for (int q = 0; q < NSQ; ++q) { const int j = tid + KT * q; if (j < nsamp) tlds[j] = res[q].t; }
-    if (tid <= nsl) sgl[tid] = rsg;
+#pragma unroll
+    for (int q = 0; q < NGS; ++q) { const int i = tid + KT * q; if (i <= nsl) sgl[i] = rsg[q]; }
     if (tid == 0) abort_flag = 0;
     store_v(op, rv, vlds);
     const bool writer = g == 0 && tid == 0;
@@ -890,10 +918,10 @@ int launch_final_t(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, doubl
     return QMRI_OK;
 }
 
-template <int N, int R1, int R2>
+template <int N, int R1, int R2, class CP>
 int lds_fits_t(qmri_ctx* ctx, int s, int M, int vcap, bool* ok) {
     const size_t vb = (size_t)vcap * 8;
-    const void* fns[6] = {(const void*)k_ks_init_a<R1, R2, false>, (const void*)k_ks_a, (const void*)k_ks_b<true>, (const void*)k_ks_b<false>,
+    const void* fns[6] = {(const void*)k_ks_init_a<R1, R2, false>, (const void*)k_ks_a<CP>, (const void*)k_ks_b<CP, true>, (const void*)k_ks_b<CP, false>,
                           (const void*)k_ks_final_w<R1, R2>, (const void*)k_ks_init_a<R1, R2, true>};
     const size_t need[6] = {(size_t)s * M * 16 + vb, vb, vb, vb, vb, (size_t)DC_MAXS * Plan<R1, R2>::LINE * 16 + vb};
     *ok = true;
@@ -904,36 +932,57 @@ int lds_fits_t(qmri_ctx* ctx, int s, int M, int vcap, bool* ok) {
     }
     return QMRI_OK;
 }
-
-}  // namespace
-
-// Does V (vcap doubles) fit next to the other LDS arrays of every k-space LSQR kernel for this grid?
-int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok) {
+template <class CP>
+int lds_fits_c(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok) {
     switch (N) {
-        case 224: return lds_fits_t<224, 16, 14>(ctx, s, M, vcap, ok);
-        case 128: return lds_fits_t<128, 16, 8>(ctx, s, M, vcap, ok);
-        case 64: return lds_fits_t<64, 8, 8>(ctx, s, M, vcap, ok);
-        default: return lds_fits_t<32, 8, 4>(ctx, s, M, vcap, ok);
+        case 224: return lds_fits_t<224, 16, 14, CP>(ctx, s, M, vcap, ok);
+        case 128: return lds_fits_t<128, 16, 8, CP>(ctx, s, M, vcap, ok);
+        case 64: return lds_fits_t<64, 8, 8, CP>(ctx, s, M, vcap, ok);
+        default: return lds_fits_t<32, 8, 4, CP>(ctx, s, M, vcap, ok);
     }
 }
 
-static int ks_attrs(qmri_ctx* ctx) {
+}  // namespace
+
+// Does V (vcap doubles) fit next to the other LDS arrays of every k-space LSQR kernel for this grid, with the unit capacities `caps` (KS_CAPS)?
+int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, int caps, bool* ok) {
+    switch (caps) {
+        case 1: return lds_fits_c<Caps1>(ctx, N, s, M, vcap, ok);
+        case 2: return lds_fits_c<Caps2>(ctx, N, s, M, vcap, ok);
+        default: return lds_fits_c<Caps0>(ctx, N, s, M, vcap, ok);
+    }
+}
+
+template <class CP> static int ks_attrs_c(qmri_ctx* ctx) {
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_a<CP>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<CP, true>));
+    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<CP, false>));
+    return QMRI_OK;
+}
+static int ks_attrs(qmri_ctx* ctx, int caps) {
     if (ctx->ks_lds_attr[0]) return QMRI_OK;
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 14, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 14, true>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 8, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<16, 8, true>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 8, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 8, true>));
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 4, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 4, true>));
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_a));
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<true>));
-    QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_b<false>));
+    if (caps == 1) QMRI_TRY(ks_attrs_c<Caps1>(ctx));
+    else if (caps == 2) QMRI_TRY(ks_attrs_c<Caps2>(ctx));
+    else QMRI_TRY(ks_attrs_c<Caps0>(ctx));
     ctx->ks_lds_attr[0] = true;
     return QMRI_OK;
 }
+// the kernels of one unit shape, by KsDev::caps
+#define KS_BY_CAPS(caps_, CALL)                                                      \
+    do {                                                                             \
+        if ((caps_) == 1) { typedef Caps1 CP; CALL; }                                \
+        else if ((caps_) == 2) { typedef Caps2 CP; CALL; }                           \
+        else { typedef Caps0 CP; CALL; }                                             \
+    } while (0)
 
 // residual + first Golub-Kahan vectors; ks.xhat / ks.zhat hold the unitary spectra of x0 and z
 // hpass_tmp (nullable): the h-pass output of z's transform; the launch then also runs the w-pass and writes ks.zhat (k_ks_init_a<FWDW>)
 int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp) {
-    QMRI_TRY(ks_attrs(ctx));
+    QMRI_TRY(ks_attrs(ctx, ks.caps));
     const size_t vb = (size_t)ks.vcap * 8;
 #define KS_INIT(R1_, R2_)                                                                                                       \
     do {                                                                                                                        \
@@ -947,7 +996,7 @@ int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const
         default: KS_INIT(8, 4); break;
     }
 #undef KS_INIT
-    k_ks_b<true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+    KS_BY_CAPS(ks.caps, (k_ks_b<CP, true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks)));
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -958,11 +1007,11 @@ int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
     hipEvent_t e0 = nullptr, e1 = nullptr;                          // profile level 2: one unit per iteration, k_ks_a's start to k_ks_b's end
     QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, PROF_LSQR));
     if (e0) {
-        hipExtLaunchKernelGGL(k_ks_a, dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, nullptr, 0, op, ks);
-        hipExtLaunchKernelGGL(k_ks_b<false>, dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, nullptr, e1, 0, op, ks);
+        KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_a<CP>), dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, nullptr, 0, op, ks)));
+        KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_b<CP, false>), dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, nullptr, e1, 0, op, ks)));
     } else {
-        k_ks_a<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
-        k_ks_b<false><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks);
+        KS_BY_CAPS(ks.caps, (k_ks_a<CP><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks)));
+        KS_BY_CAPS(ks.caps, (k_ks_b<CP, false><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks)));
     }
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
@@ -975,12 +1024,14 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, vo
     if (ks.G > KS_GRAN_MAXG || ks.maxit < 1 || op.s != DC_MAXS) return QMRI_OK;    // (the kernel is written for the reference's s = 10)
     const size_t vb = (size_t)ks.vcap * 8;
     if (ctx->ks_persist_cap < 0) {
+        const void* fn = nullptr;
+        KS_BY_CAPS(ks.caps, (fn = (const void*)k_ks_persist<CP>));
         hipFuncAttributes fa;
-        QMRI_HIP(ctx, hipFuncGetAttributes(&fa, (const void*)k_ks_persist));
+        QMRI_HIP(ctx, hipFuncGetAttributes(&fa, fn));
         int nb = 0, ncu = 0;
         if (fa.sharedSizeBytes + vb <= KS_LDS_TOTAL) {
-            QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_persist));
-            QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_ks_persist, KT, vb));
+            QMRI_TRY(allow_big_lds(ctx, fn));
+            QMRI_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, KT, vb));
         }
         QMRI_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         // residency actually granted to 256-thread blocks = min(API answer, 8, floor(800 / (ceil(sgpr / 16) * 16 + 16))) per CU
@@ -993,8 +1044,9 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, vo
     int* sticky = (int*)(gu + (size_t)ctx->op.maxB * 6 * ks.G);                         // (the word behind the granules: ks_gran_bytes)
     hipEvent_t e0 = nullptr, e1 = nullptr;                          // profile level 2: the whole solve's iterations as one unit
     QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, PROF_LSQR));
-    if (e0) hipExtLaunchKernelGGL(k_ks_persist, dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, e1, 0, op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0, sticky);
-    else k_ks_persist<<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, ctx->ks_persist == 2 ? 1 : 0, sticky);
+    const int drop = ctx->ks_persist == 2 ? 1 : 0;
+    if (e0) KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_persist<CP>), dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, e1, 0, op, ks, gu, gv, tag0, drop, sticky)));
+    else KS_BY_CAPS(ks.caps, (k_ks_persist<CP><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, drop, sticky)));
     QMRI_HIP(ctx, hipGetLastError());
     *ran = true;
     return QMRI_OK;

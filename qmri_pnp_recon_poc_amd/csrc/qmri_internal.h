@@ -91,13 +91,15 @@ struct OpDev {
 // ---------------------------------------------------------------------------------------------------
 struct KSample { uint16_t ls, t; };              // slot of a sample relative to its block's first slot; frame
 struct KsGroup { uint16_t ls, b, e, pad; };      // <= DC_GCAP samples of one slot; b, e relative to the block's first sample
-constexpr int KS_SCAP = 64;                      // slots per block
-constexpr int KS_ECAP = 1024;                    // samples per block
-constexpr int KS_GCAPB = 96;                     // groups per block  (>= KS_ECAP / DC_GCAP + KS_SCAP)
+// capacities of a work unit: slots, samples, scatter groups (= ecap / DC_GCAP + scap) per block.  Three shapes, picked when the operator is
+// planned (api_core.cpp) so that a single slice's units fit the chip at once; kslsqr_kernels.hip instantiates its kernels for each (KsCaps)
+struct KsCapsHost { int scap, ecap, gcapb; };
+constexpr KsCapsHost KS_CAPS[3] = {{64, 1024, 96}, {256, 1024, 288}, {64, 2560, 144}};
 struct KsUnit { int32_t s0, s1, e0, e1, g0, g1, pad0, pad1; };   // a work unit: its slots, samples and groups (one 32-byte scalar load)
 struct LsqrState;
 struct KsDev {
     int ns, G;                                   // sampled k locations; blocks of the iteration kernels
+    int caps;                                    // shape of the work units: index into KS_CAPS
     const KsUnit* unit;                          // [G]    slot / sample / group ranges of each block
     const KSample* es;                           // [m]
     const KsGroup* grp;                          // scatter groups, block after block
@@ -345,7 +347,7 @@ int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
 int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);
 int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran);   // all iterations in one launch
 size_t ks_gran_bytes(int G, int B);   // tmp <- conj-domain inverse w-pass of xhat
-int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, bool* ok);   // V (vcap doubles) fits the LDS of every k-space LSQR kernel
+int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, int caps, bool* ok);   // V (vcap doubles) fits the LDS of every k-space LSQR kernel with unit shape `caps`
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
                      double2* tmp, double2* x_out);
 // y (ABI order) -> k-sorted order, plus ||y||^2 into state

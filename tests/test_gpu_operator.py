@@ -98,6 +98,41 @@ def test_lsqr_one_launch_equals_two_launch_iteration_bit_for_bit(engine_mod, ora
         e.close()
 
 
+@pytest.mark.parametrize("mask,T", [("epi", 200), ("spiral", 1000), ("epi", 100)])
+def test_lsqr_one_launch_with_the_other_unit_shapes_epi_and_cut0(engine_mod, oracle, mask, T):
+    """Round 5: a single slice under an EPI mask (every k location sampled ~2.7 times: 784 units of 64 slots) or at cut0 (T = 1000: 56 samples per k,
+    604 units of 1024 samples) now gets work units of 256 slots / 2560 samples, <= 250 of them, so the one-launch iteration applies there too
+    (KS_CAPS in qmri_internal.h; the kernels are instantiated per shape).  Same arithmetic as the two-launch iteration on the same units: x, count
+    and flag IDENTICAL; both equal to the oracle's count, x to 1e-10; a measurable difference in time is asserted nowhere -- tools/xupdate_times.py
+    and the bench line's epi / cut0 objects report it."""
+    rng = np.random.default_rng(5)
+    N = 224
+    V = np.linalg.qr(rng.standard_normal((T, 10)))[0]
+    fp, k = oracle.epi_mask(N, N, 1 / 65, T) if mask == "epi" else oracle.spiral_mask(N, 771, T)
+    op = oracle.Operator(N, N, V, fp, k)
+    y = op.forward(rng.standard_normal((N, N, 10))) + 0.01 * (rng.standard_normal(int(fp[-1])) + 1j * rng.standard_normal(int(fp[-1])))
+    e = engine_mod.Engine(0)
+    e.set_operator(N, N, V, fp, k)
+    x0 = op.adjoint(y)
+    z = x0 + 0.1 * (rng.standard_normal(x0.shape) + 1j * rng.standard_normal(x0.shape))
+    for tol, maxit, start in ((1e-4, 100, x0), (1e-9, 100, x0), (1e-4, 100, 0.5 * z)):
+        e.lsqr_persist(True)
+        xa, ita, fla = e.xupdate(y, z, 0.05, tol, maxit, start, solver="lsqr")
+        e.lsqr_persist(False)
+        xb, itb, flb = e.xupdate(y, z, 0.05, tol, maxit, start, solver="lsqr")
+        assert (ita, fla) == (itb, flb), (mask, T, tol, ita, itb, fla, flb)
+        assert np.array_equal(xa, xb), (mask, T, tol, rel_err(xa, xb))
+        xo, ito, flo, _ = op.lsqr(y, z, 0.05, tol, maxit, start)
+        assert (ita, fla) == (ito, flo) and rel_err(xa, xo) < 1e-10, (mask, T, tol, ita, ito)
+    # the recovery path on these shapes: a withheld partial sum -> bounded waits, the message, the two-launch iteration, same result
+    e.lsqr_persist(2)
+    xc, itc, flc = e.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    e.lsqr_persist(False)
+    xd, itd, fld = e.xupdate(y, z, 0.05, 1e-4, 100, x0, solver="lsqr")
+    assert (itc, flc) == (itd, fld) and np.array_equal(xc, xd)
+    e.close()
+
+
 def test_lsqr_one_launch_time_out_falls_back_to_two_launch_iteration(engine_mod, oracle, case224, capfd):
     """The recovery path of k_ks_persist: with the test hook (mode 2) one workgroup withholds a partial sum, every waiting wave gives up after
     its bounded spin, nothing is stored, the library says so on stderr, repeats the solve with the two-launch iteration from the untouched
