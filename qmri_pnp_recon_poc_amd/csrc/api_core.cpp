@@ -393,12 +393,14 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         ks.caps = 0;
         int nunits = cut(KS_CAPS[0]);
         if (max_batch == 1 && s == 10 && (nunits > 320 || nunits < 0)) {
+            int ncu = 0;                                   // (the larger shapes run one workgroup per CU: every unit needs a CU of its own)
+            QMRI_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
             for (int c = 1; c <= 2; ++c) {
                 bool fits = false;
                 QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, c, &fits));
                 if (!fits) continue;
                 const int nu = cut(KS_CAPS[c]);
-                if (nu > 0 && nu <= 250) { ks.caps = c; nunits = nu; break; }
+                if (nu > 0 && nu <= ncu) { ks.caps = c; nunits = nu; break; }      // (cut0: 256 units of <= 2560 samples -- k = 0 alone is sampled in all 1000 frames)
             }
             if (ks.caps == 0) nunits = cut(KS_CAPS[0]);
         }
