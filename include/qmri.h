@@ -85,6 +85,12 @@ int qmri_adjoint_f32(qmri_ctx* ctx, const float* y, float* x);
 /* device-resident variants, `batch` slices stored back to back */
 int qmri_forward_dev(qmri_ctx* ctx, const void* d_x, void* d_y, int batch);
 int qmri_adjoint_dev(qmri_ctx* ctx, const void* d_y, void* d_x, int batch);
+/* Multi-coil extension of F (BASELINE.json configs[4]: "complex-valued multi-coil forward op").  The reference simulates ONE coil (README.md:63): no
+ * interface there to replace, parity unpinned.  maps: N x M x ncoil complex doubles (coil sensitivities C_j; ncoil = 0 clears them; set after
+ * qmri_set_operator).  y = A_mc x: m x ncoil complex, y(:, j) = F.forward(C_j .* x);  x = A_mc^H y = sum_j conj(C_j) .* F.adjoint(y(:, j)). */
+int qmri_set_coils(qmri_ctx* ctx, int ncoil, const void* maps);
+int qmri_forward_mc(qmri_ctx* ctx, const void* x, int x_is_complex, void* y);
+int qmri_adjoint_mc(qmri_ctx* ctx, const void* y, void* x);
 /* The x-update alone: x = lsqr(@afun,[y; sqrt(r) z], tol, maxit, [], [], x)  (PnP_ADMM.m:102,153-171), or the
  * closed-form minimiser when solver == QMRI_SOLVER_DIRECT.  Host buffers; x is in/out (warm start). */
 int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double r, double tol, int maxit, int solver,

@@ -164,6 +164,20 @@ class Operator:
         lib().orc_adjoint(self.h, _dp(yin), _dp(x))
         return x.view(np.complex128).reshape((self.N, self.M, self.s), order="F")
 
+    # Multi-coil extension (BASELINE.json configs[4]): the reference is single-coil (README.md:63), so these two follow NO reference line -- they
+    # restate the textbook SENSE model on top of the single-coil operator above (coil maps times image before the transform; conjugate maps and
+    # a sum over the coils behind the adjoint).  Parity unpinned: checked by adjointness and closed forms (tests/test_gpu_operator.py).
+    def forward_mc(self, x, maps):
+        maps = np.asarray(maps, np.complex128)
+        return np.stack([self.forward(maps[..., j, None] * np.asarray(x)) for j in range(maps.shape[2])], axis=1)
+
+    def adjoint_mc(self, y, maps):
+        maps, y = np.asarray(maps, np.complex128), np.asarray(y)
+        x = np.zeros((self.N, self.M, self.s), np.complex128)
+        for j in range(maps.shape[2]):                           # (j ascending: the order the product adds in)
+            x += np.conj(maps[..., j, None]) * self.adjoint(y[:, j])
+        return x
+
     def lsqr(self, y, z, r, tol=1e-4, maxit=100, x0=None):
         yin, zin = _cplx_in(y), _cplx_in(z)
         x = _cplx_in(x0 if x0 is not None else np.zeros((self.N, self.M, self.s))).copy()

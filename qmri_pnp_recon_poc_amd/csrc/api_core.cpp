@@ -134,7 +134,7 @@ void qmri_free_operator(qmri_ctx* ctx) {
                      (void*)o.ks.unit, (void*)o.ks.es, (void*)o.ks.grp, (void*)o.ks.sgrp,
                      o.ks.pu[0], o.ks.pu[1], o.ks.pv[0], o.ks.pv[1], o.ks.pinit, o.ks.pR, o.ks.cx, o.ks.cv, o.ks.cd, o.ks.cub,
                      o.ks.ut, o.ks.xhat, o.ks.zhat, o.ks.xhat_out, o.ks.stamps,
-                     o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd };
+                     o.d_x, o.d_u, o.d_vv, o.d_z, o.d_chat, o.d_mm, o.d_norm, o.d_diag, o.d_pd, o.d_coils };
     for (void* p : ptrs) free_dev(p);
     if (o.h_state) (void)hipHostFree(o.h_state);
     if (o.h_ring) (void)hipHostFree(o.h_ring);
@@ -522,6 +522,67 @@ extern "C" int qmri_adjoint(qmri_ctx* ctx, const void* y, void* x) {
     const size_t n = (size_t)o.N * o.M * o.s;
     QMRI_HIP(ctx, hipMemcpyAsync(o.d_ya, y, (size_t)o.m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
     QMRI_TRY(qmri_adjoint_dev(ctx, o.d_ya, o.d_xa, 1));
+    QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_xa, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Multi-coil extension (BASELINE.json configs[4]: "complex-valued multi-coil forward op").  NO counterpart in the reference -- it simulates a
+// single coil (README.md:63) -- so there is nothing to be a drop-in for and nothing that pins it: parity unpinned, checked by adjointness,
+// closed forms and a restatement in the oracle (oracle.py Operator.forward_mc / adjoint_mc).  A_mc x = [A (C_1 .* x); ...; A (C_nc .* x)] with A the
+// single-coil operator of qmri_set_operator and C_j the sensitivity maps; A_mc^H y = sum_j conj(C_j) .* A^H y_j.  The coils of a call go through
+// the batched transforms max_batch at a time.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int qmri_set_coils(qmri_ctx* ctx, int ncoil, const void* maps) {
+    REQUIRE_OP(ctx);
+    OpHost& o = ctx->op;
+    QMRI_CHECK_ARG(ctx, ncoil >= 0 && ncoil <= 1024 && (ncoil == 0 || maps), "0 <= ncoil <= 1024, maps must not be NULL");
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (o.d_coils) { (void)hipFree(o.d_coils); o.d_coils = nullptr; }
+    o.ncoil = 0;
+    if (ncoil == 0) return QMRI_OK;
+    const size_t count = (size_t)ncoil * o.N * o.M;
+    QMRI_HIP(ctx, hipMalloc((void**)&o.d_coils, count * sizeof(double2)));
+    QMRI_HIP(ctx, hipMemcpy(o.d_coils, maps, count * sizeof(double2), hipMemcpyHostToDevice));
+    o.ncoil = ncoil;
+    return QMRI_OK;
+}
+
+extern "C" int qmri_forward_mc(qmri_ctx* ctx, const void* x, int x_is_complex, void* y) {
+    REQUIRE_OP(ctx);
+    OpHost& o = ctx->op;
+    QMRI_CHECK_ARG(ctx, x && y, "x / y must not be NULL");
+    if (!o.ncoil) { qmri_set_error(ctx, "no coil maps set: call qmri_set_coils first"); return QMRI_ERR_STATE; }
+    const size_t n = (size_t)o.N * o.M * o.s, plane = (size_t)o.N * o.M;
+    if (x_is_complex) {
+        QMRI_HIP(ctx, hipMemcpyAsync(o.d_xa, x, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        QMRI_HIP(ctx, hipMemcpyAsync(o.d_xb, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        QMRI_TRY(ew_launch_real_to_complex(ctx, n, (const double*)o.d_xb, o.d_xa));
+    }
+    for (int j0 = 0; j0 < o.ncoil; j0 += o.maxB) {
+        const int cnt = std::min(o.maxB, o.ncoil - j0);
+        QMRI_TRY(ew_launch_coil_mul(ctx, n, plane, cnt, o.d_xa, o.d_coils + (size_t)j0 * plane, o.d_x));          // (o.d_x: [max_batch][n], free outside a reconstruction)
+        QMRI_TRY(dc_launch_fwd(ctx, qmri_opdev(ctx), o.ls, DC_PLAIN, cnt, o.d_x, o.d_tmp, o.d_ya, nullptr));
+        QMRI_HIP(ctx, hipMemcpyAsync((double2*)y + (size_t)j0 * o.m, o.d_ya, (size_t)cnt * o.m * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+extern "C" int qmri_adjoint_mc(qmri_ctx* ctx, const void* y, void* x) {
+    REQUIRE_OP(ctx);
+    OpHost& o = ctx->op;
+    QMRI_CHECK_ARG(ctx, x && y, "x / y must not be NULL");
+    if (!o.ncoil) { qmri_set_error(ctx, "no coil maps set: call qmri_set_coils first"); return QMRI_ERR_STATE; }
+    const size_t n = (size_t)o.N * o.M * o.s, plane = (size_t)o.N * o.M;
+    for (int j0 = 0; j0 < o.ncoil; j0 += o.maxB) {
+        const int cnt = std::min(o.maxB, o.ncoil - j0);
+        QMRI_HIP(ctx, hipMemcpyAsync(o.d_ya, (const double2*)y + (size_t)j0 * o.m, (size_t)cnt * o.m * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        QMRI_TRY(dc_launch_adj(ctx, qmri_opdev(ctx), cnt, o.d_ya, o.d_tmp, o.d_x));
+        QMRI_TRY(ew_launch_coil_sum(ctx, n, plane, cnt, o.d_x, o.d_coils + (size_t)j0 * plane, o.d_xa, j0 > 0));
+    }
     QMRI_HIP(ctx, hipMemcpyAsync(x, o.d_xa, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return QMRI_OK;

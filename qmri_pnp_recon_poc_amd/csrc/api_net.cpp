@@ -45,6 +45,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     if (p.d_c6part) (void)hipFree(p.d_c6part);
     if (p.d_res_xbuf) (void)hipFree(p.d_res_xbuf);
     if (p.d_res_stamps) (void)hipFree(p.d_res_stamps);
+    if (p.d_io) (void)hipFree(p.d_io);
     if (p.d_range_flag) (void)hipFree(p.d_range_flag);
     if (p.h_range_flag) (void)hipHostFree(p.h_range_flag);
     if (p.d_act_slots) (void)hipFree(p.d_act_slots);
@@ -515,8 +516,13 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
     // ADMM loop -- are left alone.
     float in_scale = 1.f, out_scale = 1.f;
     {
-        double amax = 0.0;
-        for (size_t i = 0; i < nin; ++i) { const double a = std::fabs(in[i]); if (a > amax) amax = a; }
+        // (four independent maxima: the loop vectorises; a NaN never raises amax -- such an input goes through unscaled and the range guard sees it)
+        double m4[4] = {0.0, 0.0, 0.0, 0.0};
+        size_t i = 0;
+        for (; i + 4 <= nin; i += 4)
+            for (int j = 0; j < 4; ++j) { const double a = std::fabs(in[i + j]); m4[j] = a > m4[j] ? a : m4[j]; }
+        for (; i < nin; ++i) { const double a = std::fabs(in[i]); m4[0] = a > m4[0] ? a : m4[0]; }
+        const double amax = std::max(std::max(m4[0], m4[1]), std::max(m4[2], m4[3]));
         if (std::isfinite(amax) && amax > 0.0 && (amax < 0.0625 || amax >= 256.0)) {
             int e = 0;
             (void)std::frexp(amax, &e);                             // amax = f * 2^e, f in [0.5, 1)
@@ -524,8 +530,14 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
             in_scale = std::ldexp(1.f, k); out_scale = std::ldexp(1.f, -k);
         }
     }
-    double* d_io = nullptr;
-    QMRI_HIP(ctx, hipMalloc((void**)&d_io, std::max(nin, nout) * sizeof(double)));
+    // staging buffer of the per-call drop-in mode (the reference's own PnP_ADMM.m calling param.net 100 times): kept with the plan, grown on demand
+    if (p.io_cap < std::max(nin, nout)) {
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p.d_io) { (void)hipFree(p.d_io); p.d_io = nullptr; p.io_cap = 0; }
+        QMRI_HIP(ctx, hipMalloc((void**)&p.d_io, std::max(nin, nout) * sizeof(double)));
+        p.io_cap = std::max(nin, nout);
+    }
+    double* const d_io = p.d_io;
     int st = QMRI_OK;
     bool again = false;
     for (int attempt = 0; attempt < 3; ++attempt) {        // (further passes only after a guard changed the plan: see qmri_net_forward_dev)
@@ -542,7 +554,6 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
         if (st != QMRI_OK || !again) break;
     }
     if (st == QMRI_OK && again) { qmri_set_error(ctx, "the network's guards asked for a fourth pass (resident-tile hand-off / f16 range): giving up"); st = QMRI_ERR_HIP; }
-    (void)hipFree(d_io);
     if (st == QMRI_ERR_HIP && ctx->err.empty()) qmri_set_error(ctx, "HIP failure in qmri_denoise");
     return st;
 }

@@ -312,6 +312,45 @@ int ew_launch_absmax(qmri_ctx* ctx, const float* x, const float* y, size_t n, un
     return QMRI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-coil extension of the forward operator (BASELINE.json configs[4]; the reference is single-coil, README.md:63: no counterpart there).
+//   k_coil_mul : out[j][c][px] = maps[j0 + j][px] * x[c][px]              (coil sensitivity times image, before the FFT)
+//   k_coil_sum : x[c][px] (+)= sum_j conj(maps[j0 + j][px]) * xj[j][c][px]   (coil combination after the inverse FFT; j ascending: one fixed order)
+// Streaming, complex fp64 like the operator itself.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_coil_mul(size_t n, size_t plane, int cnt, const double2* __restrict__ x, const double2* __restrict__ maps, double2* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const double2 v = x[i];
+    const size_t px = i % plane;
+    for (int j = 0; j < cnt; ++j) {
+        const double2 c = maps[(size_t)j * plane + px];
+        out[(size_t)j * n + i] = make_double2(c.x * v.x - c.y * v.y, c.x * v.y + c.y * v.x);
+    }
+}
+__global__ __launch_bounds__(NT) void k_coil_sum(size_t n, size_t plane, int cnt, const double2* __restrict__ xj, const double2* __restrict__ maps, double2* __restrict__ x, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const size_t px = i % plane;
+    double2 a = accumulate ? x[i] : make_double2(0.0, 0.0);
+    for (int j = 0; j < cnt; ++j) {
+        const double2 c = maps[(size_t)j * plane + px], v = xj[(size_t)j * n + i];
+        a.x += c.x * v.x + c.y * v.y;                              // conj(c) * v
+        a.y += c.x * v.y - c.y * v.x;
+    }
+    x[i] = a;
+}
+int ew_launch_coil_mul(qmri_ctx* ctx, size_t n, size_t plane, int cnt, const double2* x, const double2* maps, double2* out) {
+    k_coil_mul<<<dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, ctx->stream>>>(n, plane, cnt, x, maps, out);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+int ew_launch_coil_sum(qmri_ctx* ctx, size_t n, size_t plane, int cnt, const double2* xj, const double2* maps, double2* x, int accumulate) {
+    k_coil_sum<<<dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, ctx->stream>>>(n, plane, cnt, xj, maps, x, accumulate);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
 int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out) {
     k_real_to_complex<<<dim3((unsigned)((count + NT - 1) / NT)), dim3(NT), 0, ctx->stream>>>(count, in, out);
     QMRI_HIP(ctx, hipGetLastError());

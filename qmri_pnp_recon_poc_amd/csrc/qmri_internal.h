@@ -231,6 +231,7 @@ struct NetPlan {
     int res_timeouts = 0;            // hand-off time-outs since qmri_set_denoiser (three: the form stays off)
     int res_clean = 0;               // clean one-launch-per-layer passes since the last one (K_RES_REARM of them re-arm the form)
     int res_drop = 0;                // test hook: bit 0 = tile 0 withholds its hand-off
+    double* d_io = nullptr; size_t io_cap = 0;   // qmri_denoise: device staging of the caller's doubles (elements), kept between calls
     void* d_res_stamps = nullptr;    // diagnostic: phase stamps of the last k_conv6r launch (knob res_stamps), 4 x 2 x R_MAXL (10) x 8 of 1024 values
     bool ready = false;
 };
@@ -243,6 +244,7 @@ struct OpHost {
     int N = 0, M = 0, s = 0, T = 0, m = 0, maxB = 0, nsampled = 0;
     double* d_Vt = nullptr; KEntry* d_ent = nullptr; int32_t* d_perm = nullptr; int32_t* d_kptr = nullptr;
     double2* d_tw = nullptr; int32_t* d_kslot = nullptr; double* d_ginv = nullptr;
+    double2* d_coils = nullptr; int ncoil = 0;   // multi-coil extension: [ncoil][N*M] sensitivity maps (qmri_set_coils)
     KsDev ks{};                         // k-space LSQR plan + state (device pointers owned here)
     bool xhat_valid = false;            // ks.xhat holds the spectrum of d_x
     double ginv_r = -1.0;
@@ -368,6 +370,9 @@ int ew_launch_absmax(qmri_ctx* ctx, const float* x, const float* y, size_t n, un
 int ew_launch_unpack(qmri_ctx* ctx, int B, int C, int H, int W, const PTensor& out32, const PTensor& in32, int residual_noise,
                      void* dst, int dst_is_double, float scale = 1.f);
 int ew_launch_real_to_complex(qmri_ctx* ctx, size_t count, const double* in, double2* out);
+// multi-coil extension (ew_kernels.hip): coil maps times image / conjugate coil combination, `cnt` coils of a chunk at a time
+int ew_launch_coil_mul(qmri_ctx* ctx, size_t n, size_t plane, int cnt, const double2* x, const double2* maps, double2* out);
+int ew_launch_coil_sum(qmri_ctx* ctx, size_t n, size_t plane, int cnt, const double2* xj, const double2* maps, double2* x, int accumulate);
 
 // conv engine (conv_kernels.hip)
 int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,

@@ -176,6 +176,40 @@ class Engine:
         self._check(self.L.qmri_adjoint(self.h, _vp(yb), _vp(x)))
         return x.reshape((self.N, self.M, self.s), order="F")
 
+    # -- multi-coil extension (BASELINE configs[4]; no reference counterpart: README.md:63, single coil) -------------------
+    def set_coils(self, maps):
+        """maps: [N, M, ncoil] complex coil sensitivities (None clears them)."""
+        if maps is None:
+            self._check(self.L.qmri_set_coils(self.h, 0, None))
+            self.ncoil = 0
+            return
+        maps = np.asarray(maps)
+        if maps.ndim != 3 or maps.shape[:2] != (self.N, self.M):
+            raise ValueError(f"maps must be {self.N}x{self.M}xncoil")
+        mb = _cbuf(maps)
+        self._check(self.L.qmri_set_coils(self.h, int(maps.shape[2]), _vp(mb)))
+        self.ncoil = int(maps.shape[2])
+
+    def forward_mc(self, x):
+        """y[:, j] = F.forward(maps[..., j] * x): [m, ncoil] complex."""
+        x = np.asarray(x)
+        if x.shape != (self.N, self.M, self.s):
+            raise ValueError(f"x must be {self.N}x{self.M}x{self.s}")
+        y = np.empty(self.m * max(getattr(self, "ncoil", 0), 1), np.complex128)
+        xb = _cbuf(x)
+        self._check(self.L.qmri_forward_mc(self.h, _vp(xb), 1, _vp(y)))
+        return y.reshape((self.m, -1), order="F")
+
+    def adjoint_mc(self, y):
+        """x = sum_j conj(maps[..., j]) * F.adjoint(y[:, j])."""
+        yb = _cbuf(y)
+        nc = getattr(self, "ncoil", 0)
+        if nc and yb.size != self.m * nc:                        # (no maps set: the library says so, QMRI_ERR_STATE)
+            raise ValueError(f"y must be {self.m} x {nc}")
+        x = np.empty(self.N * self.M * self.s, np.complex128)
+        self._check(self.L.qmri_adjoint_mc(self.h, _vp(yb), _vp(x)))
+        return x.reshape((self.N, self.M, self.s), order="F")
+
     def xupdate(self, y, z, r, tol=1e-4, maxit=100, x0=None, solver="lsqr"):
         """The x-update of PnP_ADMM.m:102 alone.  Returns (x, iters, flag)."""
         yb, zb = _cbuf(y), _cbuf(z)

@@ -98,6 +98,44 @@ def test_lsqr_one_launch_equals_two_launch_iteration_bit_for_bit(engine_mod, ora
         e.close()
 
 
+def test_multi_coil_operator_extension(engine_mod, oracle):
+    """BASELINE.json configs[4] names a "complex-valued multi-coil forward op".  The reference simulates a single coil (README.md:63), so this extension
+    has NO reference counterpart and nothing pins it (parity unpinned): A_mc x = [A (C_j .* x)]_j, A_mc^H y = sum_j conj(C_j) .* A^H y_j on top of the
+    parity-tested single-coil operator.  Checked: against the oracle's restatement (1e-12), exact adjointness <A x, y> = <x, A^H y>, the closed form for
+    constant maps (A_mc x = [c_j A x]), one all-ones coil == the single-coil operator bit for bit, more coils than max_batch (chunks), cut0 (T = 1000)
+    with 8 coils, and the error without maps."""
+    rng = np.random.default_rng(21)
+    for N, T, nc, maxb in ((32, 24, 5, 2), (224, 1000, 8, 4)):
+        V = np.linalg.qr(rng.standard_normal((T, 10)))[0]
+        fp, k = oracle.spiral_mask(N, 771 if N == 224 else 120, T)
+        op = oracle.Operator(N, N, V, fp, k)
+        e = engine_mod.Engine(0)
+        e.set_operator(N, N, V, fp, k, max_batch=maxb)
+        x = rng.standard_normal((N, N, 10)) + 1j * rng.standard_normal((N, N, 10))
+        with pytest.raises(engine_mod.QmriError):
+            e.forward_mc(x)                                           # no maps yet: QMRI_ERR_STATE
+        hh, ww = np.meshgrid(np.linspace(-1, 1, N), np.linspace(-1, 1, N), indexing="ij")
+        maps = np.stack([np.exp(-((hh - np.cos(a)) ** 2 + (ww - np.sin(a)) ** 2)) * np.exp(1j * (a + hh * ww)) for a in np.linspace(0, 2 * np.pi, nc, endpoint=False)], axis=2)
+        e.set_coils(maps)
+        y = e.forward_mc(x)
+        assert y.shape == (e.m, nc) and rel_err(y, op.forward_mc(x, maps)) < 1e-12
+        w = rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape)
+        xa = e.adjoint_mc(w)
+        assert rel_err(xa, op.adjoint_mc(w, maps)) < 1e-12
+        lhs, rhs = np.vdot(w.ravel(), y.ravel()), np.vdot(xa.ravel(), x.ravel())
+        assert abs(lhs - rhs) / abs(lhs) < 1e-12                      # <A x, w> = <x, A^H w>
+        cst = (rng.standard_normal(nc) + 1j * rng.standard_normal(nc))[None, None, :] * np.ones((N, N, 1))
+        e.set_coils(cst)
+        y1 = e.forward(x)
+        assert rel_err(e.forward_mc(x), y1[:, None] * cst[0, 0][None, :]) < 1e-13
+        e.set_coils(np.ones((N, N, 1)))
+        assert np.array_equal(e.forward_mc(x)[:, 0], y1) and np.array_equal(e.adjoint_mc(y1[:, None]), e.adjoint(y1))
+        e.set_coils(None)
+        with pytest.raises(engine_mod.QmriError):
+            e.adjoint_mc(w)
+        e.close()
+
+
 @pytest.mark.parametrize("mask,T", [("epi", 200), ("spiral", 1000), ("epi", 100)])
 def test_lsqr_one_launch_with_the_other_unit_shapes_epi_and_cut0(engine_mod, oracle, mask, T):
     """Round 5: a single slice under an EPI mask (every k location sampled ~2.7 times: 784 units of 64 slots) or at cut0 (T = 1000: 56 samples per k,

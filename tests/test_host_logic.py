@@ -22,6 +22,24 @@ def test_abi_exports_every_declared_symbol():
     assert L.qmri_abi_version() == 1
 
 
+def test_one_debug_entry_point_and_one_environment_variable():
+    """Round 5: the library's A/B and diagnostic switches sit behind ONE entry point (qmri_debug_knob) and ONE environment variable
+    (QMRI_DEBUG="name=value,..."): a known name is accepted, an unknown one refused with a message, a malformed QMRI_DEBUG entry is reported on
+    stderr instead of being silently ignored, and no other getenv is left in csrc/."""
+    from qmri_pnp_recon_poc_amd import _lib
+    L = _lib.lib()
+    assert L.qmri_debug_knob(b"conv_xcd", 1) == 0
+    assert L.qmri_debug_knob(b"no_such_knob", 1) == -1 and b"no_such_knob" in L.qmri_last_error(None)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom qmri_pnp_recon_poc_amd import _lib\nL = _lib.lib()\nprint(L.qmri_debug_knob(b'res_delay', 24))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QMRI_DEBUG="res_delay=32,typo_knob=1,conv_xcd"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "0", r.stderr
+    assert "typo_knob=1" in r.stderr and "'conv_xcd'" in r.stderr                  # unknown name / no value: both reported
+    csrc = os.path.join(ROOT, "qmri_pnp_recon_poc_amd", "csrc")
+    uses = [(f, n + 1) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp", ".h"))
+            for n, line in enumerate(open(os.path.join(csrc, f))) if re.search(r"\bgetenv\s*\(", line)]
+    assert uses == [("api_core.cpp", uses[0][1])] and len(uses) == 1, uses
+
+
 def test_no_gpu_fails_loudly():
     """Without a usable gfx950 device the product refuses to run (no CPU fallback)."""
     import torch
