@@ -209,6 +209,9 @@ def load_traffic(B: int):
             t = json.load(f)
         if int(t.get("batch", 1)) != B:
             return None, f"no PMC pass for batch {B}"
+        fam = t.get("family_per_forward")
+        if fam:                                                    # round 5: the whole 3x3 family of a forward pass, the set of launches the roofline times
+            return int(fam["corrected_bytes"]), ("per FORWARD PASS (all units of the roofline together): " + fam.get("what", "") + "; " + t.get("source", ""))
         return int(t["corrected_bytes_per_launch_per_slice"] * B), (t.get("kernel", "") + ": " + t.get("source", ""))
     except (OSError, KeyError, ValueError):
         return None, (None if B == 1 else f"no PMC pass for batch {B} (profiles/conv_traffic_batch{B}.json)")
@@ -233,6 +236,8 @@ def conv_roofline(pr, B, kernel_text, traffic=None, traffic_source=None):
     nf = max(pr["n_net_forward"], 1)
     roof = {"kernel": kernel_text, "bound": "mfma", "achieved": round(ach, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_unit": "HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE) of ALL timed units of one forward pass, when the committed PMC file carries them; "
+                            "else per launch of the kernel named in traffic_source",
             "timing": "every launch of the family is ONE unit, timed from its own dispatch timestamps (hipExtLaunchKernelGGL events): a split-K layer from the "
                       "convolution's start to its reduce kernel's end, a resident-tile launch whole; achieved = executed flop of the units / sum of their durations",
             "units_timed": int(pr["n_conv3x3"]), "units_per_forward": round(pr["n_conv3x3"] / nf, 2), "ms_timed_per_forward": round(pr["ms_conv3x3"] / nf, 4),

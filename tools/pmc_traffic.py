@@ -35,6 +35,30 @@ def rows(d, counter):
     return sorted(out)
 
 
+def family_per_forward(dfetch, dwrite, marker):
+    """Round 5: bench.py's roofline covers the whole 3x3 family of a forward pass as timed UNITS (a launch per layer, a split-K layer with its reduce
+    kernel, a resident-tile launch whole).  This is the matching traffic: every dispatch of the family (k_conv6 / k_conv6p / k_conv6r / k_conv6_reduce*)
+    from the first dispatch whose name contains `marker` on -- the forward passes of tools/prof_net.py; what comes before is qmri_set_denoiser's
+    calibration probe -- FETCH_SIZE x 2 (16 B per lane requests; the reduce kernel's 4-byte partial-sum reads are a width the guide does not
+    calibrate: counted as they are, they are < 2 % of the total) + WRITE_SIZE, divided by the number of forward passes (= marker dispatches / 2 for
+    k_conv6r, two per pass; the head's launches for batches)."""
+    fam = lambda n: ("k_conv6<" in n or "k_conv6p<" in n or "k_conv6r<" in n or "k_conv6_reduce" in n)
+    rf, rw = rows(dfetch, "FETCH_SIZE"), rows(dwrite, "WRITE_SIZE")
+    out = {}
+    for key, rs, fac in (("fetch", rf, 2.0), ("write", rw, 1.0)):
+        ids = [i for (i, n, g, v) in rs if marker in n]
+        if not ids:
+            return None
+        first = min(ids)
+        tot = 0.0
+        for (i, n, g, v) in rs:
+            if i >= first and fam(n):
+                tot += v * 1024 * (1.0 if (key == "fetch" and "k_conv6_reduce" in n) else fac)
+        out[key] = tot
+        out["n_marker_" + key] = len(ids)
+    return out
+
+
 def main_batch(dfetch, dwrite, batch):
     """The persistent kernel of slice batches at the 224 x 224 x 64 level: k_conv6p<0, NRES>, one launch = `batch` slices = batch * 196 tiles
     on 256 workgroups.  Populations by the template argument NRES (0 plain, 1 one residual operand, 2 residual + skip)."""
@@ -68,6 +92,11 @@ def main_batch(dfetch, dwrite, batch):
         out["per_nres"][str(nres)] = {**d, "corrected_bytes": int(corr), "algorithmic_bytes": int(alg[nres]), "ratio": round(corr / alg[nres], 3)}
         tot_b += corr * d["launches"]; tot_n += d["launches"]
     out["corrected_bytes_per_launch_per_slice"] = int(tot_b / tot_n / batch)
+    fam = family_per_forward(dfetch, dwrite, "k_conv6p<0, 0")
+    if fam:
+        nfwd = REPS if REPS > 0 else 2                             # (tools/prof_net.py <batch> 2: two forward passes)
+        out["family_per_forward"] = {"forward_passes": nfwd, "corrected_bytes": int((fam["fetch"] + fam["write"]) / nfwd),
+                                     "what": "every 3x3-family dispatch of a forward pass of %d slices: FETCH_SIZE x 2 + WRITE_SIZE" % batch}
     with open(os.path.join(ROOT, "profiles", "conv_traffic_batch%d.json" % batch), "w") as fh:
         json.dump(out, fh, indent=1)
     txt = json.dumps(out, indent=1)
@@ -77,7 +106,7 @@ def main_batch(dfetch, dwrite, batch):
     print(txt)
 
 
-def main_resident(f, w):
+def main_resident(f, w, family=None):
     """k_conv6r: one launch = the eight ResBlock layers of the 224 x 224 x 64 level with LDS-resident tiles (conv6_kernels.hip).  Two launches per
     forward pass: the down path's (no skip operand) and the up path's (+ the skip tensor at the last layer): the two populations of FETCH_SIZE.
     Every request is 16 B per lane: FETCH_SIZE x 2.  Algorithmic bytes per launch: the input tile with its ring once, the four block inputs read
@@ -105,6 +134,10 @@ def main_resident(f, w):
                              "launched alone (profiles/r04_l_pmc_conv_traffic.txt): the ReLU intermediates never leave the chip",
            "tensor_format": "blocked [c/8][w][h][8]",
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/prof_net.py 1 3; tools/pmc_traffic.py; FETCH x2 (every request of the kernel is 16 B per lane)"}
+    if family:
+        nfwd = REPS if REPS > 0 else max(1, family["n_marker_fetch"] // 2)   # (two k_conv6r launches per pass)
+        out["family_per_forward"] = {"forward_passes": nfwd, "corrected_bytes": int((family["fetch"] + family["write"]) / nfwd),
+                                     "what": "every 3x3-family dispatch of a one-slice forward pass (k_conv6r x 2, k_conv6 x 40, k_conv6_reduce_blk x 8): FETCH_SIZE x 2 + WRITE_SIZE"}
     with open(os.path.join(ROOT, "profiles", "conv_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     txt = json.dumps(out, indent=1)
@@ -114,16 +147,22 @@ def main_resident(f, w):
     print(txt)
 
 
+REPS = 0      # forward passes of the profiled run (--reps N; default: 2 for batches, counted from the k_conv6r launches for one slice)
+
+
 def main():
+    global REPS
     batch = 1
     if sys.argv[1] == "--batch":
         batch = int(sys.argv[2]); del sys.argv[1:3]
+    if sys.argv[1] == "--reps":
+        REPS = int(sys.argv[2]); del sys.argv[1:3]
     dfetch, dwrite = sys.argv[1], sys.argv[2]
     if batch > 1:
         return main_batch(dfetch, dwrite, batch)
     rf, rw = [v for (_, n, g, v) in rows(dfetch, "FETCH_SIZE") if "k_conv6r" in n], [v for (_, n, g, v) in rows(dwrite, "WRITE_SIZE") if "k_conv6r" in n]
     if rf and rw:
-        return main_resident(sorted(rf), sorted(rw))
+        return main_resident(sorted(rf), sorted(rw), family_per_forward(dfetch, dwrite, "k_conv6r"))
     sel = lambda rs: [v for (_, n, g, v) in rs if "k_conv6<0, 2" in n and g == 196 * 512]
     f, w = sel(rows(dfetch, "FETCH_SIZE")), sel(rows(dwrite, "WRITE_SIZE"))
     if not f or not w:

@@ -4,7 +4,7 @@
 # passes for tools/pmc_traffic.py (one slice and a 15-slice batch) and the matrix-core / clock pass of tools/pmc_conv.sh.
 # rocprofv3 is given the program itself after `--` (python3 ...), never a wrapper; counters and traces are separate runs.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
