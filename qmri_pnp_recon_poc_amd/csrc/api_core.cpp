@@ -340,7 +340,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
 
     LsqrDev& ls = o.ls;
     // ---- k-space LSQR plan (kslsqr_kernels.hip): the sampled k locations ("slots", k' order) are cut into work units of
-    // similar sample count, each unit's samples into scatter groups of <= DC_GCAP samples of one slot
+    // similar sample count, each unit's samples into scatter groups of <= gcap samples of one slot (KS_CAPS: 32 for dense masks, 4 for sparse ones)
     KsDev& ks = o.ks;
     {
         const int ns = o.nsampled;
@@ -370,14 +370,14 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
                     bslot.push_back(first);
                     gptr.push_back((int32_t)grp.size());
                     while (j < ns) {
-                        const int cnt = sptr[j + 1] - sptr[j], gj = (cnt + DC_GCAP - 1) / DC_GCAP;
+                        const int cnt = sptr[j + 1] - sptr[j], gj = (cnt + cp.gcap - 1) / cp.gcap;
                         if (cnt > cp.ecap || cnt > 65535) return -cnt;
                         const int have = sptr[j] - e0;
                         if (j > first && (j - first >= cp.scap || have + cnt > cp.ecap || ngr + gj > cp.gcapb || have + cnt / 2 > target)) break;
                         sgrp[j] = (int32_t)grp.size();
-                        for (int e = sptr[j]; e < sptr[j + 1]; e += DC_GCAP) {
+                        for (int e = sptr[j]; e < sptr[j + 1]; e += cp.gcap) {
                             KsGroup g;
-                            g.ls = (uint16_t)(j - first); g.b = (uint16_t)(e - e0); g.e = (uint16_t)(std::min(e + DC_GCAP, sptr[j + 1]) - e0); g.pad = 0;
+                            g.ls = (uint16_t)(j - first); g.b = (uint16_t)(e - e0); g.e = (uint16_t)(std::min(e + cp.gcap, sptr[j + 1]) - e0); g.pad = 0;
                             grp.push_back(g);
                         }
                         for (int e = sptr[j]; e < sptr[j + 1]; ++e) { es[e].ls = (uint16_t)(j - first); es[e].t = o.ent_h[e].t; }
@@ -390,19 +390,25 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
             return (int)bslot.size();
         };
         ks.vcap = ((T * s + 10 + 15) / 16) * 16;       // (+10: the channel loops of the kernels are unrolled to 10)
-        ks.caps = 0;
-        int nunits = cut(KS_CAPS[0]);
+        // sparse masks (fewer than 8 samples per sampled k on average: EPI) give every scatter group of <= 4 samples to one lane; dense ones
+        // (the spiral: 11 at cut3, 56 at cut0) share groups of <= 32 samples among 8 lanes (KS_CAPS)
+        const bool sparse = ns > 0 && (double)m / ns < 8.0;
+        int base = sparse ? 3 : 0;
+        ks.caps = base;
+        int nunits = cut(KS_CAPS[base]);
+        if (sparse && nunits < 0) { base = 0; ks.caps = 0; nunits = cut(KS_CAPS[0]); }      // (sparse on average with one very busy location: the dense shape)
         if (max_batch == 1 && s == 10 && (nunits > 320 || nunits < 0)) {
             int ncu = 0;                                   // (the larger shapes run one workgroup per CU: every unit needs a CU of its own)
             QMRI_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-            for (int c = 1; c <= 2; ++c) {
+            const int order[2] = {sparse ? 1 : 2, sparse ? 2 : 1};
+            for (int c : order) {
                 bool fits = false;
                 QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, c, &fits));
                 if (!fits) continue;
                 const int nu = cut(KS_CAPS[c]);
                 if (nu > 0 && nu <= ncu) { ks.caps = c; nunits = nu; break; }      // (cut0: 256 units of <= 2560 samples -- k = 0 alone is sampled in all 1000 frames)
             }
-            if (ks.caps == 0) nunits = cut(KS_CAPS[0]);
+            if (ks.caps == base) nunits = cut(KS_CAPS[base]);
         }
         if (nunits < 0) { qmri_set_error(ctx, "a k location is sampled %d times; at most %d are supported", -nunits, KS_CAPS[2].ecap); return QMRI_ERR_UNSUPPORTED; }
         bslot.push_back(ns);

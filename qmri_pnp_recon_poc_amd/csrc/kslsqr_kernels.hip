@@ -35,25 +35,28 @@ using namespace dcdev;
 namespace {
 
 constexpr int KT = 256;          // threads of every kernel in this file
-constexpr int SL = 8;            // lanes sharing one scatter group
 // Capacities of a work unit (round 5): the iteration kernels are instantiated for three shapes of unit, chosen when the operator is planned
 // (api_core.cpp, KS_CAPS in qmri_internal.h) so that a single slice's units fit the chip at once and the one-launch iteration applies:
 //   0  64 slots x 1024 samples   the spiral masks of cut1 ... cut3 (11 051 sampled k, ~11 samples each at T = 200): ~250 units
 //   1  256 slots x 1024 samples  masks that sample EVERY k a few times (EPI: 50 176 k x 2.7 samples): 196 - 250 units instead of 784
 //   2  64 slots x 2560 samples   few k, many samples each (spiral cut0, T = 1000: 56 per k): ~248 units instead of 604
-template <int ID_, int SCAP_, int ECAP_> struct KsCaps {
-    static constexpr int ID = ID_, SCAP = SCAP_, ECAP = ECAP_, GCAPB = ECAP_ / DC_GCAP + SCAP_;
+template <int ID_, int SCAP_, int ECAP_, int GCAP_, int SL_> struct KsCaps {
+    static constexpr int ID = ID_, SCAP = SCAP_, ECAP = ECAP_, GCAP = GCAP_, SL = SL_, GCAPB = ECAP_ / GCAP_ + SCAP_;   // GCAP samples per scatter group, SL lanes share one
     static constexpr int NEQ = (SCAP_ * DC_MAXS + KT - 1) / KT;    // (slot, channel) elements per thread
     static constexpr int NSQ = (ECAP_ + KT - 1) / KT;              // samples per thread
-    static constexpr int NGQ = (GCAPB * SL + KT - 1) / KT;         // scatter groups per 8 lanes
-    static constexpr int MINW = (ID_ == 0) ? 2 : 1;                // workgroups per CU the register budget is planned for
+    static constexpr int NGQ = (GCAPB * SL_ + KT - 1) / KT;        // scatter groups per SL lanes
+    static constexpr int MINW = (ID_ == 0 || ID_ == 3) ? 2 : 1;    // workgroups per CU the register budget is planned for
 };
-typedef KsCaps<0, 64, 1024> Caps0;
-typedef KsCaps<1, 256, 1024> Caps1;
-typedef KsCaps<2, 64, 2560> Caps2;
-static_assert(Caps0::SCAP == KS_CAPS[0].scap && Caps0::ECAP == KS_CAPS[0].ecap && Caps0::GCAPB == KS_CAPS[0].gcapb, "unit capacities: host table");
-static_assert(Caps1::SCAP == KS_CAPS[1].scap && Caps1::ECAP == KS_CAPS[1].ecap && Caps1::GCAPB == KS_CAPS[1].gcapb, "unit capacities: host table");
-static_assert(Caps2::SCAP == KS_CAPS[2].scap && Caps2::ECAP == KS_CAPS[2].ecap && Caps2::GCAPB == KS_CAPS[2].gcapb, "unit capacities: host table");
+typedef KsCaps<0, 64, 1024, 32, 8> Caps0;
+typedef KsCaps<1, 256, 768, 4, 1> Caps1;
+typedef KsCaps<2, 64, 2560, 32, 8> Caps2;
+typedef KsCaps<3, 64, 256, 4, 1> Caps3;
+template <class CP> constexpr bool caps_ok() {
+    return CP::SCAP == KS_CAPS[CP::ID].scap && CP::ECAP == KS_CAPS[CP::ID].ecap && CP::GCAP == KS_CAPS[CP::ID].gcap && CP::SL == KS_CAPS[CP::ID].sl && CP::GCAPB == KS_CAPS[CP::ID].gcapb;
+}
+static_assert(caps_ok<Caps0>() && caps_ok<Caps1>() && caps_ok<Caps2>() && caps_ok<Caps3>(), "unit shapes: host table (qmri_internal.h KS_CAPS)");
+// sum over the SL lanes that share a scatter group (SL = 8: fixed DPP tree; SL = 1: the lane's own sum)
+template <int SL> __device__ __forceinline__ double group_sum(double v) { if constexpr (SL == 8) return group8_sum(v); else return v; }
 constexpr int NVQ = 8;                                     // V values per thread requested up front (8 * 256 = 2048)
 constexpr int KS_GRAN_MAXG = 320;                          // k_ks_persist: most work units per slice (its all-reduce holds 2G granules in 64 x 10 registers)
 
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_a(OpDev op, KsDev ks) {
 // ---------------------------------------------------------------------------------------------------------------
 template <class CP, bool INIT>
 __global__ __launch_bounds__(KT, CP::MINW) void k_ks_b(OpDev op, KsDev ks) {
-    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ;
+    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ, SL = CP::SL, GPL = CP::GCAP / CP::SL;   // (GPL: a group's samples per lane)
     __shared__ double2 ulds[CP::ECAP];
     __shared__ cd part[CP::GCAPB * DC_MAXS];
     __shared__ unsigned short tlds[CP::ECAP];
@@ -420,17 +423,17 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_b(OpDev op, KsDev ks) {
             double xr[DC_MAXS], xi[DC_MAXS];
 #pragma unroll
             for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
-            double2 u[DC_GCAP / SL];
-            int t[DC_GCAP / SL];
+            double2 u[GPL];
+            int t[GPL];
 #pragma unroll
-            for (int j = 0; j < DC_GCAP / SL; ++j) {       // all of the lane's samples in flight at once
+            for (int j = 0; j < GPL; ++j) {       // all of the lane's samples in flight at once
                 const int e = gr.b + sub + SL * j;
                 const bool ok = e < gr.e;
                 u[j] = ulds[ok ? e : 0]; t[j] = tlds[ok ? e : 0];
                 if (!ok) u[j] = make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int j = 0; j < DC_GCAP / SL; ++j) {
+            for (int j = 0; j < GPL; ++j) {
 #pragma unroll
                 for (int c = 0; c < DC_MAXS; ++c) {
                     const double v = vlds[t[j] * s + c];   // (c >= s reads a neighbour: finite garbage into unused sums)
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_b(OpDev op, KsDev ks) {
                 }
             }
 #pragma unroll
-            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group8_sum(xr[c]); xi[c] = group8_sum(xi[c]); }
+            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group_sum<SL>(xr[c]); xi[c] = group_sum<SL>(xi[c]); }
             if (sub == 0) {
 #pragma unroll
                 for (int c = 0; c < DC_MAXS; ++c) part[gi * DC_MAXS + c] = mk(xr[c], xi[c]);
@@ -551,7 +554,7 @@ __device__ __forceinline__ void ks_tell_host(LsqrState* h, unsigned seq) {
 
 template <class CP>
 __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop, int* sticky) {
-    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ;
+    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ, SL = CP::SL, GPL = CP::GCAP / CP::SL;   // (GPL: a group's samples per lane)
     __shared__ cd vl[CP::SCAP * DC_MAXS];                  // v of the unit's slots, [slot][c]   (k_ks_a)
     __shared__ double2 ulds[CP::ECAP];                     // u(1:m) of the unit's samples        (k_ks_b)
     __shared__ cd part[CP::GCAPB * DC_MAXS];
@@ -693,17 +696,17 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
                 double xr[DC_MAXS], xi[DC_MAXS];
 #pragma unroll
                 for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
-                double2 u[DC_GCAP / SL];
-                int t[DC_GCAP / SL];
+                double2 u[GPL];
+                int t[GPL];
 #pragma unroll
-                for (int j = 0; j < DC_GCAP / SL; ++j) {
+                for (int j = 0; j < GPL; ++j) {
                     const int e = gr.b + sub + SL * j;
                     const bool okk = e < gr.e;
                     u[j] = ulds[okk ? e : 0]; t[j] = tlds[okk ? e : 0];
                     if (!okk) u[j] = make_double2(0.0, 0.0);
                 }
 #pragma unroll
-                for (int j = 0; j < DC_GCAP / SL; ++j) {
+                for (int j = 0; j < GPL; ++j) {
 #pragma unroll
                     for (int c = 0; c < DC_MAXS; ++c) {
                         const double v = vlds[t[j] * s + c];
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group8_sum(xr[c]); xi[c] = group8_sum(xi[c]); }
+                for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group_sum<SL>(xr[c]); xi[c] = group_sum<SL>(xi[c]); }
                 if (sub == 0) {
 #pragma unroll
                     for (int c = 0; c < DC_MAXS; ++c) part[gi * DC_MAXS + c] = mk(xr[c], xi[c]);
@@ -949,6 +952,7 @@ int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, int caps, bool* ok
     switch (caps) {
         case 1: return lds_fits_c<Caps1>(ctx, N, s, M, vcap, ok);
         case 2: return lds_fits_c<Caps2>(ctx, N, s, M, vcap, ok);
+        case 3: return lds_fits_c<Caps3>(ctx, N, s, M, vcap, ok);
         default: return lds_fits_c<Caps0>(ctx, N, s, M, vcap, ok);
     }
 }
@@ -967,6 +971,7 @@ static int ks_attrs(qmri_ctx* ctx, int caps) {
     QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 4, false>)); QMRI_TRY(allow_big_lds(ctx, (const void*)k_ks_init_a<8, 4, true>));
     if (caps == 1) QMRI_TRY(ks_attrs_c<Caps1>(ctx));
     else if (caps == 2) QMRI_TRY(ks_attrs_c<Caps2>(ctx));
+    else if (caps == 3) QMRI_TRY(ks_attrs_c<Caps3>(ctx));
     else QMRI_TRY(ks_attrs_c<Caps0>(ctx));
     ctx->ks_lds_attr[0] = true;
     return QMRI_OK;
@@ -976,6 +981,7 @@ static int ks_attrs(qmri_ctx* ctx, int caps) {
     do {                                                                             \
         if ((caps_) == 1) { typedef Caps1 CP; CALL; }                                \
         else if ((caps_) == 2) { typedef Caps2 CP; CALL; }                           \
+        else if ((caps_) == 3) { typedef Caps3 CP; CALL; }                           \
         else { typedef Caps0 CP; CALL; }                                             \
     } while (0)
 

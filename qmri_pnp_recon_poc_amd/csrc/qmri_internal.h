@@ -73,7 +73,6 @@ struct KEntry {          // one sample of the k-sorted measurement list
     uint16_t t;          // frame
 };
 
-constexpr int DC_GCAP = 32;          // samples per scatter group of the k-space LSQR
 
 struct OpDev {
     int N, M, s, T, m;
@@ -90,11 +89,17 @@ struct OpDev {
 // k-space LSQR (kslsqr_kernels.hip): work partition over the sampled k locations ("slots", k' order)
 // ---------------------------------------------------------------------------------------------------
 struct KSample { uint16_t ls, t; };              // slot of a sample relative to its block's first slot; frame
-struct KsGroup { uint16_t ls, b, e, pad; };      // <= DC_GCAP samples of one slot; b, e relative to the block's first sample
-// capacities of a work unit: slots, samples, scatter groups (= ecap / DC_GCAP + scap) per block.  Three shapes, picked when the operator is
-// planned (api_core.cpp) so that a single slice's units fit the chip at once; kslsqr_kernels.hip instantiates its kernels for each (KsCaps)
-struct KsCapsHost { int scap, ecap, gcapb; };
-constexpr KsCapsHost KS_CAPS[3] = {{64, 1024, 96}, {256, 1024, 288}, {64, 2560, 144}};
+struct KsGroup { uint16_t ls, b, e, pad; };      // <= gcap samples of one slot; b, e relative to the block's first sample
+// The shape of a work unit: slots, samples, samples per scatter group, lanes that share a group, scatter groups per block (= ecap / gcap + scap).
+// Picked when the operator is planned (api_core.cpp); kslsqr_kernels.hip instantiates its kernels for each (KsCaps):
+//   0  dense masks (a sampled k location carries >= 8 samples on average: the spiral), slice batches and single slices whose units fit the chip
+//   1  sparse masks (EPI: every k location, 2.7 samples each), ONE slice: 256 slots per unit so that <= 250 units result (one-launch iteration)
+//   2  dense, very many samples per k (cut0: 56), ONE slice: 2560 samples per unit, <= 256 units (one-launch iteration)
+//   3  sparse masks, slice batches (and whatever 1 does not fit): small units
+// Sparse shapes give every scatter group (<= 4 samples of one slot) to ONE lane; the dense ones share a group of <= 32 samples among 8 lanes.
+struct KsCapsHost { int scap, ecap, gcap, sl, gcapb; };
+constexpr KsCapsHost KS_CAPS[4] = {{64, 1024, 32, 8, 96}, {256, 768, 4, 1, 448}, {64, 2560, 32, 8, 144}, {64, 256, 4, 1, 128}};
+constexpr int KS_NCAPS = 4;
 struct KsUnit { int32_t s0, s1, e0, e1, g0, g1, pad0, pad1; };   // a work unit: its slots, samples and groups (one 32-byte scalar load)
 struct LsqrState;
 struct KsDev {
