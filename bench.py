@@ -276,7 +276,9 @@ def xupdate_roofline(pr, ns, s, m, B, one_launch):
     li = max(pr["lsqr_iters"], 1)                                   # summed over slices
     byt = xupdate_bytes_per_lsqr_iteration(ns, s, m)
     out = {"lsqr_iters_per_xupdate": round(pr["lsqr_iters"] / it / B, 2), "bytes_per_lsqr_iteration_per_slice": byt,
-           "form": "k_ks_persist: all iterations of a solve in one launch, the iteration's state on chip" if one_launch else
+           "form": ("k_ks_persist: all iterations of a solve in one launch, the iteration's state on chip" +
+                    ("; the slices of a batch go through it as many per launch as are resident together (EPI: one, the spiral: two)" if B > 1 else ""))
+                   if one_launch else
                    "two launches per LSQR iteration (k_ks_a, k_ks_b), the state streams through HBM / Infinity Cache"}
     if pr["n_lsqr_launches"] > 0 and pr["ms_lsqr_kernels"] > 0:
         # per LSQR iteration of the whole batch: the iteration kernels' own dispatch timestamps; iterations = the slowest slice's count summed over

@@ -355,9 +355,10 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         // Units of similar sample count, about one per CU.  The one-launch iteration (k_ks_persist) is paced by its slowest workgroup, and two
         // workgroups that share a CU are the slow ones: where the caps allow, the cut is repeated with fewer, larger units until at most
         // 250 result (263 at the headline operator with the first cut: 7 CUs held two).
-        // Round 5: three unit shapes (KS_CAPS).  A mask that samples every k a few times (EPI: 784 units of the first shape) or few k very often
-        // (cut0: 604) gets the shape under which <= 250 units result, so that a single slice runs the one-launch iteration too.  Plans for slice
-        // batches keep the first shape: their grids (units x slices) never fit the chip at once, and small units fill it more evenly.
+        // Round 5: four unit shapes (KS_CAPS).  A mask that samples every k a few times (EPI: 784 units of the first shape) or few k very often
+        // (cut0: 604) gets the shape under which <= 256 units result, so that a slice runs the one-launch iteration too -- a slice batch as
+        // well, a slice or two per launch (ks_launch_persist).  With the one-launch iteration switched off, plans for slice batches keep the
+        // small shapes: their grids (units x slices) never fit the chip at once, and small units fill it more evenly.
         auto cut = [&](const KsCapsHost& cp) -> int {
             int want = 256;
             for (int attempt = 0; attempt < 8; ++attempt, want -= 8) {
@@ -397,7 +398,8 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         ks.caps = base;
         int nunits = cut(KS_CAPS[base]);
         if (sparse && nunits < 0) { base = 0; ks.caps = 0; nunits = cut(KS_CAPS[0]); }      // (sparse on average with one very busy location: the dense shape)
-        if (max_batch == 1 && s == 10 && (nunits > 320 || nunits < 0)) {
+        const bool one_launch = ctx->ks_persist != 0 && (ctx->ks_persist > 0 || qmri_knob(K_LSQR_PERSIST));
+        if ((max_batch == 1 || one_launch) && s == 10 && (nunits > 320 || nunits < 0)) {
             int ncu = 0;                                   // (the larger shapes run one workgroup per CU: every unit needs a CU of its own)
             QMRI_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
             const int order[2] = {sparse ? 1 : 2, sparse ? 2 : 1};
@@ -414,7 +416,7 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
         bslot.push_back(ns);
         gptr.push_back((int32_t)grp.size());
         sgrp[ns] = (int32_t)grp.size();
-        ks.ns = ns; ks.G = (int)bslot.size() - 1;
+        ks.ns = ns; ks.G = (int)bslot.size() - 1; ks.b0 = 0;
         bool v_fits = false;
         QMRI_TRY(ks_lds_fits(ctx, N, s, M, ks.vcap, ks.caps, &v_fits));
         if (!v_fits) {     // T = 1000, s = 10 (cut0, main_recon_tsmis_FFT.m:41-44) needs 80 KB of the CU's 160 KB; T*s <~ 14 900 fits

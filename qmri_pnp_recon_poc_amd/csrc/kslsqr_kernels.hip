@@ -565,7 +565,7 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
     extern __shared__ __align__(16) unsigned char smem[];
     double* vlds = (double*)smem;
     constexpr int s = DC_MAXS;                             // (the launcher requires op.s == DC_MAXS, the reference's 10 channels: row pitches become constants)
-    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y, G = ks.G;
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y + ks.b0, G = ks.G;
     LsqrState* st = ks.st + b;
     // (a spin of an EARLIER launch of this context timed out: nothing of this launch can be trusted to complete either -- requested here with
     //  the other operands, looked at below)
@@ -1023,10 +1023,13 @@ int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
     return QMRI_OK;
 }
 
-// All iterations in one launch (k_ks_persist).  *ran = false when the grid would not be resident at once, or the option is off:
-// the caller then iterates with ks_launch_iter.
-int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran) {
+// All iterations in one launch (k_ks_persist).  *ran = false when not even one slice's units would be resident at once, or the option is off:
+// the caller then iterates with ks_launch_iter.  Round 5: a slice batch goes through the kernel as many slices at a time as are resident
+// together (EPI: 250 one-per-CU units = one slice; the spiral: 2 x 250 two-per-CU units = two slices), launch after launch on the stream:
+// the state of a solve then never leaves the registers, where the two-launch iteration moves 66 - 80 MB per slice and iteration.
+int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks_in, int B, void* gran, unsigned tag0, bool* ran) {
     *ran = false;
+    KsDev ks = ks_in;
     if (ks.G > KS_GRAN_MAXG || ks.maxit < 1 || op.s != DC_MAXS) return QMRI_OK;    // (the kernel is written for the reference's s = 10)
     const size_t vb = (size_t)ks.vcap * 8;
     if (ctx->ks_persist_cap < 0) {
@@ -1044,15 +1047,24 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, vo
         // (MI355X_MICROARCH.md, "Residency and cooperative launch"); a kernel can use at most 102 SGPRs + VCC, i.e. >= 6 by that term
         ctx->ks_persist_cap = std::min(nb, 6) * ncu;
     }
-    if ((long)ks.G * B > ctx->ks_persist_cap) return QMRI_OK;
+    const int per_launch = std::min(B, ctx->ks_persist_cap / ks.G);
+    if (per_launch < 1) return QMRI_OK;
     KsGran* gu = (KsGran*)gran;
     KsGran* gv = gu + (size_t)B * 4 * ks.G;
     int* sticky = (int*)(gu + (size_t)ctx->op.maxB * 6 * ks.G);                         // (the word behind the granules: ks_gran_bytes)
     hipEvent_t e0 = nullptr, e1 = nullptr;                          // profile level 2: the whole solve's iterations as one unit
     QMRI_TRY(qmri_prof_pair(ctx, &e0, &e1, PROF_LSQR));
     const int drop = ctx->ks_persist == 2 ? 1 : 0;
-    if (e0) KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_persist<CP>), dim3(ks.G, B), dim3(KT), (std::uint32_t)vb, ctx->stream, e0, e1, 0, op, ks, gu, gv, tag0, drop, sticky)));
-    else KS_BY_CAPS(ks.caps, (k_ks_persist<CP><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, drop, sticky)));
+    for (int b0 = 0; b0 < B; b0 += per_launch) {
+        const int nb = std::min(per_launch, B - b0);
+        ks.b0 = b0;
+        if (e0) {
+            hipEvent_t ea = b0 == 0 ? e0 : nullptr, eb = b0 + nb >= B ? e1 : nullptr;
+            KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_persist<CP>), dim3(ks.G, nb), dim3(KT), (std::uint32_t)vb, ctx->stream, ea, eb, 0, op, ks, gu, gv, tag0, drop, sticky)));
+        } else {
+            KS_BY_CAPS(ks.caps, (k_ks_persist<CP><<<dim3(ks.G, nb), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, drop, sticky)));
+        }
+    }
     QMRI_HIP(ctx, hipGetLastError());
     *ran = true;
     return QMRI_OK;

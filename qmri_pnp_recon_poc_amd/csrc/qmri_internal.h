@@ -123,6 +123,7 @@ struct KsDev {
     double* pdiag;                               // [B][N] partial ||y - A x||^2 or null
     double sr, tol;
     int maxit, ii, vcap;
+    int b0;                                      // k_ks_persist: first slice of this launch (a batch goes through it a few slices at a time)
     unsigned long long* stamps;
 };
 

@@ -287,6 +287,22 @@ class Engine:
         return (x.reshape((self.N, self.M, self.s), order="F"),
                 diag[: 2 * iters].reshape(iters, 2) if diag is not None else None, li[:iters])
 
+    def pnp_admm_batch(self, ys, slices_per_launch=15, gamma=0.05, iters=100, cg_tol=1e-4, cg_maxit=100, solver="lsqr", multi_level=False,
+                       noise_std=0.01):
+        """A slice stack ys [S, m] through this context, slices_per_launch at a time (qmri_pnp_admm_batch; what `PnP_ADMM_hip(Y, param)` calls
+        for a measurement matrix).  Returns (X [S,N,M,s] complex, lsqr_iters [S, iters])."""
+        p = AdmmParams(float(gamma), int(iters), float(cg_tol), int(cg_maxit), SOLVER_LSQR if solver == "lsqr" else SOLVER_DIRECT,
+                       int(bool(multi_level)), float(noise_std), 0)
+        yb = np.ascontiguousarray(np.asarray(ys, np.complex128))
+        if yb.ndim != 2 or yb.shape[1] != self.m:
+            raise ValueError(f"ys must be [slices, {self.m}]")
+        S, n = yb.shape[0], self.N * self.M * self.s
+        x = np.empty((S, n), np.complex128)
+        li = np.zeros((S, max(iters, 1)), np.int32)
+        self._check(self.L.qmri_pnp_admm_batch(self.h, S, int(slices_per_launch), _vp(yb), C.byref(p), None, None, _vp(x), None,
+                                               li.ctypes.data_as(C.POINTER(C.c_int32))))
+        return np.stack([x[i].reshape((self.N, self.M, self.s), order="F") for i in range(S)]), li[:, :iters]
+
     # -- dictionary ----------------------------------------------------------------------------------
     def set_dictionary(self, D, normD, lut):
         D = real_dictionary_array(D, "dict.D", np.float32)

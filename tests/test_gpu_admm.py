@@ -195,6 +195,36 @@ def test_config2_epi_multi_level_batch_of_15_every_slice(engine_mod, oracle, syn
     print(f"config2, 15 slices together: worst rel_err vs oracle {worst:.2e}")
 
 
+@pytest.mark.parametrize("mask", ["epi", "spiral"])
+def test_slice_batches_solve_with_the_one_launch_lsqr_a_slice_or_two_at_a_time(engine_mod, oracle, synth, case224, mask):
+    """Round 5: the x-update of a slice BATCH goes through the one-launch LSQR kernel too -- as many slices per launch as are resident together
+    (EPI: one slice's <= 256 one-per-CU units; the spiral: two slices), launch after launch (ks_launch_persist) -- instead of two launches per
+    iteration over all slices.  Same arithmetic on the same work units: x of every slice and every LSQR count IDENTICAL to a run of the
+    same plan with the two-launch iteration; each slice equal to the oracle's count and to 1e-4 in x.  5 slices: an odd number, so the spiral's last launch holds one slice."""
+    dic = case224["dic"]
+    fp, k = (oracle.epi_mask(224, 224, 1 / 65, 200) if mask == "epi" else (case224["fp"], case224["k"]))
+    op = oracle.Operator(224, 224, dic["V"], fp, k)
+    w = synth.structured_weights(seed=2, eps=0.3)
+    nsl, iters = 5, 3
+    ys = np.stack([synth.awgn_measured(op.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(224, seed=70 + sl), dic)), 30.0, seed=70 + sl)
+                   for sl in range(nsl)])
+    out = {}
+    for on in (1, 0):
+        e = engine_mod.Engine(0)
+        e.set_operator(224, 224, dic["V"], fp, k, max_batch=nsl)
+        e.set_denoiser(w, 224, 224, max_batch=nsl)
+        e.lsqr_persist(bool(on))                                         # (after the plan: both runs work on the same units)
+        out[on] = e.pnp_admm_batch(ys, slices_per_launch=nsl, iters=iters)
+        e.close()
+    assert np.array_equal(out[1][1], out[0][1]), (out[1][1], out[0][1])
+    assert np.array_equal(out[1][0], out[0][0]), rel_err(out[1][0], out[0][0])
+    net = oracle.Net(w)
+    for sl in (0, nsl - 1):
+        xo, _, lo = oracle.pnp_admm(op, net, ys[sl], iters=iters)
+        assert np.array_equal(out[1][1][sl], np.asarray(lo).ravel()[:iters]), (sl, out[1][1][sl], lo)
+        assert rel_err(out[1][0][sl], xo) < 1e-4
+
+
 def test_config3_thirty_slices_two_workers_224(engine_mod, oracle, synth, case224):
     """BASELINE.json configs[3] at size on one device: 30 cut3 slices at 224 x 224 through qmri_recon_batch with TWO workers (host thread +
     context each; one per GPU on a node, both on device 0 here), 8 slices per launch, 2 ADMM iterations + dictionary match.  Every
