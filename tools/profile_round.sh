@@ -18,8 +18,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write1
 cd $R
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_conv_traffic.txt || echo "pmc_traffic failed"
 python3 tools/pmc_traffic.py --batch 15 $OUT/pmc_fetch15 $OUT/pmc_write15 $OUT/pmc_conv_traffic_batch15.txt || echo "pmc_traffic (batch) failed"
-bash tools/pmc_conv.sh 1 gpurun_out/prof_$TAG/pmc_conv_mfma_busy_single.txt > /dev/null 2>&1 || echo "pmc_conv 1 failed"
-bash tools/pmc_conv.sh 15 gpurun_out/prof_$TAG/pmc_conv_mfma_busy_batch15.txt > /dev/null 2>&1 || echo "pmc_conv 15 failed"
+bash tools/pmc_conv.sh 1 gpurun_out/prof_$TAG/pmc_conv_mfma_busy_single.txt < /dev/null > /dev/null 2>&1 || echo "pmc_conv 1 failed"
+bash tools/pmc_conv.sh 15 gpurun_out/prof_$TAG/pmc_conv_mfma_busy_batch15.txt < /dev/null > /dev/null 2>&1 || echo "pmc_conv 15 failed"
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +5M -delete
 ls -R $OUT | head -60
