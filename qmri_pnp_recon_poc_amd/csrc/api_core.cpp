@@ -25,7 +25,7 @@ const KnobDef g_knob_defs[K_COUNT] = {
     {"conv_resident", 1}, {"res_head", 1}, {"res_tail", 1}, {"res_down", 1}, {"res_delay", 24}, {"res_rearm", 64},
     {"res_stamps", 0}, {"conv_stamps", 0}, {"conv_stamp_launch", -1}, {"lsqr_stamps", 0},
     {"conv_mt2", 1024}, {"conv_occ", 2},
-    {"fuse_ew", 1}, {"lsqr_persist", 1}, {"dictw_lsp", 2}, {"verbose", 0},
+    {"fuse_ew", 1}, {"lsqr_persist", 1}, {"lsqr_fold", 1}, {"dictw_lsp", 2}, {"verbose", 0},
 };
 std::atomic<int> g_knob_val[K_COUNT];
 std::once_flag g_knob_once;
@@ -701,7 +701,13 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     if (!o.xhat_valid) QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_SPECTRUM, B, d_x, o.d_tmp, ks.xhat, nullptr));
     if (z_fused) ks.nblk_z = fuse->z_hpass_nblk;
     else QMRI_TRY(dc_launch_fwd(ctx, op, o.ls, DC_FWD_H_ONLY, B, d_z, o.d_tmp, nullptr, nullptr));
-    QMRI_TRY(ks_launch_init(ctx, op, ks, B, o.d_tmp));                  // w-pass of z (-> ks.zhat) + first Golub-Kahan vectors
+    // Round 5: when the one-launch kernel will run, it takes the first Golub-Kahan step (beta0, v = B'u / beta0, d = 0) itself -- k_ks_b<INIT>
+    // is not launched, v and d never exist in memory (knob lsqr_fold = 0: the separate launch, same bits)
+    if (ctx->ks_persist < 0) ctx->ks_persist = qmri_knob(K_LSQR_PERSIST) ? 1 : 0;
+    int per_launch = 0;
+    if (ctx->ks_persist > 0 && maxit >= 1) QMRI_TRY(ks_persist_plan(ctx, op, ks, B, &per_launch));
+    const bool fold = per_launch > 0 && qmri_knob(K_LSQR_FOLD) != 0;
+    QMRI_TRY(ks_launch_init(ctx, op, ks, B, o.d_tmp, !fold));           // w-pass of z (-> ks.zhat) + first Golub-Kahan vectors
     // The predicted number of iterations is launched, then -- speculatively -- the kernels that turn the solution back into
     // an image.  The host waits only for the copy of the LSQR state (an event between the two), so the device keeps working
     // while the host wakes up and enqueues the next stage.  If a slice was not done yet (rare: counts fall from one x-update
@@ -711,15 +717,14 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
     // two sums per iteration are in-kernel hand-offs instead of kernel boundaries); the two-launch iteration otherwise (EPI masks,
     // cut0, slice batches) and after a time-out of the persistent kernel (never seen; the inputs are untouched then).
     bool persisted = false;
-    if (ctx->ks_persist < 0) ctx->ks_persist = qmri_knob(K_LSQR_PERSIST) ? 1 : 0;
-    if (ctx->ks_persist > 0 && maxit >= 1) {
+    if (per_launch > 0) {
         if (!ctx->d_ks_gran) {
             const size_t nb = ks_gran_bytes(ks.G, o.maxB);
             QMRI_HIP(ctx, hipMalloc(&ctx->d_ks_gran, nb));
             QMRI_HIP(ctx, hipMemsetAsync(ctx->d_ks_gran, 0, nb, ctx->stream));      // (tag 0 is never used)
         }
         const unsigned tag0 = ctx->ks_tag;
-        QMRI_TRY(ks_launch_persist(ctx, op, ks, B, ctx->d_ks_gran, tag0, &persisted));
+        QMRI_TRY(ks_launch_persist(ctx, op, ks, B, ctx->d_ks_gran, tag0, fold, &persisted));
         if (persisted) {
             ctx->ks_tag += 2u * (unsigned)(maxit + 2);
             QMRI_TRY(ks_launch_final(ctx, op, ks, B, o.d_tmp));

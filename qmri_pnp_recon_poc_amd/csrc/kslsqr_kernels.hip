@@ -190,7 +190,8 @@ __global__ __launch_bounds__(KT) void k_ks_init_a(OpDev op, KsDev ks, const doub
         ks.pinit[(size_t)b * 2 * N + kh] = accS;
         ks.pinit[(size_t)b * 2 * N + N + kh] = accT;
         ks.pR[(size_t)b * N + kh] = r;
-    }
+        if (kh == 0) ks.st[b].pad = 0;                      // (77: a workgroup of k_ks_persist gave up on this solve -- a new solve starts clean,
+    }                                                       //  whichever kernel takes the first Golub-Kahan step)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -552,9 +553,50 @@ __device__ __forceinline__ void ks_tell_host(LsqrState* h, unsigned seq) {
     if (h) __hip_atomic_store(&h->pad, (int32_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// sum_t V(t,c) u(t,k) per scatter group of a unit (k_ks_persist; the same statements as k_ks_b's): SL lanes share a group's samples, fixed tree
 template <class CP>
-__global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop, int* sticky) {
-    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ, SL = CP::SL, GPL = CP::GCAP / CP::SL;   // (GPL: a group's samples per lane)
+__device__ __forceinline__ void ks_group_sums(int tid, int ng, const KsGroup (&rg)[CP::NGQ], const double2* ulds, const unsigned short* tlds,
+                                              const double* vlds, cd* part) {
+    constexpr int NGQ = CP::NGQ, SL = CP::SL, GPL = CP::GCAP / CP::SL, s = DC_MAXS;
+#pragma unroll
+    for (int q = 0; q < NGQ; ++q) {
+        const int gi = (tid + KT * q) / SL, sub = tid & (SL - 1);
+        if (gi < ng) {
+            const KsGroup gr = rg[q];
+            double xr[DC_MAXS], xi[DC_MAXS];
+#pragma unroll
+            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
+            double2 u[GPL];
+            int t[GPL];
+#pragma unroll
+            for (int j = 0; j < GPL; ++j) {
+                const int e = gr.b + sub + SL * j;
+                const bool okk = e < gr.e;
+                u[j] = ulds[okk ? e : 0]; t[j] = tlds[okk ? e : 0];
+                if (!okk) u[j] = make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < GPL; ++j) {
+#pragma unroll
+                for (int c = 0; c < DC_MAXS; ++c) {
+                    const double v = vlds[t[j] * s + c];
+                    xr[c] += v * u[j].x; xi[c] += v * u[j].y;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group_sum<SL>(xr[c]); xi[c] = group_sum<SL>(xi[c]); }
+            if (sub == 0) {
+#pragma unroll
+                for (int c = 0; c < DC_MAXS; ++c) part[gi * DC_MAXS + c] = mk(xr[c], xi[c]);
+            }
+        }
+    }
+}
+
+template <class CP>
+__global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks, KsGran* gu_all, KsGran* gv_all, unsigned tag0, int test_drop, int* sticky,
+                                                             int init_here) {
+    constexpr int NEQ = CP::NEQ, NSQ = CP::NSQ, NGQ = CP::NGQ, SL = CP::SL;
     __shared__ cd vl[CP::SCAP * DC_MAXS];                  // v of the unit's slots, [slot][c]   (k_ks_a)
     __shared__ double2 ulds[CP::ECAP];                     // u(1:m) of the unit's samples        (k_ks_b)
     __shared__ cd part[CP::GCAPB * DC_MAXS];
@@ -582,7 +624,9 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
 #pragma unroll
     for (int q = 0; q < NEQ; ++q) {
         const int i = (tid + KT * q < ne) ? tid + KT * q : 0;
-        rcv[q] = ks.cv[cb + i]; rub[q] = ks.cub[cb + i]; rd[q] = ks.cd[cb + i]; rx[q] = ks.cx[cb + i];
+        rub[q] = ks.cub[cb + i]; rx[q] = ks.cx[cb + i];
+        if (!init_here) { rcv[q] = ks.cv[cb + i]; rd[q] = ks.cd[cb + i]; }
+        else { rcv[q] = make_double2(0.0, 0.0); rd[q] = make_double2(0.0, 0.0); }      // (d = 0: k_ks_b<INIT>)
     }
     KSample res[NSQ];
     double2 rut[NSQ];
@@ -600,9 +644,12 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
     for (int q = 0; q < NGS; ++q) { const int i = tid + KT * q; rsg[q] = ks.sgrp[s0 + ((i <= nsl) ? i : 0)] - g0; }
     double rv[NVQ];
     load_v(op, rv);
-    LsqrScalars O = st->sc[0];                                      // written by k_ks_b<INIT>
-    const double R = st->R, tolb = st->tolb, sr = ks.sr;
-    if (st->done) {                                                 // x0 already exact, or b = 0 (uniform over the grid)
+    LsqrScalars O;
+    double R = 0.0, tolb = 0.0;
+    const double sr = ks.sr;
+    const double ny2 = st->ny2;
+    if (!init_here) { O = st->sc[0]; R = st->R; tolb = st->tolb; }  // written by k_ks_b<INIT>
+    if (!init_here && st->done) {                                   // x0 already exact, or b = 0 (uniform over the grid)
         if (g == 0 && tid == 0 && ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = st->flag; h->iter = st->iter; ks_tell_host(h, tag0); }
         return;
     }
@@ -611,16 +658,68 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
         return;
     }
     if (tid < 64) {
-        const double pa0 = wave_sum(ks.pv[0] + (size_t)b * G, G);   // |v|^2 partials of the INIT launch (plain: another kernel's output)
-        if (tid == 0) red[0] = pa0;
+        if (!init_here) {
+            const double pa0 = wave_sum(ks.pv[0] + (size_t)b * G, G);   // |v|^2 partials of the INIT launch (plain: another kernel's output)
+            if (tid == 0) red[0] = pa0;
+        } else {                                                    // the sums k_ks_b<INIT> takes from k_ks_init_a's partials
+            const double pa = wave_sum(ks.pinit + (size_t)b * 2 * op.N, 2 * op.N);
+            const double pb = wave_sum(ks.pR + (size_t)b * op.N, op.N);
+            const double pc = wave_sum(ks.pz + (size_t)b * ks.nblk_z, ks.nblk_z);
+            if (tid == 0) { red[0] = pa; red[1] = pb; red[2] = pc; }
+        }
     }
 #pragma unroll
-    for (int q = 0; q < NSQ; ++q) { const int j = tid + KT * q; if (j < nsamp) tlds[j] = res[q].t; }
+    for (int q = 0; q < NSQ; ++q) { const int j = tid + KT * q; if (j < nsamp) { tlds[j] = res[q].t; if (init_here) ulds[j] = rut[q]; } }
 #pragma unroll
     for (int q = 0; q < NGS; ++q) { const int i = tid + KT * q; if (i <= nsl) sgl[i] = rsg[q]; }
     if (tid == 0) abort_flag = 0;
     store_v(op, rv, vlds);
     const bool writer = g == 0 && tid == 0;
+    if (init_here) {
+        // ---- the first Golub-Kahan step, k_ks_b<INIT>'s arithmetic in k_ks_b<INIT>'s order: beta0, v = B'u / beta0, d = 0 -- in this launch, so that
+        // v and d never exist in memory and the solve is one launch less (round 5).  Scalars: every workgroup, identical bits.
+        lds_barrier();
+        const double pa = red[0], pc = red[2];
+        R = red[1];
+        const double beta0 = sqrt(pa + (sr * sr) * R);
+        const double n2b = sqrt(ny2 + sr * sr * pc);
+        const bool fin = (beta0 == 0.0 || n2b == 0.0);             // x0 already exact, or b = 0
+        O.c = 1.0; O.s = 0.0; O.phibar = beta0; O.normr = beta0; O.norma = 0.0; O.factor = beta0;
+        O.thet = 0.0; O.rho = 1.0; O.phi = 0.0; O.beta = beta0; O.alpha = 0.0;
+        O.ua = fin ? 0.0 : (sr * (1.0 / beta0)) * sr;
+        O.ub = sr; O.uc = 0.0; O.ue = 0.0;
+        tolb = ks.tol * n2b;
+        if (writer) {
+            st->sc[0] = O; st->R = R; st->ue_final = 0.0; st->n2b = n2b; st->tolb = tolb;
+            st->iter = fin ? 0 : ks.maxit; st->flag = fin ? 0 : 1; st->done = fin ? 1 : 0;
+            if (fin) {
+                if (ks.hst) { LsqrState* h = ks.hst + b; h->done = 1; h->flag = 0; h->iter = 0; }
+                ks_tell_host(ks.hst ? ks.hst + b : nullptr, tag0);
+            }
+        }
+        if (fin) return;
+        const double inv_beta0 = 1.0 / beta0;
+        ks_group_sums<CP>(tid, ng, rg, ulds, tlds, vlds, part);
+        lds_barrier();
+        double acc0 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NEQ; ++q) {
+            const int i = tid + KT * q;
+            if (i < ne) {
+                const int ls = i / s, c = i - ls * s;
+                double qx = 0.0, qy = 0.0;
+                for (int gi = sgl[ls]; gi < sgl[ls + 1]; ++gi) { const cd pp = part[gi * DC_MAXS + c]; qx += pp.x; qy += pp.y; }
+                const double vx = qx * inv_beta0, vy = qy * inv_beta0;
+                const double2 ub = rub[q];
+                const double2 vr = make_double2(vx + (ub.x * inv_beta0) * sr, vy + (ub.y * inv_beta0) * sr);     // v = A'*u(1:m) + sqrt(r) u(m+1:end)
+                rcv[q] = vr;
+                acc0 += vr.x * vr.x + vr.y * vr.y;
+            }
+        }
+        const double tot0 = block_sum(acc0, red + 4);
+        if (tid == 0) gran_store(gv[0] + g, tot0, tag0 + 1u);      // (iteration 1 reads parity 0 with tag0 + 1: the slot iteration "0" would have used)
+        lds_barrier();                                              // (part / ulds / red are rewritten by the first iteration)
+    }
     double ue_final = 0.0;
     int conv_iter = -1;
     bool aborted = false;
@@ -651,7 +750,7 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
             }
         }
         PS(1);
-        if (ii > 1 && tid < 64) {                                   // |v|^2 of the previous iteration: all-reduce over the slice's workgroups
+        if ((ii > 1 || init_here) && tid < 64) {                    // |v|^2 of the previous iteration (or of the first step above): all-reduce over the slice's workgroups
             double pa;
             const bool ok = gran_sum<(KS_GRAN_MAXG + 63) / 64>(gv[(ii - 1) & 1], G, tagB - 2u, pa);
             if (tid == 0) { red[0] = pa; if (!ok) abort_flag = 1; }
@@ -688,39 +787,7 @@ __global__ __launch_bounds__(KT, CP::MINW) void k_ks_persist(OpDev op, KsDev ks,
         if (tid == 0 && !(test_drop && g == 1 && ii == 2)) { gran_store(gu[ii & 1] + g, acc_b, tagA); gran_store(gu[ii & 1] + G + g, acc_t, tagA); }
         // ================= k_ks_b: what does not need beta first -- sum_t V(t,c) u(t,k) per scatter group =================
         // (block_sum2's barriers follow the stores into ulds)
-#pragma unroll
-        for (int q = 0; q < NGQ; ++q) {
-            const int gi = (tid + KT * q) / SL, sub = tid & (SL - 1);
-            if (gi < ng) {
-                const KsGroup gr = rg[q];
-                double xr[DC_MAXS], xi[DC_MAXS];
-#pragma unroll
-                for (int c = 0; c < DC_MAXS; ++c) { xr[c] = 0.0; xi[c] = 0.0; }
-                double2 u[GPL];
-                int t[GPL];
-#pragma unroll
-                for (int j = 0; j < GPL; ++j) {
-                    const int e = gr.b + sub + SL * j;
-                    const bool okk = e < gr.e;
-                    u[j] = ulds[okk ? e : 0]; t[j] = tlds[okk ? e : 0];
-                    if (!okk) u[j] = make_double2(0.0, 0.0);
-                }
-#pragma unroll
-                for (int j = 0; j < GPL; ++j) {
-#pragma unroll
-                    for (int c = 0; c < DC_MAXS; ++c) {
-                        const double v = vlds[t[j] * s + c];
-                        xr[c] += v * u[j].x; xi[c] += v * u[j].y;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < DC_MAXS; ++c) { xr[c] = group_sum<SL>(xr[c]); xi[c] = group_sum<SL>(xi[c]); }
-                if (sub == 0) {
-#pragma unroll
-                    for (int c = 0; c < DC_MAXS; ++c) part[gi * DC_MAXS + c] = mk(xr[c], xi[c]);
-                }
-            }
-        }
+        ks_group_sums<CP>(tid, ng, rg, ulds, tlds, vlds, part);
         PS(4);
         if (tid < 64) {                                             // |u|^2: all-reduce
             double pb;
@@ -987,7 +1054,7 @@ static int ks_attrs(qmri_ctx* ctx, int caps) {
 
 // residual + first Golub-Kahan vectors; ks.xhat / ks.zhat hold the unitary spectra of x0 and z
 // hpass_tmp (nullable): the h-pass output of z's transform; the launch then also runs the w-pass and writes ks.zhat (k_ks_init_a<FWDW>)
-int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp) {
+int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp, bool first_step) {
     QMRI_TRY(ks_attrs(ctx, ks.caps));
     const size_t vb = (size_t)ks.vcap * 8;
 #define KS_INIT(R1_, R2_)                                                                                                       \
@@ -1002,7 +1069,8 @@ int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const
         default: KS_INIT(8, 4); break;
     }
 #undef KS_INIT
-    KS_BY_CAPS(ks.caps, (k_ks_b<CP, true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks)));
+    // (first_step = false: k_ks_persist takes the first Golub-Kahan step itself, ks_launch_persist(..., init_here = true))
+    if (first_step) KS_BY_CAPS(ks.caps, (k_ks_b<CP, true><<<dim3(ks.G, B), dim3(KT), vb, ctx->stream>>>(op, ks)));
     QMRI_HIP(ctx, hipGetLastError());
     return QMRI_OK;
 }
@@ -1027,9 +1095,9 @@ int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B) {
 // the caller then iterates with ks_launch_iter.  Round 5: a slice batch goes through the kernel as many slices at a time as are resident
 // together (EPI: 250 one-per-CU units = one slice; the spiral: 2 x 250 two-per-CU units = two slices), launch after launch on the stream:
 // the state of a solve then never leaves the registers, where the two-launch iteration moves 66 - 80 MB per slice and iteration.
-int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks_in, int B, void* gran, unsigned tag0, bool* ran) {
-    *ran = false;
-    KsDev ks = ks_in;
+// How many slices of a B-slice solve one k_ks_persist launch takes (0: the kernel does not apply -- too many units, s != 10, maxit < 1)
+int ks_persist_plan(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, int* per_launch) {
+    *per_launch = 0;
     if (ks.G > KS_GRAN_MAXG || ks.maxit < 1 || op.s != DC_MAXS) return QMRI_OK;    // (the kernel is written for the reference's s = 10)
     const size_t vb = (size_t)ks.vcap * 8;
     if (ctx->ks_persist_cap < 0) {
@@ -1047,8 +1115,17 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks_in, int B,
         // (MI355X_MICROARCH.md, "Residency and cooperative launch"); a kernel can use at most 102 SGPRs + VCC, i.e. >= 6 by that term
         ctx->ks_persist_cap = std::min(nb, 6) * ncu;
     }
-    const int per_launch = std::min(B, ctx->ks_persist_cap / ks.G);
+    *per_launch = std::min(B, ctx->ks_persist_cap / ks.G);
+    return QMRI_OK;
+}
+
+int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks_in, int B, void* gran, unsigned tag0, bool init_here, bool* ran) {
+    *ran = false;
+    KsDev ks = ks_in;
+    int per_launch = 0;
+    QMRI_TRY(ks_persist_plan(ctx, op, ks, B, &per_launch));
     if (per_launch < 1) return QMRI_OK;
+    const size_t vb = (size_t)ks.vcap * 8;
     KsGran* gu = (KsGran*)gran;
     KsGran* gv = gu + (size_t)B * 4 * ks.G;
     int* sticky = (int*)(gu + (size_t)ctx->op.maxB * 6 * ks.G);                         // (the word behind the granules: ks_gran_bytes)
@@ -1060,9 +1137,9 @@ int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks_in, int B,
         ks.b0 = b0;
         if (e0) {
             hipEvent_t ea = b0 == 0 ? e0 : nullptr, eb = b0 + nb >= B ? e1 : nullptr;
-            KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_persist<CP>), dim3(ks.G, nb), dim3(KT), (std::uint32_t)vb, ctx->stream, ea, eb, 0, op, ks, gu, gv, tag0, drop, sticky)));
+            KS_BY_CAPS(ks.caps, (hipExtLaunchKernelGGL((k_ks_persist<CP>), dim3(ks.G, nb), dim3(KT), (std::uint32_t)vb, ctx->stream, ea, eb, 0, op, ks, gu, gv, tag0, drop, sticky, init_here ? 1 : 0)));
         } else {
-            KS_BY_CAPS(ks.caps, (k_ks_persist<CP><<<dim3(ks.G, nb), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, drop, sticky)));
+            KS_BY_CAPS(ks.caps, (k_ks_persist<CP><<<dim3(ks.G, nb), dim3(KT), vb, ctx->stream>>>(op, ks, gu, gv, tag0, drop, sticky, init_here ? 1 : 0)));
         }
     }
     QMRI_HIP(ctx, hipGetLastError());

@@ -59,6 +59,7 @@ enum QmriKnob {
     K_CONV_MT2, K_CONV_OCC,                         // f32-MFMA fallback kernels: tile / occupancy choices
     K_FUSE_EW,            // the fused launches between the network and the solve
     K_LSQR_PERSIST,       // k_ks_persist: all LSQR iterations of a solve in one launch
+    K_LSQR_FOLD,          // ... and the first Golub-Kahan step (k_ks_b<INIT>) inside that launch
     K_DICTW_LSP,
     K_VERBOSE,            // calibration / guard decisions on stderr
     K_COUNT
@@ -350,10 +351,11 @@ int dc_hpass_blocks(const OpDev& op);
 struct LsqrFuse { int z_hpass_nblk = 0; const double2* mm_u = nullptr; double* mm = nullptr; };
 int dc_launch_dual_fwd_h(qmri_ctx* ctx, const OpDev& op, int B, const DualArgs& d, const ActCheckArgs& ac, double2* tmp);
 // k-space LSQR (kslsqr_kernels.hip)
-int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp = nullptr);
+int ks_launch_init(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, const double2* hpass_tmp = nullptr, bool first_step = true);
 int ks_launch_iter(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B);
 int ks_launch_final(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, double2* tmp);
-int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool* ran);   // all iterations in one launch
+int ks_persist_plan(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, int* per_launch);                             // slices per k_ks_persist launch (0: not applicable)
+int ks_launch_persist(qmri_ctx* ctx, const OpDev& op, const KsDev& ks, int B, void* gran, unsigned tag0, bool init_here, bool* ran);   // all iterations in one launch
 size_t ks_gran_bytes(int G, int B);   // tmp <- conj-domain inverse w-pass of xhat
 int ks_lds_fits(qmri_ctx* ctx, int N, int s, int M, int vcap, int caps, bool* ok);   // V (vcap doubles) fits the LDS of every k-space LSQR kernel with unit shape `caps`
 int dc_launch_direct(qmri_ctx* ctx, const OpDev& op, int B, const double2* z, const double2* chat, double r,
