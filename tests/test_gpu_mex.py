@@ -117,3 +117,16 @@ def test_recon_batch_through_the_gateway_30_slices_two_workers(mex, engine_mod, 
     with pytest.raises(mex.MexError) as e:
         mex.qmri_mex("recon_batch", np.ascontiguousarray(ys[:2].T).astype(np.complex128), prm, np.array([99.0]), 2.0, np.array([224.0, 224.0, 10.0]), nargout=1)
     assert "device" in e.value.msg
+
+
+def test_load_onnx_with_the_file_the_torch_exporter_wrote(mex):
+    """`param.net = qmri_make_net(denoiser_path, ...)`: qmri_mex('load_onnx', path, residual_noise, H, W) on
+    tests/golden/unetres_small_torch_export.onnx (torch.onnx.export of the reference's UNetRes with export_to_onnx's arguments,
+    utils.py:468-481), then `param.net(x)` == the reference network's own output on the fixture's input."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "unetres_small_torch_export.npz"))
+    in_nc, out_nc = mex.qmri_mex("load_onnx", os.path.join(gold, "unetres_small_torch_export.onnx"), 0.0, 32.0, 32.0, nargout=2)
+    in_nc, out_nc = int(np.ravel(in_nc)[0]), int(np.ravel(out_nc)[0])
+    assert (in_nc, out_nc) == (int(g["in_nc"]), int(g["out_nc"]))
+    y = mex.qmri_mex("denoise", np.asfortranarray(g["x"].transpose(1, 2, 0).astype(np.float64)), float(out_nc), nargout=1)
+    assert y.shape == (32, 32, out_nc) and rel_err(y.transpose(2, 0, 1), g["y"]) < 2e-5

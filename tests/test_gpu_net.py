@@ -42,6 +42,20 @@ def test_checkpoint_and_onnx_files_to_engine(engine_mod, tmp_path):
     e.close()
 
 
+def test_onnx_file_written_by_the_torch_exporter_to_engine(engine_mod):
+    """tests/golden/unetres_small_torch_export.onnx -- torch.onnx.export of the reference's UNetRes with export_to_onnx's arguments
+    (utils.py:468-481; tools/gen_golden.py onnx) -- read by the library's own reader, run on the GPU, compared with the reference
+    network's output: the route `param.net = qmri_make_net(denoiser_path, ...)` takes with the file the reference's training kit writes."""
+    g = np.load(os.path.join(GOLDEN, "unetres_small_torch_export.npz"))
+    w, a = engine_mod.read_onnx_unetres(os.path.join(GOLDEN, "unetres_small_torch_export.onnx"))
+    assert np.array_equal(w, g["weights"])
+    e = engine_mod.Engine(0)
+    e.set_denoiser(w, 32, 32, **a)
+    y = e.denoise(g["x"].transpose(1, 2, 0).astype(np.float64)).transpose(2, 0, 1)
+    assert rel_err(y, g["y"]) < 2e-5
+    e.close()
+
+
 def test_f16_range_guard_falls_back_to_bf16_scheme(engine_mod):
     """Activations beyond the f16-splittable range (|x| > 6e4) trip the guard of the default f16 x 3 scheme; the call is
     then repeated on the bf16 x 6 scheme (no range limit) and still returns the network's fp32 result.  UNetRes is

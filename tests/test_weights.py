@@ -2,8 +2,10 @@
 
 Pinned by: tests/golden/checkpoint_small.pt - written by torch.save from the reference's own UNetRes in the layout
 main_train.py:407-411 uses (tools/gen_golden.py checkpoint) - with the expected flat weights in checkpoint_small.npz.
-ONNX: no exporter can run in this image (no `onnx` package), so the files come from tests/onnx_writer.py (schema-built);
-the Python reader and the library's native reader are checked against the known blob and against each other.
+ONNX: tests/golden/unetres_small_torch_export.onnx is a file from torch.onnx.export itself, called on the reference's UNetRes with the
+arguments of export_to_onnx (PyTorch_Denoiser/utils.py:468-481; tools/gen_golden.py onnx, round 5) -- both readers are pinned to it;
+the encodings an exporter MAY use but this one did not (float_data, packed dims, renamed initializers, other float types, mangled
+files) come from tests/onnx_writer.py (schema-built) and are checked against the known blob and between the two readers.
 """
 import os
 import pickle
@@ -128,6 +130,26 @@ def test_blob_rejects_non_unetres(W, ck):
 
 
 # ---- ONNX --------------------------------------------------------------------------------------------------
+def test_onnx_file_written_by_the_torch_exporter(W, engine_mod, oracle):
+    """The file torch.onnx.export wrote for the reference's own UNetRes (opset 9, constant folding, named input / output, dynamic batch axis:
+    utils.py:468-481).  Both readers return the state dict's weights bit for bit and recognise the architecture; the CPU restatement of the
+    network with those weights reproduces the reference network's output on the fixture's input."""
+    g = np.load(os.path.join(GOLD, "unetres_small_torch_export.npz"))
+    path = os.path.join(GOLD, "unetres_small_torch_export.onnx")
+    a = arch_of(g)
+    m = W.read_onnx(path)
+    assert m["opset"] == 9 and m["inputs"] == ["input"] and m["outputs"] == ["output"]
+    assert len(m["convs"]) == 14 * a["nb"] + 8
+    blob, arch = W.load_denoiser_weights(path)
+    assert arch == a and np.array_equal(blob, g["weights"])
+    nblob, narch = engine_mod.read_onnx_unetres(path)                   # libqmri's own reader (C ABI, host only)
+    assert narch == a and np.array_equal(nblob, g["weights"])
+    net = oracle.Net(nblob, in_nc=a["in_nc"], out_nc=a["out_nc"], nc=a["nc"], nb=a["nb"])
+    y = net.forward_f32(g["x"].transpose(1, 2, 0)).transpose(2, 0, 1)          # CHW (torch) <-> HWC (MATLAB dims)
+    err = np.linalg.norm(y.astype(np.float64) - g["y"]) / np.linalg.norm(g["y"])
+    assert err < 2e-5, err
+
+
 ONNX_VARIANTS = [
     dict(mode="raw"),                                                # what torch.onnx.export writes
     dict(mode="raw", packed_dims=True, initializers_first=True),

@@ -28,7 +28,15 @@ Fixtures
                                                   model_state_dict, optimizer_state_dict after one Adam step, loss) of
                                                   UNetRes(11,10,[4,8,8,16],nb=2), written by torch.save; the .npz holds
                                                   the expected flat weights, an input and the reference's output
-`python tools/gen_golden.py [tiny full64 full224 full224random checkpoint]` regenerates a subset.
+  unetres_small_torch_export.onnx (+ .npz)        G6 (round 5): the same small UNetRes written by torch.onnx.export with the arguments of
+                                                  export_to_onnx (PyTorch_Denoiser/utils.py:468-481: opset 9, constant folding, input /
+                                                  output names, a dynamic batch axis) -- a file from the exporter the reference uses, not
+                                                  from tests/onnx_writer.py.  The image has no `onnx` package; the TorchScript exporter
+                                                  needs it for ONE step after its C++ serialiser has produced the file's bytes
+                                                  (onnx_proto_utils._add_onnxscript_fn: inserts custom onnxscript functions, returns the
+                                                  bytes unchanged when there are none, as here), so that step is replaced by the identity
+                                                  for the call.  The .npz holds the expected flat weights, an input and the reference's output
+`python tools/gen_golden.py [tiny full64 full224 full224random checkpoint onnx]` regenerates a subset.
 Tensor layout in the fixtures is PyTorch's [C][H][W]; tests transpose to the MATLAB order.
 """
 import os
@@ -171,8 +179,29 @@ def checkpoint():
     print(f"checkpoint: params {flat_weights(net).size}, file {os.path.getsize(os.path.join(OUT, 'checkpoint_small.pt'))} B")
 
 
+def onnx_export():
+    import warnings
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes     # (see the module docstring, G6)
+    in_nc, nc, nb = 11, [4, 8, 8, 16], 2
+    torch.manual_seed(8765)
+    net = UNetRes(in_nc=in_nc, out_nc=10, nc=nc, nb=nb, act_mode="R", downsample_mode="strideconv", upsample_mode="convtranspose").eval()
+    check_order(net, in_nc, 10, nc, nb)
+    path = os.path.join(OUT, "unetres_small_torch_export.onnx")
+    with torch.enable_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xe = torch.randn(1, in_nc, 16, 16, requires_grad=True)                              # utils.py:466
+        torch.onnx.export(net, xe, path, export_params=True, opset_version=9, do_constant_folding=True, input_names=["input"],
+                          output_names=["output"], dynamic_axes={"input": {0: "batch_size"}, "output": {0: "batch_size"}}, dynamo=False)   # utils.py:469-481
+    x = synth.uniform01(57, in_nc * 32 * 32).astype(np.float32).reshape(in_nc, 32, 32)
+    y = net(torch.from_numpy(x)[None])[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "unetres_small_torch_export.npz"), weights=flat_weights(net), x=x, y=y, in_nc=in_nc, out_nc=10,
+                        nc=np.array(nc), nb=nb, torch_version=str(torch.__version__))
+    print(f"onnx: params {flat_weights(net).size}, file {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["tiny", "full64", "full224", "full224random", "checkpoint"]
+    todo = sys.argv[1:] or ["tiny", "full64", "full224", "full224random", "checkpoint", "onnx"]
     if "tiny" in todo:
         tiny(10)
         tiny(11)
@@ -185,3 +214,5 @@ if __name__ == "__main__":
         full224_random(11)
     if "checkpoint" in todo:
         checkpoint()
+    if "onnx" in todo:
+        onnx_export()
