@@ -4,5 +4,5 @@ function [x, info] = FISTA_deep_hip(data, param)
 %   data.y  k-space measurements;  data.N, data.M, data.L  image dimensions;  data.F  must come from qmri_make_F (the
 %   operator lives in the library);  param.K, .iter, .step, .tol, .backtrack as set at main_recon_tsmis_FFT.m:274-279
 %   (param.usegpu and paramTV are not needed).
-[x, info] = qmri_mex('lrtv', double(data.y(:)), param, [data.M data.M data.L]);   % (the script passes data.N = M, :281)
+[x, info] = qmri_mex('lrtv', complex(double(data.y(:))), param, [data.M data.M data.L]);   % (the script passes data.N = M, :281)
 end

@@ -73,6 +73,28 @@ static double scalar_field(const mxArray* s, const char* name, double dflt) {
 static void need(int nrhs, int n, const char* usage) {
     if (nrhs < n) mexErrMsgIdAndTxt("qmri:usage", "%s", usage);
 }
+// The C ABI takes plain pointers: what a MATLAB array must be and hold is checked HERE, before the library reads it (a wrong class or a short
+// array would otherwise be read past its end).  Errors are MATLAB exceptions with an identifier, like the reference's validateInputImage.
+static void want(bool ok, const char* id, const char* msg) {
+    if (!ok) mexErrMsgIdAndTxt(id, "%s", msg);
+}
+static bool is_cdouble(const mxArray* a) { return mxIsDouble(a) && mxIsComplex(a); }
+static size_t image_numel() {                                       // N * M * s of the planned operator
+    want(g_op.V != nullptr, "qmri:state", "no operator: call qmri_mex('set_operator', ...) (qmri_make_F) first");
+    return (size_t)g_op.N * (size_t)g_op.M * mxGetN(g_op.V);
+}
+static size_t dims_numel(const mxArray* d) {                        // the [N M s] argument
+    want(mxIsDouble(d) && !mxIsComplex(d) && mxGetNumberOfElements(d) == 3, "qmri:size", "the size argument must be [N M s]");
+    const double* v = mxGetDoubles(d);
+    const size_t n = (size_t)v[0] * (size_t)v[1] * (size_t)v[2];
+    want(n == image_numel(), "qmri:size", "[N M s] does not match the operator (N x M grid, s = columns of V)");
+    return n;
+}
+static size_t operator_m() {
+    int m = 0;
+    check(qmri_operator_m(ctx(), &m));
+    return (size_t)m;
+}
 
 // (re-)make the plans from the kept specifications
 static void plan_operator(int max_batch) {
@@ -135,6 +157,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     } else if (c == "set_operator") {                // qmri_mex('set_operator', N, M, V, frame_ptr(int32), kidx(int32) [, max_batch])
         need(nrhs, 6, "qmri_mex('set_operator', N, M, V, frame_ptr, kidx [, max_batch])");
         if (!mxIsDouble(prhs[3]) || mxIsComplex(prhs[3])) mexErrMsgIdAndTxt("qmri:set_operator:type", "V must be a real double T x s matrix");
+        want(mxIsInt32(prhs[4]) && mxIsInt32(prhs[5]), "qmri:set_operator:type", "frame_ptr and kidx must be int32 (as 'build_spiral' / 'build_epi' return them)");
+        {
+            const size_t T = mxGetM(prhs[3]);
+            want(mxGetNumberOfElements(prhs[4]) == T + 1, "qmri:set_operator:size", "frame_ptr must have T + 1 entries (T = rows of V)");
+            const int32_t total = ((const int32_t*)mxGetData(prhs[4]))[T];
+            want(total >= 0 && mxGetNumberOfElements(prhs[5]) == (size_t)total, "qmri:set_operator:size", "kidx must have frame_ptr(end) entries");
+        }
         drop(g_op.V); drop(g_op.fp); drop(g_op.kidx);
         g_op.N = (int)mxGetScalar(prhs[1]); g_op.M = (int)mxGetScalar(prhs[2]);
         g_op.V = keep(prhs[3]); g_op.fp = keep(prhs[4]); g_op.kidx = keep(prhs[5]);
@@ -165,14 +194,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (st != QMRI_OK) mexErrMsgIdAndTxt("qmri:mask", "%s", qmri_last_error(nullptr));
     } else if (c == "forward") {                     // y = qmri_mex('forward', x)   (F.forward, main_recon_tsmis_FFT.m:228)
         need(nrhs, 2, "y = qmri_mex('forward', x)");
-        int m = 0;
-        check(qmri_operator_m(ctx(), &m));
-        plhs[0] = mxCreateDoubleMatrix(m, 1, mxCOMPLEX);
+        want(mxIsDouble(prhs[1]) && mxGetNumberOfElements(prhs[1]) == image_numel(), "qmri:forward:size", "x must be a double N x M x s array");
+        plhs[0] = mxCreateDoubleMatrix(operator_m(), 1, mxCOMPLEX);
         const bool cx = mxIsComplex(prhs[1]);
         check(qmri_forward(ctx(), cx ? (const void*)mxGetComplexDoubles(prhs[1]) : (const void*)mxGetDoubles(prhs[1]), cx,
                            mxGetComplexDoubles(plhs[0])));
     } else if (c == "adjoint") {                     // x = qmri_mex('adjoint', y, [N M s])   (F.adjoint, :229)
         need(nrhs, 3, "x = qmri_mex('adjoint', y, [N M s])");
+        (void)dims_numel(prhs[2]);
+        want(is_cdouble(prhs[1]) && mxGetNumberOfElements(prhs[1]) == operator_m(), "qmri:adjoint:size", "y must be a complex double vector with one entry per sample");
         const double* d = mxGetDoubles(prhs[2]);
         const mwSize dims[3] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2]};
         plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
@@ -182,6 +212,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         qmri_net_desc d;
         d.arch = QMRI_ARCH_UNETRES;
         d.in_nc = (int)mxGetScalar(prhs[2]); d.out_nc = (int)mxGetScalar(prhs[3]);
+        want(mxIsDouble(prhs[4]) && mxGetNumberOfElements(prhs[4]) == 4, "qmri:set_denoiser:size", "nc must hold the four channel counts");
         const double* nc = mxGetDoubles(prhs[4]);
         for (int i = 0; i < 4; ++i) d.nc[i] = (int)nc[i];
         d.nb = (int)mxGetScalar(prhs[5]); d.residual_noise = (int)mxGetScalar(prhs[6]);
@@ -216,9 +247,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         // y: m x 1 -> x is N x M x s;  y: m x S (a slice stack) -> x is N x M x s x S, diag 2 x iter x S, lsqr_iters iter x S: the slices advance together
         // through the batched kernels, slices_per_launch = min(S, 15) at a time, on the current device (X0 / gt: N x M x s x S or empty)
         need(nrhs, 6, "[x, diag, lsqr_iters] = qmri_mex('pnp_admm', y, param, X0, gt, [N M s])");
+        want(mxIsStruct(prhs[2]), "qmri:pnp_admm:type", "param must be a struct");
         const qmri_admm_params p = admm_params(prhs[2], nlhs > 1);
         const double* d = mxGetDoubles(prhs[5]);
-        const size_t S = mxGetN(prhs[1]), m = mxGetM(prhs[1]), n = (size_t)d[0] * (size_t)d[1] * (size_t)d[2];
+        const size_t S = mxGetN(prhs[1]), m = mxGetM(prhs[1]), n = dims_numel(prhs[5]);
+        want(is_cdouble(prhs[1]) && S >= 1 && m == operator_m(), "qmri:pnp_admm:size", "y must be complex double, one column of m samples per slice");
+        want(g_net.w != nullptr, "qmri:state", "no denoiser: call qmri_mex('set_denoiser' | 'load_onnx', ...) (qmri_make_net) first");
+        want((mxIsEmpty(prhs[3]) || is_cdouble(prhs[3])) && (mxIsEmpty(prhs[4]) || is_cdouble(prhs[4])), "qmri:pnp_admm:type", "X0 and gt_tsmi must be complex double or empty");
         const int it = p.iters > 0 ? p.iters : 1;
         const mwSize dims[4] = {(mwSize)d[0], (mwSize)d[1], (mwSize)d[2], (mwSize)S};
         plhs[0] = mxCreateNumericArray(S > 1 ? 4 : 3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
@@ -239,7 +274,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             check(qmri_pnp_admm_batch(ctx(), (int)S, spl, y, &p, x0, gt, mxGetComplexDoubles(plhs[0]), p.want_diag ? mxGetDoubles(diag) : nullptr,
                                       (int32_t*)mxGetData(li)));
         }
-        (void)m;
         if (nlhs > 1) plhs[1] = diag; else mxDestroyArray(diag);
         if (nlhs > 2) plhs[2] = li; else mxDestroyArray(li);
     } else if (c == "recon_batch") {                 // [X, qmap, pd] = qmri_mex('recon_batch', Y(m x S), param_struct, devs, slices_per_launch, [N M s])
@@ -249,8 +283,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         need(nrhs, 6, "[X, qmap, pd] = qmri_mex('recon_batch', Y, param, devs, slices_per_launch, [N M s])");
         if (!g_op.V || !g_net.w) mexErrMsgIdAndTxt("qmri:recon_batch:state", "set_operator and set_denoiser (or load_onnx) must come first");
         const size_t S = mxGetN(prhs[1]);
+        (void)dims_numel(prhs[5]);
+        want(mxIsStruct(prhs[2]), "qmri:recon_batch:type", "param must be a struct");
+        want(is_cdouble(prhs[1]) && S >= 1 && mxGetM(prhs[1]) == operator_m(), "qmri:recon_batch:size", "Y must be complex double, one column of m samples per slice");
+        want(mxIsDouble(prhs[3]) && !mxIsComplex(prhs[3]), "qmri:recon_batch:devs", "devs must be a double vector of device ids");
         const double* d = mxGetDoubles(prhs[5]);
-        const size_t npix = (size_t)d[0] * (size_t)d[1];
         std::vector<int> devs(mxGetNumberOfElements(prhs[3]));
         for (size_t i = 0; i < devs.size(); ++i) devs[i] = (int)mxGetDoubles(prhs[3])[i];
         if (devs.empty()) mexErrMsgIdAndTxt("qmri:recon_batch:devs", "devs must name at least one device");
@@ -275,7 +312,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             qm = mxCreateNumericArray(4, qd, mxSINGLE_CLASS, mxREAL);
             pd = mxCreateNumericArray(3, pdd, mxSINGLE_CLASS, mxCOMPLEX);
         }
-        (void)npix;
         char err[1024] = "";
         const int st = qmri_recon_batch((int)devs.size(), devs.data(), (int)S, &pb, mxGetComplexDoubles(prhs[1]), mxGetComplexDoubles(plhs[0]),
                                         qm ? (float*)mxGetData(qm) : nullptr, pd ? (float*)mxGetData(pd) : nullptr, err, sizeof err);
@@ -289,6 +325,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     } else if (c == "lrtv") {                        // [x, info] = qmri_mex('lrtv', y, param_struct, [N M s])   (FISTA_deep, main_recon_tsmis_FFT.m:273-282)
         need(nrhs, 4, "[x, info] = qmri_mex('lrtv', y, param, [N M s])");
         const mxArray* P = prhs[2];
+        want(mxIsStruct(P), "qmri:lrtv:type", "param must be a struct");
+        (void)dims_numel(prhs[3]);
+        want(is_cdouble(prhs[1]) && mxGetNumberOfElements(prhs[1]) == operator_m(), "qmri:lrtv:size", "y must be a complex double vector with one entry per sample");
         qmri_lrtv_params p;
         p.K = scalar_field(P, "K", 4e-5);
         p.iters = (int)scalar_field(P, "iter", 200);
@@ -320,6 +359,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         plan_dictionary();
     } else if (c == "dict_match") {                  // [qmap, pd, mt, dm, xfit] = qmri_mex('dict_match', X(Npix x s complex double), Q)
         need(nrhs, 3, "[qmap, pd, mt, dm, xfit] = qmri_mex('dict_match', X, Q)");
+        want(g_dict.D != nullptr, "qmri:state", "no dictionary: call qmri_mex('set_dictionary', ...) (mrf_dtm_hip(dict, [], [])) first");
+        want(is_cdouble(prhs[1]) && mxGetN(prhs[1]) == mxGetN(g_dict.D), "qmri:dict_match:size", "X must be complex double, Npix x s (s = columns of dict.D)");
+        want((size_t)mxGetScalar(prhs[2]) == mxGetN(g_dict.lut), "qmri:dict_match:size", "Q must be the number of columns of dict.lut");
         const int npix = (int)mxGetM(prhs[1]), Q = (int)mxGetScalar(prhs[2]);
         mxArray* xfit = (nlhs > 4) ? mxCreateNumericMatrix(npix, mxGetN(prhs[1]), mxSINGLE_CLASS, mxCOMPLEX) : nullptr;   // out.Xfit, mrf_dtm_cpu.m:129-134
         plhs[0] = mxCreateNumericMatrix(npix, Q, mxSINGLE_CLASS, mxREAL);

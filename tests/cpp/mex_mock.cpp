@@ -121,6 +121,8 @@ bool mxIsChar(const mxArray* a) { return a->cls == mxCHAR_CLASS; }
 bool mxIsComplex(const mxArray* a) { return a->cplx; }
 bool mxIsDouble(const mxArray* a) { return a->cls == mxDOUBLE_CLASS; }
 bool mxIsSingle(const mxArray* a) { return a->cls == mxSINGLE_CLASS; }
+bool mxIsInt32(const mxArray* a) { return a->cls == mxINT32_CLASS; }
+bool mxIsStruct(const mxArray* a) { return a->is_struct; }
 bool mxIsEmpty(const mxArray* a) { return numel(a) == 0; }
 
 // ---- the mock's own entry points (tests/mexmock.py) ----------------------------------------------------------------------------------------

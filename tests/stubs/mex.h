@@ -54,6 +54,8 @@ bool mxIsChar(const mxArray* pm);
 bool mxIsComplex(const mxArray* pm);
 bool mxIsDouble(const mxArray* pm);
 bool mxIsSingle(const mxArray* pm);
+bool mxIsInt32(const mxArray* pm);
+bool mxIsStruct(const mxArray* pm);
 bool mxIsEmpty(const mxArray* pm);
 void mxSetFieldByNumber(mxArray* pm, mwIndex index, int fieldnumber, mxArray* pvalue);
 void mxSetM(mxArray* pm, mwSize m);

@@ -130,3 +130,36 @@ def test_load_onnx_with_the_file_the_torch_exporter_wrote(mex):
     assert (in_nc, out_nc) == (int(g["in_nc"]), int(g["out_nc"]))
     y = mex.qmri_mex("denoise", np.asfortranarray(g["x"].transpose(1, 2, 0).astype(np.float64)), float(out_nc), nargout=1)
     assert y.shape == (32, 32, out_nc) and rel_err(y.transpose(2, 0, 1), g["y"]) < 2e-5
+
+
+def test_gateway_refuses_arrays_of_the_wrong_size_or_class(mex, synth):
+    """The C ABI takes plain pointers, so the gateway checks every array against the planned operator / dictionary before the library reads it:
+    a short or real-valued array is a MATLAB error with an identifier, never a read past the end."""
+    from mexmock import MexError
+    N, T, s, S = 32, 24, 6, 120
+    nc, nb = (8, 16, 16, 32), 2
+    dic = synth.make_dictionary(T=T, n_t1=24, n_t2=16, s=s)
+    fp, k = mex.qmri_mex("build_spiral", float(N), float(S), float(T), nargout=2)
+    w = synth.structured_weights(in_nc=s, out_nc=s, nc=nc, nb=nb, seed=3, eps=0.05)
+    _plan(mex, dic, fp.ravel(), k.ravel(), w, N, s, nc, nb)
+    m = int(fp.ravel()[-1])
+    dims = np.array([N, N, s], np.float64)
+    prm = {"gamma": 0.05, "iter": 2, "cg_tol": 1e-4, "multi_level": 0, "noise_std": 0.01}
+    cases = [
+        ("qmri:forward:size", lambda: mex.qmri_mex("forward", np.zeros((N, N, s - 1)), nargout=1)),
+        ("qmri:adjoint:size", lambda: mex.qmri_mex("adjoint", np.zeros(m), dims, nargout=1)),                                  # real y
+        ("qmri:adjoint:size", lambda: mex.qmri_mex("adjoint", np.zeros(m - 1, np.complex128), dims, nargout=1)),
+        ("qmri:size", lambda: mex.qmri_mex("adjoint", np.zeros(m, np.complex128), np.array([N, N, s + 1], np.float64), nargout=1)),
+        ("qmri:pnp_admm:size", lambda: mex.qmri_mex("pnp_admm", np.zeros((m + 1, 2), np.complex128), prm, np.zeros((0, 0)), np.zeros((0, 0)), dims, nargout=1)),
+        ("qmri:pnp_admm:size", lambda: mex.qmri_mex("pnp_admm", np.zeros((m, 1), np.complex128), prm, np.zeros((N, N, s - 1), np.complex128), np.zeros((0, 0)), dims, nargout=1)),
+        ("qmri:recon_batch:size", lambda: mex.qmri_mex("recon_batch", np.zeros((m - 2, 3), np.complex128), prm, np.array([0.0]), 3.0, dims, nargout=1)),
+        ("qmri:dict_match:size", lambda: mex.qmri_mex("dict_match", np.zeros((16, s + 1), np.complex128), 2.0, nargout=1)),
+        ("qmri:lrtv:size", lambda: mex.qmri_mex("lrtv", np.zeros(m + 5, np.complex128), {"iter": 1}, dims, nargout=1)),
+    ]
+    for want_id, call in cases:
+        with pytest.raises(MexError) as e:
+            call()
+        assert e.value.id == want_id, (want_id, e.value.id, e.value.msg)
+    # and the well-formed calls still run afterwards
+    y = mex.qmri_mex("forward", np.zeros((N, N, s)), nargout=1)
+    assert y.shape == (m, 1)

@@ -38,13 +38,33 @@ def test_gateway_usage_errors_are_matlab_errors():
     with pytest.raises(MexError) as e:
         qmri_mex("set_dictionary", np.zeros((8, 2), np.complex64), np.ones(8, np.float32), np.ones((8, 2), np.float32))
     assert e.value.id == "qmri:set_dictionary:type"                # complex atoms are refused on this route too
+    # round 5: what an array must be and hold is checked by the gateway before the library reads through the plain pointers of the C ABI
+    with pytest.raises(MexError) as e:
+        qmri_mex("forward", np.zeros((8, 8, 2)), nargout=1)
+    assert e.value.id == "qmri:state" and "set_operator" in e.value.msg          # no operator planned: nothing to size x against
+    fp, k = qmri_mex("build_spiral", 32.0, 40.0, 6.0, nargout=2)
+    V = np.linalg.qr(np.random.default_rng(0).standard_normal((6, 2)))[0]
+    with pytest.raises(MexError) as e:
+        qmri_mex("set_operator", 32.0, 32.0, V, fp.astype(np.float64), k)          # frame_ptr as doubles: would be read as garbage int32
+    assert e.value.id == "qmri:set_operator:type"
+    with pytest.raises(MexError) as e:
+        qmri_mex("set_operator", 32.0, 32.0, V, fp[:-1].copy(), k)                 # T + 1 entries wanted
+    assert e.value.id == "qmri:set_operator:size"
+    with pytest.raises(MexError) as e:
+        qmri_mex("set_operator", 32.0, 32.0, V, fp, k[:-3].copy())                 # kidx shorter than frame_ptr(end): would be read past its end
+    assert e.value.id == "qmri:set_operator:size"
+    with pytest.raises(MexError) as e:
+        qmri_mex("dict_match", np.zeros((16, 2), np.complex128), 2.0, nargout=1)
+    assert e.value.id == "qmri:state"                               # no dictionary
 
 
 def test_gateway_fails_loudly_without_a_gpu():
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
+    fp, k = qmri_mex("build_spiral", 32.0, 40.0, 6.0, nargout=2)
+    V = np.linalg.qr(np.random.default_rng(0).standard_normal((6, 2)))[0]
     with pytest.raises(MexError) as e:
-        qmri_mex("forward", np.zeros((8, 8, 2)), nargout=1)
+        qmri_mex("set_operator", 32.0, 32.0, V, fp, k)              # well-formed: the first command that needs the device
     assert e.value.id == "qmri:create" and "no CPU fallback" in e.value.msg
     mexmock.mex_exit()
