@@ -400,15 +400,20 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
 
     copied = [None, None]                                      # event on the copy stream behind the copies out of buffer set j
 
+    batch_s = []                                               # host clock of every launch of the last run() (qmri_pnp_admm_dev returns when its slices are done)
+
     def run(count, it):
         p = params(it)
+        batch_s.clear()
         for bi, s0 in enumerate(range(0, count, B)):
+            tb = time.perf_counter()
             j, cnt = bi & 1, min(B, count - s0)
             if copied[j] is not None:                              # set j is written again: its copies (two launches ago) must be over, as in recon_worker (api_net.cpp)
                 stream.wait_event(copied[j])
                 copied[j].synchronize()                            # (... and the pinned results consumed: here they are simply dropped)
             eng._check(eng.L.qmri_pnp_admm_dev(eng.h, cnt, C.c_void_p(d_y.data_ptr() + s0 * m * 16), C.byref(p), None, None,
                                                C.c_void_p(d_x[j].data_ptr()), None, None))
+            batch_s.append(round(time.perf_counter() - tb, 4))
             for i in range(cnt):
                 match(j, i)
             ev = torch.cuda.Event()
@@ -444,6 +449,7 @@ def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, 
         out = {"metric": f"slices/sec ({total}-slice synthetic batch: {iters} ADMM iterations + dictionary match per slice)", "value": round(total / dt, 4),
                "unit": "slices/s", "n_gpus": world, "scaling": "strong", "seconds": round(dt, 3), "ms_per_slice": round(dt / max(nsl, 1) * 1e3, 3),
                "slices_on_rank0": nsl, "total_slices": total, "batch": B, "admm_iters_per_slice": iters, "dict_K": K,
+               "launch_seconds_rank0": list(batch_s),        # (one entry per launch of `batch` slices: a stalled launch would show here)
                "sharding": "fixed total, contiguous blocks (batch.shard_slices), no collective in the data path",
                "results": "x (8 MB) and the T1 / T2 / PD maps of every slice copied to pinned host memory inside the timed region (copy stream, overlapped)",
                "workload": f"cut3 {total}-slice batch over {world} GPU(s), {B} slices advanced together, spiral mask, PnP-ADMM + UNetRes + dictionary match K={K}"}
