@@ -196,7 +196,7 @@ def test_config2_epi_multi_level_batch_of_15_every_slice(engine_mod, oracle, syn
 
 
 @pytest.mark.parametrize("mask", ["epi", "spiral"])
-def test_slice_batches_solve_with_the_one_launch_lsqr_a_slice_or_two_at_a_time(engine_mod, oracle, synth, case224, mask):
+def test_slice_batches_solve_with_the_one_launch_lsqr_a_slice_or_two_at_a_time(engine_mod, oracle, synth, case224, mask, capfd):
     """Round 5: the x-update of a slice BATCH goes through the one-launch LSQR kernel too -- as many slices per launch as are resident together
     (EPI: one slice's <= 256 one-per-CU units; the spiral: two slices), launch after launch (ks_launch_persist) -- instead of two launches per
     iteration over all slices.  Same arithmetic on the same work units: x of every slice and every LSQR count IDENTICAL to a run of the
@@ -218,6 +218,17 @@ def test_slice_batches_solve_with_the_one_launch_lsqr_a_slice_or_two_at_a_time(e
         e.close()
     assert np.array_equal(out[1][1], out[0][1]), (out[1][1], out[0][1])
     assert np.array_equal(out[1][0], out[0][0]), rel_err(out[1][0], out[0][0])
+    # the recovery path with a batch: the test hook makes every slice's first solve time out; the reconstruction repeats itself on the
+    # two-launch iteration (one message), same x and counts
+    capfd.readouterr()
+    e = engine_mod.Engine(0)
+    e.set_operator(224, 224, dic["V"], fp, k, max_batch=nsl)
+    e.set_denoiser(w, 224, 224, max_batch=nsl)
+    e.lsqr_persist(2)
+    xt, lt = e.pnp_admm_batch(ys, slices_per_launch=nsl, iters=iters)
+    e.close()
+    assert capfd.readouterr().err.count("timed out") == 1
+    assert np.array_equal(lt, out[0][1]) and np.array_equal(xt, out[0][0])
     net = oracle.Net(w)
     for sl in (0, nsl - 1):
         xo, _, lo = oracle.pnp_admm(op, net, ys[sl], iters=iters)
