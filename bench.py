@@ -826,10 +826,17 @@ def worker(args):
     # ---- the other single-GPU configurations of BASELINE.json on the same line (rank 0; the other ranks wait at the final barrier) ----------------
     secondary = {}
     if args.workload == "admm" and not args.no_secondary and rank == 0:
-        secondary["epi_batch15"] = secondary_config(args, torch, dev, local_rank, "BASELINE configs[2]: cut3, EPI mask (m = 134 400), 15 slices advanced together, "
-                                                    "PnP-ADMM + 11-channel multi-level UNetRes", 200, "epi", 15, True, args.secondary_steps)
-        secondary["cut0"] = secondary_config(args, torch, dev, local_rank, "BASELINE configs[4] as far as the reference goes: cut0 (T = 1000, m = 618 000), spiral mask, one "
-                                             "slice, PnP-ADMM + 10-channel UNetRes", 1000, "spiral", 1, False, args.secondary_steps)
+        # (rank 0 only, no collective inside: a failure here -- say, no memory left on a shared box -- is reported in the object instead of costing
+        #  the line its headline metric)
+        for key, cfg_args in (("epi_batch15", ("BASELINE configs[2]: cut3, EPI mask (m = 134 400), 15 slices advanced together, "
+                                               "PnP-ADMM + 11-channel multi-level UNetRes", 200, "epi", 15, True)),
+                              ("cut0", ("BASELINE configs[4] as far as the reference goes: cut0 (T = 1000, m = 618 000), spiral mask, one "
+                                        "slice, PnP-ADMM + 10-channel UNetRes", 1000, "spiral", 1, False))):
+            try:
+                secondary[key] = secondary_config(args, torch, dev, local_rank, *cfg_args, args.secondary_steps)
+            except Exception as exc:                                # noqa: BLE001
+                secondary[key] = {"workload": cfg_args[0], "value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
+                print(f"bench.py: secondary configuration {key} failed: {exc}", file=sys.stderr)
     if rank == 0:
         strong = args.workload == "slices" and args.total_slices > 0
         if args.workload == "admm":
