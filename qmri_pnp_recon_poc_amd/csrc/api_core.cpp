@@ -754,6 +754,9 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
             }
         }
     }
+    // (guard: the first Golub-Kahan step was left to a one-launch kernel that then did not run -- the plan is the same in both places, so this
+    //  cannot happen; if it ever does, the two-launch iteration must not start from an unset state)
+    if (fold && !persisted && !(ctx->ks_persist == 0)) QMRI_TRY(ks_launch_init(ctx, op, ks, B));
     int launched = 0;
     int chunk = std::min(std::max(ctx->lsqr_pred, 1), std::max(maxit, 1));
     bool all_done = persisted;
