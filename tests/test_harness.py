@@ -132,3 +132,19 @@ def test_training_volume_layout(tmp_path):
     H.save_training_pickle(tmp_path / "vol1.pkl", X)
     with open(tmp_path / "vol1.pkl", "rb") as f:
         assert np.array_equal(pickle.load(f), v)
+
+
+def test_training_pickle_against_the_reference_scripts_own_output():
+    """tests/golden/training_pickle_small.npz holds what the reference's OWN ready_real_data (PyTorch_Denoiser/main_save_python_tsmis.py:98-205)
+    pickled for 2 subjects x 3 small `.mat` slices (tools/gen_golden.py pickle): harness.training_volume must reproduce every array bit for bit,
+    for all channels and for the script's `select_channels` variants; the script's file naming (`vol<k>_real_<scan>_cut<c>_numpyfloat64_<C>channels.pkl`,
+    subject 1 -> training, subject 2 -> testing at a split of 2) is recorded with it."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "training_pickle_small.npz"))
+    X = g["X"]                                                     # [subject][slice] N x M x C
+    for tag, ch in (("all", None), ("first1", 1), ("first2", 2)):
+        C = X.shape[-1] if ch is None else ch
+        assert list(g[tag + "_files"]) == [f"train/vol1_real_fisp_cut3_numpyfloat64_{C}channels.pkl", f"test/vol2_real_fisp_cut3_numpyfloat64_{C}channels.pkl"]
+        for v in range(X.shape[0]):
+            ref = g[f"{tag}_vol{v + 1}_real_fisp_cut3_numpyfloat64_{C}channels.pkl"]
+            mine = H.training_volume(X[v], channels_to_save=ch)
+            assert mine.dtype == ref.dtype == np.float64 and mine.shape == ref.shape and np.array_equal(mine, ref)

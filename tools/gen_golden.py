@@ -36,7 +36,12 @@ Fixtures
                                                   (onnx_proto_utils._add_onnxscript_fn: inserts custom onnxscript functions, returns the
                                                   bytes unchanged when there are none, as here), so that step is replaced by the identity
                                                   for the call.  The .npz holds the expected flat weights, an input and the reference's output
-`python tools/gen_golden.py [tiny full64 full224 full224random checkpoint onnx]` regenerates a subset.
+  training_pickle_small.npz                       G7 (round 5): the `.mat` -> training-pickle step run by the reference's OWN function
+                                                  (PyTorch_Denoiser/main_save_python_tsmis.py:98-205, ready_real_data) on a scratch directory
+                                                  of small per-slice `.mat` files (2 subjects x 3 slices, X: 7 x 6 x 4): the slices in the
+                                                  order the script sorts them and the arrays it pickled (all channels; first 1; first 2),
+                                                  with the file names it chose
+`python tools/gen_golden.py [tiny full64 full224 full224random checkpoint onnx pickle]` regenerates a subset.
 Tensor layout in the fixtures is PyTorch's [C][H][W]; tests transpose to the MATLAB order.
 """
 import os
@@ -200,8 +205,45 @@ def onnx_export():
     print(f"onnx: params {flat_weights(net).size}, file {os.path.getsize(path)} B")
 
 
+def training_pickle():
+    import argparse
+    import contextlib
+    import io
+    import pickle
+    import tempfile
+    import scipy.io as scio
+    import main_save_python_tsmis as ref                      # (the reference's script: definitions only at import, read-only)
+    rng = np.random.default_rng(77)
+    nvol, nsl = 2, 3
+    X = rng.random((nvol, nsl, 7, 6, 4))                        # [subject][slice] N x M x C, float64 like the script's data['X']
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        tr, te = os.path.join(td, "in_train") + os.sep, os.path.join(td, "in_test") + os.sep
+        os.makedirs(tr); os.makedirs(te)
+        for v in range(nvol):
+            for sl in range(nsl):                               # subject 1 -> training input, subject 2 -> testing input (matlab_train_test_split = 2)
+                scio.savemat((tr if v == 0 else te) + f"vol{v + 1}s{sl + 1}.mat", {"X": X[v, sl]})
+        for tag, kw in (("all", dict(select_channels=False)), ("first1", dict(select_channels=True, channels_to_save=1)),
+                        ("first2", dict(select_channels=True, channels_to_save=2))):
+            otr, ote = os.path.join(td, "out_train_" + tag) + os.sep, os.path.join(td, "out_test_" + tag) + os.sep
+            os.makedirs(otr); os.makedirs(ote)
+            args = argparse.Namespace(scan_type="fisp", cut=3, num_slices=nsl, training_data_input_path=tr, testing_data_input_path=te,
+                                      training_data_output_path=otr, testing_data_output_path=ote, matlab_train_test_split=2, python_train_test_split=2)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref.ready_real_data(args, **kw)
+            names = []
+            for d in (otr, ote):
+                for fn in sorted(os.listdir(d)):
+                    with open(d + fn, "rb") as f:
+                        out[f"{tag}_{fn}"] = pickle.load(f)
+                    names.append(("train/" if d == otr else "test/") + fn)
+            out[tag + "_files"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "training_pickle_small.npz"), X=X, **out)
+    print("pickle:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["tiny", "full64", "full224", "full224random", "checkpoint", "onnx"]
+    todo = sys.argv[1:] or ["tiny", "full64", "full224", "full224random", "checkpoint", "onnx", "pickle"]
     if "tiny" in todo:
         tiny(10)
         tiny(11)
@@ -216,3 +258,5 @@ if __name__ == "__main__":
         checkpoint()
     if "onnx" in todo:
         onnx_export()
+    if "pickle" in todo:
+        training_pickle()
