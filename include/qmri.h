@@ -260,8 +260,31 @@ typedef struct {
     double ms_net_forward;      /* level 2: whole forward passes of the network, first launch to last (stream events) */
     int64_t n_net_forward;
 } qmri_profile;
-int qmri_profile_enable(qmri_ctx* ctx, int level);   /* 0 off, 1 per stage, 2 also per conv3x3 launch */
+int qmri_profile_enable(qmri_ctx* ctx, int level);   /* 0 off, 1 per stage (synchronises at every stage boundary), 2 also per conv3x3 launch,
+                                                        3 stage MARKS: event records at the stage boundaries that are read only after the call's own final
+                                                        synchronisation -- the stage split of a timed run without a wait inside it (batches; an event record
+                                                        between two dependent kernels costs a few microseconds, so not for the one-slice headline) */
 int qmri_profile_get(qmri_ctx* ctx, qmri_profile* out, int reset);
+
+/* Health of a context (no counterpart in the reference, which reconstructs one slice per run -- main_recon_tsmis_FFT.m:37-38 -- and has no
+ * alternative paths): which of the library's self-checking fast paths are armed, how often one of them gave up and the work was repeated on the
+ * slower path, and what the most recent qmri_pnp_admm_dev call cost.  A reconstruction that is slow for one of THESE reasons says so here; the
+ * results are the same either way (every fallback is tested for bits).  Counters run from qmri_create; the denoiser's from qmri_set_denoiser. */
+typedef struct {
+    int denoiser_scheme;        /* 2 = f16 x 3 products, 3 = bf16 x 6 products, 0 = no denoiser set */
+    int denoiser_fallbacks;     /* switches f16 -> bf16 by the range / low-magnitude guards since qmri_set_denoiser */
+    int resident_armed;         /* 1 = the resident-tile launch of the full-resolution ResBlocks is in use (one slice per launch only) */
+    int resident_timeouts;      /* ring hand-offs that timed out since qmri_set_denoiser (each: the forward pass was repeated, one launch per layer) */
+    int lsqr_one_launch;        /* 1 = the one-launch LSQR iteration is armed, 0 = switched off (by a time-out or by the caller), -1 = not decided yet */
+    int lsqr_timeouts;          /* one-launch LSQR kernels that gave up waiting for a partial sum (each: the solve or the reconstruction was repeated) */
+    int repeated_calls;         /* qmri_pnp_admm* calls that ran their reconstruction twice (any of the reasons above) */
+    int reserved;
+    double last_call_wall_ms;   /* host wall clock of the most recent qmri_pnp_admm_dev call, entry to return */
+    double last_call_stage_ms[4]; /* its x-update / denoiser / elementwise / diagnostics stages on the device (profile level 1 or 3 only, else zeros) */
+    double set_denoiser_ms[3];  /* the most recent qmri_set_denoiser on the host clock: weight splitting, packing and upload of all layers / tensors and
+                                   buffers / the two-pass calibration probe (the reference loads its network once per run: main_recon_tsmis_FFT.m:138-152) */
+} qmri_health;
+int qmri_get_health(const qmri_ctx* ctx, qmri_health* out);
 
 /* Diagnostics (no counterpart in the reference): in-kernel 100 MHz phase stamps, recorded only when the library was
  * started with the knobs lsqr_stamps / conv_stamps set (qmri_debug_knob, QMRI_DEBUG; otherwise QMRI_ERR_STATE).  `out` receives 2*512*16 and 4096*11

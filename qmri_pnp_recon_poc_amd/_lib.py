@@ -20,7 +20,7 @@ SYMBOLS = [
     "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
     "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_set_coils", "qmri_forward_mc", "qmri_adjoint_mc", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_pnp_admm_batch", "qmri_set_dictionary", "qmri_dict_match",
-    "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get",
+    "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get", "qmri_get_health",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_debug_conv_resident", "qmri_debug_knob",
     "qmri_onnx_read_unetres",
     "qmri_lrtv", "qmri_prox_tv", "qmri_norm_tv", "qmri_synthesize_tsmi", "qmri_synthesize_tsmi_complex",
@@ -62,6 +62,12 @@ class Profile(C.Structure):
                 ("ms_tv_iter", C.c_double), ("n_tv_iter", C.c_int64),
                 ("flop_conv3x3", C.c_double), ("ms_conv2x2", C.c_double), ("n_conv2x2", C.c_int64), ("flop_conv2x2", C.c_double),
                 ("ms_lsqr_kernels", C.c_double), ("n_lsqr_launches", C.c_int64), ("ms_net_forward", C.c_double), ("n_net_forward", C.c_int64)]
+
+
+class Health(C.Structure):
+    _fields_ = [("denoiser_scheme", C.c_int32), ("denoiser_fallbacks", C.c_int32), ("resident_armed", C.c_int32), ("resident_timeouts", C.c_int32),
+                ("lsqr_one_launch", C.c_int32), ("lsqr_timeouts", C.c_int32), ("repeated_calls", C.c_int32), ("reserved", C.c_int32),
+                ("last_call_wall_ms", C.c_double), ("last_call_stage_ms", C.c_double * 4), ("set_denoiser_ms", C.c_double * 3)]
 
 
 def build(force: bool = False) -> str:
@@ -121,6 +127,7 @@ def lib() -> C.CDLL:
     L.qmri_onnx_read_unetres.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qmri_net_forward_dev.argtypes = [vp, vp, i, vp]
     L.qmri_denoiser_scheme.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.qmri_get_health.argtypes = [vp, C.POINTER(Health)]
     L.qmri_pnp_admm.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_pnp_admm_dev.argtypes = [vp, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]
     L.qmri_pnp_admm_batch.argtypes = [vp, i, i, vp, C.POINTER(AdmmParams), vp, vp, vp, dp, ip]

@@ -412,7 +412,14 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
             }
             if (ks.caps == base) nunits = cut(KS_CAPS[base]);
         }
-        if (nunits < 0) { qmri_set_error(ctx, "a k location is sampled %d times; at most %d are supported", -nunits, KS_CAPS[2].ecap); return QMRI_ERR_UNSUPPORTED; }
+        if (nunits < 0) {
+            // the limit of the shapes that were actually TRIED (the larger shapes only with one slice per launch or the one-launch iteration)
+            int tried = std::max(KS_CAPS[base].ecap, KS_CAPS[0].ecap);
+            if ((max_batch == 1 || one_launch) && s == 10) tried = std::max(tried, std::max(KS_CAPS[1].ecap, KS_CAPS[2].ecap));
+            qmri_set_error(ctx, "a k location is sampled %d times; at most %d are supported%s", -nunits, tried,
+                           tried < KS_CAPS[2].ecap ? " with several slices per launch and the two-launch LSQR iteration (one slice per launch: 2560)" : "");
+            return QMRI_ERR_UNSUPPORTED;
+        }
         bslot.push_back(ns);
         gptr.push_back((int32_t)grp.size());
         sgrp[ns] = (int32_t)grp.size();
@@ -749,6 +756,7 @@ int qmri_lsqr_run(qmri_ctx* ctx, int B, const double2* d_z, double r, double tol
             if (timed_out) {                                       // repeat with the two-launch iteration, from the untouched inputs
                 fprintf(stderr, "libqmri: the one-launch LSQR timed out waiting for a partial sum; using the two-launch iteration from now on\n");
                 ctx->ks_persist = 0;
+                ctx->ks_timeouts += 1;
                 persisted = false;
                 QMRI_TRY(ks_launch_init(ctx, op, ks, B));
             }

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <chrono>
 #include <cstdlib>
 
 void qmri_free_operator(qmri_ctx* ctx);
@@ -259,6 +260,17 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     const float* w = weights;
     const int nb = desc->nb;
     const size_t B = (size_t)max_batch;
+    // (qmri_get_health: where the set-up time goes -- the layers' weight packing and upload, the tensors, the calibration probe)
+    typedef std::chrono::steady_clock Clk;
+    const auto t_begin = Clk::now();
+    double ms_pack = 0.0;
+    auto add_layer_timed = [&](qmri_ctx* c, ConvKind kind, int cin, int cout, const float*& wp) {
+        const auto t0 = Clk::now();
+        const int rc = add_layer(c, kind, cin, cout, wp);
+        ms_pack += std::chrono::duration<double, std::milli>(Clk::now() - t0).count();
+        return rc;
+    };
+#define add_layer add_layer_timed
     if (desc->arch == QMRI_ARCH_UNETRES) {
         const int32_t* nc = desc->nc;
         QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, nc[0], w));
@@ -311,9 +323,16 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     QMRI_TRY(dev_alloc(ctx, &p.d_counter, (size_t)1));
     QMRI_HIP(ctx, hipMemset(p.d_counter, 0, sizeof(unsigned)));
     if (qmri_knob(K_CONV_STAMPS)) { QMRI_HIP(ctx, hipMalloc(&p.d_stamps, 4096 * 11 * sizeof(unsigned long long))); }
+#undef add_layer
     p.counter_base = 0;
     p.ready = true;
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t_cal = Clk::now();
     if (p.sp6 == 2) QMRI_TRY(net_calibrate_scheme(ctx));
+    const auto t_end = Clk::now();
+    p.setup_ms[0] = ms_pack;
+    p.setup_ms[2] = std::chrono::duration<double, std::milli>(t_end - t_cal).count();
+    p.setup_ms[1] = std::chrono::duration<double, std::milli>(t_cal - t_begin).count() - ms_pack;
     return QMRI_OK;
 }
 
@@ -497,6 +516,23 @@ extern "C" int qmri_denoiser_scheme(const qmri_ctx* ctx, int* scheme_out, int* f
     return QMRI_OK;
 }
 
+extern "C" int qmri_get_health(const qmri_ctx* ctx, qmri_health* out) {
+    if (!ctx || !out) return QMRI_ERR_INVALID_ARG;
+    const NetPlan& p = ctx->net;
+    std::memset(out, 0, sizeof *out);
+    out->denoiser_scheme = p.ready ? p.sp6 : 0;
+    out->denoiser_fallbacks = p.ready ? p.fallbacks : 0;
+    out->resident_armed = (p.ready && !p.res_off && p.sp6 == 2 && qmri_knob(K_CONV_RESIDENT) != 0) ? 1 : 0;
+    out->resident_timeouts = p.res_timeouts;
+    out->lsqr_one_launch = (ctx->ks_persist < 0) ? -1 : (ctx->ks_persist > 0 ? 1 : 0);
+    out->lsqr_timeouts = ctx->ks_timeouts;
+    out->repeated_calls = ctx->admm_repeats;
+    out->last_call_wall_ms = ctx->last_call_wall_ms;
+    for (int i = 0; i < 4; ++i) out->last_call_stage_ms[i] = ctx->last_call_ms[i];
+    for (int i = 0; i < 3; ++i) out->set_denoiser_ms[i] = p.setup_ms[i];
+    return QMRI_OK;
+}
+
 extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C, int B, double* out) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
@@ -563,22 +599,73 @@ extern "C" int qmri_denoise(qmri_ctx* ctx, const double* in, int H, int W, int C
 // ---------------------------------------------------------------------------------------------------
 struct StageTimer {
     qmri_ctx* ctx;
-    bool on;
-    explicit StageTimer(qmri_ctx* c) : ctx(c), on(c->prof_level >= 1) {}
-    void start() { if (on) (void)hipEventRecord(ctx->ev[0], ctx->stream); }
+    bool on, marks;
+    int cur = -1;
+    explicit StageTimer(qmri_ctx* c) : ctx(c), on(c->prof_level == 1 || c->prof_level == 2), marks(c->prof_level == 3) {
+        c->marks_n = 0;
+        for (double& v : c->last_call_ms) v = 0.0;
+    }
+    void start() {
+        if (on) (void)hipEventRecord(ctx->ev[0], ctx->stream);
+        if (marks) {
+            if (ctx->marks_n + 2 > ctx->marks.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { marks = false; return; }
+                ctx->marks.push_back(a); ctx->marks.push_back(b); ctx->mark_kind.push_back(0);
+            }
+            cur = (int)ctx->marks_n;
+            (void)hipEventRecord(ctx->marks[cur], ctx->stream);
+        }
+    }
     void stop(double& acc) {
-        if (!on) return;
-        (void)hipEventRecord(ctx->ev[1], ctx->stream);
-        (void)hipEventSynchronize(ctx->ev[1]);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-        acc += ms;
+        if (on) {
+            (void)hipEventRecord(ctx->ev[1], ctx->stream);
+            (void)hipEventSynchronize(ctx->ev[1]);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+            acc += ms;
+            ctx->last_call_ms[kind_of(acc)] += ms;
+        }
+        if (marks && cur >= 0) {
+            (void)hipEventRecord(ctx->marks[cur + 1], ctx->stream);
+            ctx->mark_kind[cur / 2] = kind_of(acc);
+            ctx->marks_n = (size_t)cur + 2;
+            cur = -1;
+        }
+    }
+    int kind_of(const double& acc) const {
+        const qmri_profile& p = ctx->prof;
+        return (&acc == &p.ms_xupdate) ? 0 : (&acc == &p.ms_denoiser) ? 1 : (&acc == &p.ms_elementwise) ? 2 : 3;
+    }
+    // after the call's final synchronisation: the marks become stage times (profile and last_call_ms)
+    void resolve() {
+        if (!marks) return;
+        for (size_t i = 0; i + 1 < ctx->marks_n; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->marks[i], ctx->marks[i + 1]) != hipSuccess) continue;
+            const int k = ctx->mark_kind[i / 2];
+            ctx->last_call_ms[k] += ms;
+            (k == 0 ? ctx->prof.ms_xupdate : k == 1 ? ctx->prof.ms_denoiser : k == 2 ? ctx->prof.ms_elementwise : ctx->prof.ms_diag) += ms;
+        }
+        ctx->marks_n = 0;
     }
 };
 
+static int pnp_admm_dev_impl(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* prm, const void* d_x0,
+                             const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out);
+
+// (the wall clock of the call, repeats included, for qmri_get_health)
 extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* prm, const void* d_x0,
                                  const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int st = pnp_admm_dev_impl(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+    ctx->last_call_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+static int pnp_admm_dev_impl(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_admm_params* prm, const void* d_x0,
+                             const void* d_gt, void* d_x_out, double* diag_out, int32_t* lsqr_iters_out) {
     QMRI_HIP(ctx, hipSetDevice(ctx->device));
     OpHost& o = ctx->op;
     NetPlan& net = ctx->net;
@@ -702,6 +789,7 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
     if (prm->want_diag && diag_out && prm->iters > 0 && !range_trip)
         QMRI_HIP(ctx, hipMemcpyAsync(diag_out, o.d_diag, (size_t)B * prm->iters * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    tm.resolve();                                                  // (profile level 3: the stage marks of this call)
     QMRI_TRY(qmri_prof_chain_finish(ctx));                         // (profile level 2: the LSQR launches since the last forward pass)
     if (prm->solver == QMRI_SOLVER_LSQR && !range_trip) {          // LSQR counts of the iterations whose state was deferred; a timed-out one-launch kernel
         bool timed_out = false;
@@ -718,8 +806,9 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         if (timed_out) {                                           // (never seen) everything after it is garbage: once more with the two-launch iteration
             fprintf(stderr, "libqmri: the one-launch LSQR timed out waiting for a partial sum; repeating the reconstruction with the two-launch iteration\n");
             ctx->ks_persist = 0;
+            ctx->ks_timeouts += 1; ctx->admm_repeats += 1;
             ctx->prof = prof_at_entry;
-            return qmri_pnp_admm_dev(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+            return pnp_admm_dev_impl(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
         }
     }
     if (prm->iters > 0) {
@@ -728,7 +817,8 @@ extern "C" int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, co
         QMRI_TRY(net_range_tripped(ctx, again));
         if (again) {
             ctx->prof = prof_at_entry;                     // the repeated run is the one that counts
-            return qmri_pnp_admm_dev(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
+            ctx->admm_repeats += 1;
+            return pnp_admm_dev_impl(ctx, nslices, d_y, prm, d_x0, d_gt, d_x_out, diag_out, lsqr_iters_out);
         }
     }
     return QMRI_OK;
@@ -963,7 +1053,11 @@ extern "C" int qmri_dict_match(qmri_ctx* ctx, const void* X, int Npix, float* qm
 // compute stream and the results (x, maps) are copied to the pinned set on a COPY stream behind an event; the host then moves the PREVIOUS launch's
 // results from its pinned set into the caller's (pageable) arrays while the device works, and goes on to launch k + 1, whose kernels overlap the
 // copies of launch k.  Before: pageable hipMemcpy of 8 MB per slice plus a synchronise and two small copies per slice, all in series with the compute.
-static int recon_worker(int device, int widx, int nworkers, int nslices, const qmri_problem* pb, const char* Y, char* X_out,
+// shared_device (round 6): another worker of this call uses the same GPU.  The launches that need the device to themselves -- the one-launch LSQR
+// iteration (one workgroup per CU, every unit resident at once) and the resident-tile convolution launch -- would then be partially resident
+// side by side, both would wait to their time-outs and the reconstruction would be repeated: such a worker starts on the two-launch iteration
+// and one launch per layer (same bits, tested).
+static int recon_worker(int device, bool shared_device, int widx, int nworkers, int nslices, const qmri_problem* pb, const char* Y, char* X_out,
                         float* qmap_out, float* pd_out, std::string* err) {
     qmri_ctx* ctx = nullptr;
     int st = qmri_create(device, &ctx);
@@ -993,6 +1087,10 @@ static int recon_worker(int device, int widx, int nworkers, int nslices, const q
         if ((st = qmri_set_operator(ctx, pb->N, pb->M, pb->s, pb->T, pb->V, pb->frame_ptr, pb->kidx, spl)) != QMRI_OK) { bail(st); break; }
         if ((st = qmri_set_denoiser(ctx, pb->net, pb->weights, pb->weights_nbytes, pb->N, pb->M, spl)) != QMRI_OK) { bail(st); break; }
         if (pb->K > 0 && (st = qmri_set_dictionary(ctx, pb->K, pb->s, pb->Q, pb->D, pb->normD, pb->lut)) != QMRI_OK) { bail(st); break; }
+        if (shared_device) {
+            if ((st = qmri_debug_lsqr_persist(ctx, 0)) != QMRI_OK) { bail(st); break; }
+            if ((st = qmri_debug_conv_resident(ctx, 0, nullptr)) != QMRI_OK) { bail(st); break; }
+        }
         bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
         for (int j = 0; j < 2 && ok; ++j) {
             Set& S = set[j];
@@ -1054,10 +1152,13 @@ extern "C" int qmri_recon_batch(int ndev, const int* devs, int nslices, const qm
     std::vector<std::thread> th;
     std::vector<int> status(ndev, QMRI_OK);
     std::vector<std::string> errs(ndev);
-    for (int w = 0; w < ndev; ++w)
-        th.emplace_back([&, w]() {
-            status[w] = recon_worker(devs[w], w, ndev, nslices, prob, (const char*)Y, (char*)X_out, qmap_out, pd_out, &errs[w]);
+    for (int w = 0; w < ndev; ++w) {
+        bool shared = false;
+        for (int v = 0; v < ndev; ++v) shared = shared || (v != w && devs[v] == devs[w]);
+        th.emplace_back([&, w, shared]() {
+            status[w] = recon_worker(devs[w], shared, w, ndev, nslices, prob, (const char*)Y, (char*)X_out, qmap_out, pd_out, &errs[w]);
         });
+    }
     for (auto& t : th) t.join();
     for (int w = 0; w < ndev; ++w)
         if (status[w] != QMRI_OK) { report("device " + std::to_string(devs[w]) + ": " + errs[w]); return status[w]; }

@@ -38,7 +38,7 @@ constexpr int KT = 256;          // threads of every kernel in this file
 // Capacities of a work unit (round 5): the iteration kernels are instantiated for three shapes of unit, chosen when the operator is planned
 // (api_core.cpp, KS_CAPS in qmri_internal.h) so that a single slice's units fit the chip at once and the one-launch iteration applies:
 //   0  64 slots x 1024 samples   the spiral masks of cut1 ... cut3 (11 051 sampled k, ~11 samples each at T = 200): ~250 units
-//   1  256 slots x 1024 samples  masks that sample EVERY k a few times (EPI: 50 176 k x 2.7 samples): 196 - 250 units instead of 784
+//   1  256 slots x  768 samples  masks that sample EVERY k a few times (EPI: 50 176 k x 2.7 samples): 196 - 250 units instead of 784
 //   2  64 slots x 2560 samples   few k, many samples each (spiral cut0, T = 1000: 56 per k): ~248 units instead of 604
 template <int ID_, int SCAP_, int ECAP_, int GCAP_, int SL_> struct KsCaps {
     static constexpr int ID = ID_, SCAP = SCAP_, ECAP = ECAP_, GCAP = GCAP_, SL = SL_, GCAPB = ECAP_ / GCAP_ + SCAP_;   // GCAP samples per scatter group, SL lanes share one

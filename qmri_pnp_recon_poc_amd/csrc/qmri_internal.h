@@ -235,6 +235,7 @@ struct NetPlan {
     unsigned res_epoch = 0;
     bool res_off = false;
     bool res_forced_off = false;     // ... by qmri_debug_conv_resident(ctx, 0, ..): never re-armed
+    double setup_ms[3] = {0, 0, 0};  // qmri_set_denoiser: weight packing + upload / tensors and buffers / calibration probe (qmri_get_health)
     int res_timeouts = 0;            // hand-off time-outs since qmri_set_denoiser (three: the form stays off)
     int res_clean = 0;               // clean one-launch-per-layer passes since the last one (K_RES_REARM of them re-arm the form)
     int res_drop = 0;                // test hook: bit 0 = tile 0 withholds its hand-off
@@ -325,6 +326,16 @@ struct qmri_ctx {
     int ks_persist_cap = -1;            // ... workgroups of it the device holds at once (occupancy query, first use)
     void* d_ks_gran = nullptr;          // ... its tagged partial sums (granules)
     unsigned ks_tag = 16;               // ... tag of the next solve's first granule (tags are unique across solves)
+    // round 6 (qmri_get_health): what a slow or repeated reconstruction was doing.  Counters since qmri_create.
+    int ks_timeouts = 0;                // one-launch LSQR kernels that gave up waiting for a partial sum (the solve / reconstruction was repeated)
+    int admm_repeats = 0;               // qmri_pnp_admm_dev calls that ran their reconstruction a second time (LSQR time-out, f16 range guard, hand-off time-out)
+    // profile level 3: stage MARKS -- event records at the stage boundaries of the PnP-ADMM loop, never waited for inside the loop; resolved after
+    // the call's own final synchronisation into prof.ms_* and last_call_ms (level 1 synchronises at every boundary and is for stage splits only)
+    std::vector<hipEvent_t> marks;      // [2i] start, [2i+1] stop of a stage interval
+    std::vector<int> mark_kind;         // 0 x-update, 1 denoiser, 2 elementwise, 3 diagnostics
+    size_t marks_n = 0;
+    double last_call_ms[4] = {0, 0, 0, 0};   // stage times of the most recent qmri_pnp_admm_dev call (levels 1 and 3)
+    double last_call_wall_ms = 0;            // ... its host wall clock, entry to return (always)
     int conv_ncu = 0;                   // f32-MFMA conv kernels (conv_kernels.hip): CU count and resident workgroups per CU by (kind, MT)
     int conv_occ[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 };

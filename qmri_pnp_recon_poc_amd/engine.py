@@ -251,6 +251,22 @@ class Engine:
         self._check(self.L.qmri_denoiser_scheme(self.h, C.byref(sc), C.byref(fb)))
         return sc.value, fb.value
 
+    def health(self) -> dict:
+        """qmri_get_health: which self-checking fast paths are armed, how often one gave up (the work was then repeated on the slower path, same
+        results), and wall clock + stage times of the most recent qmri_pnp_admm_dev call (stages: profile level 1 or 3)."""
+        from ._lib import Health
+        h = Health()
+        self._check(self.L.qmri_get_health(self.h, C.byref(h)))
+        st = list(h.last_call_stage_ms)
+        return {"denoiser_scheme": {0: None, 2: "f16x3", 3: "bf16x6"}.get(h.denoiser_scheme, str(h.denoiser_scheme)),
+                "denoiser_fallbacks": h.denoiser_fallbacks, "resident_tile_launch_armed": bool(h.resident_armed),
+                "resident_tile_timeouts": h.resident_timeouts, "lsqr_one_launch": {-1: "undecided", 0: "off", 1: "armed"}.get(h.lsqr_one_launch, "armed"),
+                "lsqr_one_launch_timeouts": h.lsqr_timeouts, "repeated_calls": h.repeated_calls,
+                "last_call_wall_ms": round(h.last_call_wall_ms, 3),
+                "last_call_stage_ms": {"xupdate": round(st[0], 3), "denoiser": round(st[1], 3), "elementwise": round(st[2], 3), "diagnostics": round(st[3], 3)},
+                "set_denoiser_ms": {"pack_and_upload": round(h.set_denoiser_ms[0], 2), "tensors_and_buffers": round(h.set_denoiser_ms[1], 2),
+                                    "calibration_probe": round(h.set_denoiser_ms[2], 2)}}
+
     def denoise(self, x):
         """I = denoiseImage_PnP_ADMM(x, net, true, residual_noise): x [H,W,C] or [H,W,C,B] double."""
         x = np.asarray(x, dtype=np.float64)

@@ -21,6 +21,7 @@
 #include "qmri.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -59,9 +60,9 @@ static qmri_ctx* ctx() {
     if (!g_ctx) {
         int st = qmri_create(g_device, &g_ctx);
         if (st != QMRI_OK) mexErrMsgIdAndTxt("qmri:create", "%s", qmri_last_error(nullptr));
-        static bool registered = false;
-        if (!registered) { mexAtExit(cleanup); mexLock(); registered = true; }
     }
+    static bool registered = false;
+    if (!registered) { mexAtExit(cleanup); mexLock(); registered = true; }
     return g_ctx;
 }
 
@@ -79,6 +80,14 @@ static void want(bool ok, const char* id, const char* msg) {
     if (!ok) mexErrMsgIdAndTxt(id, "%s", msg);
 }
 static bool is_cdouble(const mxArray* a) { return mxIsDouble(a) && mxIsComplex(a); }
+// a MATLAB scalar that is about to become an int / size_t: real, finite, integer-valued and inside [lo, hi] BEFORE the cast (a NaN or a negative
+// double cast to an integer type is undefined behaviour)
+static int int_arg(const mxArray* a, double lo, double hi, const char* id, const char* msg) {
+    want(a && mxIsDouble(a) && !mxIsComplex(a) && mxGetNumberOfElements(a) == 1, id, msg);
+    const double v = mxGetScalar(a);
+    want(std::isfinite(v) && v == std::floor(v) && v >= lo && v <= hi, id, msg);
+    return (int)v;
+}
 static size_t image_numel() {                                       // N * M * s of the planned operator
     want(g_op.V != nullptr, "qmri:state", "no operator: call qmri_mex('set_operator', ...) (qmri_make_F) first");
     return (size_t)g_op.N * (size_t)g_op.M * mxGetN(g_op.V);
@@ -86,6 +95,7 @@ static size_t image_numel() {                                       // N * M * s
 static size_t dims_numel(const mxArray* d) {                        // the [N M s] argument
     want(mxIsDouble(d) && !mxIsComplex(d) && mxGetNumberOfElements(d) == 3, "qmri:size", "the size argument must be [N M s]");
     const double* v = mxGetDoubles(d);
+    for (int i = 0; i < 3; ++i) want(std::isfinite(v[i]) && v[i] == std::floor(v[i]) && v[i] >= 1 && v[i] <= 1e6, "qmri:size", "[N M s] must hold positive integers");
     const size_t n = (size_t)v[0] * (size_t)v[1] * (size_t)v[2];
     want(n == image_numel(), "qmri:size", "[N M s] does not match the operator (N x M grid, s = columns of V)");
     return n;
@@ -144,11 +154,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 
     if (c == "device") {                             // qmri_mex('device', d): the GPU of the single-context commands (plans are re-made on it)
         need(nrhs, 2, "qmri_mex('device', d)");
-        const int d = (int)mxGetScalar(prhs[1]);
+        const int d = int_arg(prhs[1], 0, 1023, "qmri:device", "the device id must be a non-negative integer");
         if (d != g_device || !g_ctx) {
-            if (g_ctx) { qmri_destroy(g_ctx); g_ctx = nullptr; }
-            g_device = d;
-            (void)ctx();
+            // try the new device first: a failed qmri_create must leave the gateway on the device it had (with its context and plans)
+            qmri_ctx* fresh = nullptr;
+            if (qmri_create(d, &fresh) != QMRI_OK) mexErrMsgIdAndTxt("qmri:create", "%s", qmri_last_error(nullptr));
+            if (g_ctx) qmri_destroy(g_ctx);
+            g_ctx = fresh; g_device = d;
+            (void)ctx();                                            // (registers the exit hook and the lock on first use)
             if (g_op.V) plan_operator(std::max(1, g_op.max_batch));
             if (g_net.w) plan_denoiser(std::max(1, g_net.max_batch));
             if (g_dict.D) plan_dictionary();
@@ -164,10 +177,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             const int32_t total = ((const int32_t*)mxGetData(prhs[4]))[T];
             want(total >= 0 && mxGetNumberOfElements(prhs[5]) == (size_t)total, "qmri:set_operator:size", "kidx must have frame_ptr(end) entries");
         }
+        const int Nn = int_arg(prhs[1], 1, 65536, "qmri:set_operator:size", "N must be a positive integer");
+        const int Mm = int_arg(prhs[2], 1, 65536, "qmri:set_operator:size", "M must be a positive integer");
+        const int mb = nrhs > 6 ? int_arg(prhs[6], 1, 4096, "qmri:set_operator:size", "max_batch must be a positive integer") : 1;
         drop(g_op.V); drop(g_op.fp); drop(g_op.kidx);
-        g_op.N = (int)mxGetScalar(prhs[1]); g_op.M = (int)mxGetScalar(prhs[2]);
+        g_op.N = Nn; g_op.M = Mm;
         g_op.V = keep(prhs[3]); g_op.fp = keep(prhs[4]); g_op.kidx = keep(prhs[5]);
-        plan_operator(nrhs > 6 ? std::max(1, (int)mxGetScalar(prhs[6])) : 1);
+        plan_operator(mb);
     } else if (c == "build_spiral" || c == "build_epi") {   // [frame_ptr, kidx] = qmri_mex('build_spiral', N, S, T)   (host integer code: no GPU needed)
         need(nrhs, 4, "[frame_ptr, kidx] = qmri_mex('build_spiral', N, S, T) | qmri_mex('build_epi', N, M, pct, T)");
         const int N = (int)mxGetScalar(prhs[1]);
@@ -239,8 +255,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (mxIsComplex(prhs[1]) || !mxIsDouble(prhs[1]) || nd > 4)
             mexErrMsgIdAndTxt("images:denoiseImage:invalidImageFormat", "A must be a real double H x W x C (x N) array");
         const int H = (int)dm[0], W = (int)dm[1], C = nd > 2 ? (int)dm[2] : 1, B = nd > 3 ? (int)dm[3] : 1;
+        // the library writes H * W * (the PLAN's out_nc) * B doubles: the output array is sized from the plan, and what the caller says is checked
+        // against it here (an out_nc below the plan's would otherwise be a write past the end of a MATLAB array)
+        want(g_net.w != nullptr, "qmri:state", "no denoiser: call qmri_mex('set_denoiser' | 'load_onnx', ...) (qmri_make_net) first");
+        want(H == g_net.H && W == g_net.W && C == g_net.d.in_nc, "qmri:denoise:size", "A must be H x W x in_nc (x N) as given to set_denoiser");
+        want(int_arg(prhs[2], 1, 1 << 20, "qmri:denoise:size", "out_nc must be a positive integer") == g_net.d.out_nc, "qmri:denoise:size",
+             "out_nc does not match the denoiser's output channels");
+        want(B >= 1, "qmri:denoise:size", "A holds no slice");
         reserve(B, false, true);                                    // a batch larger than the plan: re-planned, as the reference's handle takes any N
-        const mwSize od[4] = {(mwSize)H, (mwSize)W, (mwSize)mxGetScalar(prhs[2]), (mwSize)B};
+        const mwSize od[4] = {(mwSize)H, (mwSize)W, (mwSize)g_net.d.out_nc, (mwSize)B};
         plhs[0] = mxCreateNumericArray(B > 1 ? 4 : 3, od, mxDOUBLE_CLASS, mxREAL);
         check(qmri_denoise(ctx(), mxGetDoubles(prhs[1]), H, W, C, B, mxGetDoubles(plhs[0])));
     } else if (c == "pnp_admm") {                    // [x, diag, lsqr_iters] = qmri_mex('pnp_admm', y, param_struct, X0, gt, [N M s])

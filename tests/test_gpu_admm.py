@@ -289,7 +289,7 @@ def test_cut0_T1000_admm_and_match_at_bench_K(engine_mod, oracle, synth):
     e.close()
 
 
-def test_recon_batch_two_workers(engine_mod, oracle, synth):
+def test_recon_batch_two_workers(engine_mod, oracle, synth, capfd):
     """qmri_recon_batch with two workers (host threads, one context each) -- both on device 0 here, one per GPU on a node: the
     slice shards are disjoint, every slice comes back in its own slot, results equal the single-worker run bit for bit."""
     from qmri_pnp_recon_poc_amd import batch
@@ -299,11 +299,35 @@ def test_recon_batch_two_workers(engine_mod, oracle, synth):
                    for sl in range(5)])
     kw = dict(N=32, M=32, V=dic["V"], frame_ptr=fp, kidx=k, weights=w, in_nc=s, out_nc=s, nc=nc, nb=2, dictionary=dic, iters=4)
     one = batch.recon_batch([0], ys, slices_per_launch=2, **kw)
+    capfd.readouterr()
     two = batch.recon_batch([0, 0], ys, slices_per_launch=2, **kw)
+    assert "timed out" not in capfd.readouterr().err                 # (workers that share a device do not start on the forms that need it to themselves)
     assert np.array_equal(one["X"], two["X"])
     assert np.array_equal(one["qmap"], two["qmap"])
     xo, _, _ = oracle.pnp_admm(op, oracle.Net(w, in_nc=s, out_nc=s, nc=nc, nb=2), ys[4], iters=4)
     assert rel_err(two["X"][4], xo) < 1e-4
+
+
+def test_recon_batch_eight_workers_sixteen_slices(engine_mod, oracle, synth, capfd):
+    """The N = 8 shape of qmri_recon_batch without eight GPUs: EIGHT workers -- eight host threads, eight contexts -- in ONE
+    process, sixteen slices, two per launch, all on device 0 here (one per GPU on a node).  Every slice comes back in its own slot and equals the
+    one-worker run bit for bit.  Workers that share a device start on the two-launch LSQR iteration and one launch per layer (the one-launch forms
+    need the device to themselves; round 5's advice): nothing may time out on the way."""
+    from qmri_pnp_recon_poc_amd import batch
+    dic, X0, fp, k, op, y0, nc, w = _small_case(oracle, synth)
+    s = X0.shape[2]
+    ys = np.stack([synth.awgn_measured(op.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(32, seed=sl), dic)), 30.0, seed=sl)
+                   for sl in range(16)])
+    kw = dict(N=32, M=32, V=dic["V"], frame_ptr=fp, kidx=k, weights=w, in_nc=s, out_nc=s, nc=nc, nb=2, dictionary=dic, iters=3)
+    one = batch.recon_batch([0], ys, slices_per_launch=2, **kw)
+    capfd.readouterr()
+    eight = batch.recon_batch([0] * 8, ys, slices_per_launch=2, **kw)
+    err = capfd.readouterr().err
+    assert "timed out" not in err, err
+    assert np.array_equal(one["X"], eight["X"]) and np.array_equal(one["qmap"], eight["qmap"]) and np.array_equal(one["pd"], eight["pd"])
+    assert len({one["X"][i].tobytes() for i in range(16)}) == 16    # sixteen different slices, each in its own slot
+    xo, _, _ = oracle.pnp_admm(op, oracle.Net(w, in_nc=s, out_nc=s, nc=nc, nb=2), ys[15], iters=3)
+    assert rel_err(eight["X"][15], xo) < 1e-4
 
 
 @pytest.mark.parametrize("config", ["spiral_single_level_10ch", "epi_multi_level_11ch"])
@@ -397,3 +421,44 @@ def test_fused_small_launches_equal_separate_kernels(tmp_path):
             assert np.array_equal(a, b), (k, a, b)
         else:
             assert rel_err(a, b) < 1e-12, (k, rel_err(a, b))
+
+
+def test_health_counters_are_zero_on_a_clean_run_and_count_what_was_provoked(engine_mod, synth):
+    """qmri_get_health (round 6): the fast paths that check themselves -- the one-launch LSQR iteration, the resident-tile convolution launch, the
+    f16 scheme's range guards -- count every time they give up and the work is repeated on the slower path.  A clean reconstruction leaves every
+    counter at zero and both forms armed; a provoked LSQR time-out and a provoked hand-off time-out each show up, with the same x."""
+    E = engine_mod
+    N, T, s, S = 64, 48, 10, 200
+    dic = synth.make_dictionary(T=T, n_t1=16, n_t2=8, s=s)
+    fp, k = E.build_spiral(N, S, T)
+    w = synth.structured_weights(in_nc=s, out_nc=s, nc=(64, 64, 64, 64), nb=2, seed=5, eps=0.05)      # (nc[0] = 64: the resident-tile form applies)
+    eng = E.Engine(0)
+    eng.set_operator(N, N, dic["V"], fp, k)
+    eng.set_denoiser(w, N, N, nc=(64, 64, 64, 64), nb=2)
+    y = synth.awgn_measured(eng.forward(synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=1), dic)), 30.0, seed=1)
+    h = eng.health()
+    assert h["denoiser_scheme"] == "f16x3" and h["set_denoiser_ms"]["pack_and_upload"] > 0 and h["set_denoiser_ms"]["calibration_probe"] > 0
+    eng.profile_enable(3)                                           # stage marks: no wait inside the loop, resolved after the call
+    x0, _, li0 = eng.pnp_admm(y, iters=4)
+    eng.profile_enable(0)
+    h = eng.health()
+    assert (h["denoiser_fallbacks"], h["resident_tile_timeouts"], h["lsqr_one_launch_timeouts"], h["repeated_calls"]) == (0, 0, 0, 0)
+    assert h["resident_tile_launch_armed"] and h["lsqr_one_launch"] == "armed" and h["last_call_wall_ms"] > 0
+    st = h["last_call_stage_ms"]
+    assert st["xupdate"] > 0 and st["denoiser"] > 0 and st["elementwise"] > 0 and st["diagnostics"] == 0
+    assert sum(st.values()) <= h["last_call_wall_ms"] * 1.001
+    # the marks change nothing, and a run without them leaves the stage fields at zero
+    x1, _, li1 = eng.pnp_admm(y, iters=4)
+    assert np.array_equal(x0, x1) and np.array_equal(li0, li1) and sum(eng.health()["last_call_stage_ms"].values()) == 0
+    # provoked: one partial sum of the one-launch LSQR kernel is withheld -> time-out, the reconstruction is repeated on the two-launch iteration
+    eng._check(eng.L.qmri_debug_lsqr_persist(eng.h, 2))
+    x2, _, li2 = eng.pnp_admm(y, iters=4)
+    h = eng.health()
+    assert np.array_equal(x0, x2) and np.array_equal(li0, li2)
+    assert h["lsqr_one_launch_timeouts"] == 1 and h["repeated_calls"] == 1 and h["lsqr_one_launch"] == "off"
+    # provoked: one tile of the resident-tile launch publishes nothing -> its neighbours time out, the forward pass is repeated, one launch per layer
+    eng._check(eng.L.qmri_debug_conv_resident(eng.h, 2, None))
+    x3, _, _ = eng.pnp_admm(y, iters=2)
+    h = eng.health()
+    assert h["resident_tile_timeouts"] >= 1 and h["repeated_calls"] >= 2 and not h["resident_tile_launch_armed"] and h["denoiser_fallbacks"] == 0
+    eng.close()

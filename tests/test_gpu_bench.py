@@ -78,6 +78,25 @@ def test_bench_line_has_roofline_cpu_baseline_and_parity():
     assert pa["admm_iters_compared"] == 6 and pa["tsmi_rel_l2"] < 1e-3 and pa["lsqr_iteration_counts_identical"]
     assert pa["atom_index_identical_frac"] > pa["atom_index_identical_frac_bound_at_this_K"] >= 0.85 and pa["pd_rel_err"] < 1e-3 and pa["tsmi_psnr_db_mean"] > 60
     assert pa["net_rel_l2_random_weights"] < 2e-5 and pa["net_random_weights_scheme"] == [2, 0]      # every level of the network matters here
+    # round 6: a slow or repeated phase must be able to say why -- every phase object carries the library's own health record, zero on a clean run
+    clean = {"denoiser_fallbacks": 0, "resident_tile_timeouts": 0, "lsqr_one_launch_timeouts": 0, "repeated_calls": 0}
+    for h in (out["health"], sl["health"], ep["health"], c0["health"]):
+        assert h["denoiser_scheme"] == "f16x3" and all(h[k] == v for k, v in clean.items()), h
+    assert out["health"]["resident_tile_launch_armed"] and out["health"]["lsqr_one_launch"] == "armed" and out["health"]["all_ranks"] == clean
+    assert sl["health"]["all_ranks"] == clean and len(sl["rank_seconds"]["per_rank"]) == 1 and sl["rank_seconds"]["max"] >= sl["rank_seconds"]["min"] > 0
+    sw = sl["slowest_launch_rank0"]                                  # stage marks of the timed launches: the stages account for the launch
+    assert set(sw["stage_ms"]) == {"xupdate", "denoiser", "elementwise", "diagnostics"} and sw["stage_ms"]["denoiser"] > sw["stage_ms"]["xupdate"] > 0
+    assert 0.5 * sw["library_wall_ms"] < sw["stages_sum_ms"] <= sw["library_wall_ms"] * 1.001
+    # ... the cold start of ONE reconstruction (the reference's unit of work) is on the line
+    cs = out["cold_start"]
+    assert set(cs["setup_ms"]) >= {"qmri_create", "qmri_set_operator", "qmri_set_denoiser", "qmri_set_dictionary", "total"} and cs["dict_K"] == 98304
+    assert cs["time_to_first_slice_s"] > cs["first_reconstruction_s"] > 0 and cs["same_reconstruction_again_s"] > 0
+    assert set(cs["setup_ms"]["qmri_set_denoiser_split"]) == {"pack_and_upload", "tensors_and_buffers", "calibration_probe"}
+    # ... the x-update's roofline object says what binds it and carries PMC traffic where a committed pass exists for the configuration
+    for xo in (xu, ep["xupdate"], c0["xupdate"]):
+        r = xo["roofline"]
+        assert r["effective_gbs"] == r["achieved"] and r["binding_limit"].startswith("latency") and (r["traffic"] is None or r["traffic"] > 0)
+    assert cb["slices_K"] == 98304 and cb["dict_match_s_at_slices_K"] > 0
     wd = out["with_diagnostics"]                                                                      # PnP_ADMM.m:106-109 on the GPU side too
     # (6 steps each: which of the two short timed regions is faster is noise; a sanity bound)
     assert 0 < wd["value"] <= out["value"] * 1.5 and 0 < wd["last_data_fidelity_rel"] < 1 and 0 < wd["last_gt_rel_err"] < 1

@@ -49,6 +49,17 @@ def test_single_slice_commands_equal_the_python_host_side(mex, engine_mod, oracl
     assert xa.shape == (N, N, s) and np.array_equal(xa, e.adjoint(y))
     img = np.random.default_rng(1).random((N, N, s))
     assert np.array_equal(mex.qmri_mex("denoise", img, float(s), nargout=1), e.denoise(img))
+    # round 6 (advice): the output array is sized from the PLAN; an out_nc, H, W or C that disagrees with it is an error with an identifier,
+    # never a write past the end of a MATLAB array
+    for args in ((img, float(s - 1)), (img, float("nan")), (img[:, :, :-1], float(s)), (img[:-1], float(s))):
+        with pytest.raises(mex.MexError) as err:
+            mex.qmri_mex("denoise", np.ascontiguousarray(args[0]), args[1], nargout=1)
+        assert err.value.id == "qmri:denoise:size"
+    # ... and a failed 'device' leaves the gateway on the device (and the plans) it had
+    with pytest.raises(mex.MexError) as err:
+        mex.qmri_mex("device", 900.0)
+    assert err.value.id == "qmri:create"
+    assert np.array_equal(mex.qmri_mex("denoise", img, float(s), nargout=1), e.denoise(img))
     prm = {"gamma": 0.05, "iter": 5, "cg_tol": 1e-4, "multi_level": 0, "noise_std": 0.01}
     x, diag, li = mex.qmri_mex("pnp_admm", y.astype(np.complex128), prm, np.zeros((0, 0)), np.asarray(X0, np.complex128), np.array([N, N, s], np.float64), nargout=3)
     xe, de, le = e.pnp_admm(y, iters=5, gt=X0, want_diag=True)

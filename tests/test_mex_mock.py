@@ -56,6 +56,20 @@ def test_gateway_usage_errors_are_matlab_errors():
     with pytest.raises(MexError) as e:
         qmri_mex("dict_match", np.zeros((16, 2), np.complex128), 2.0, nargout=1)
     assert e.value.id == "qmri:state"                               # no dictionary
+    # round 6 (advice): scalars are checked BEFORE they are cast to an integer type (a NaN or a negative double cast to int / size_t is undefined)
+    for bad in (float("nan"), -1.0, 2.5, float("inf")):
+        with pytest.raises(MexError) as e:
+            qmri_mex("set_operator", bad, 32.0, V, fp, k)
+        assert e.value.id == "qmri:set_operator:size"
+        with pytest.raises(MexError) as e:
+            qmri_mex("set_operator", 32.0, 32.0, V, fp, k, bad)                     # max_batch
+        assert e.value.id == "qmri:set_operator:size"
+        with pytest.raises(MexError) as e:
+            qmri_mex("device", bad)
+        assert e.value.id == "qmri:device"
+    with pytest.raises(MexError) as e:
+        qmri_mex("denoise", np.zeros((8, 8, 2)), 2.0, nargout=1)
+    assert e.value.id == "qmri:state" and "set_denoiser" in e.value.msg          # nothing to size the output against: refused, not guessed
 
 
 def test_gateway_fails_loudly_without_a_gpu():

@@ -48,6 +48,7 @@ for idx, (name, T, mask, B) in enumerate((("spiral cut3", 200, "spiral", 1), ("E
     it = max(pr["admm_iters"], 1)
     print(json.dumps({"config": name, "T": T, "m": int(fp[-1]), "slices_per_launch": B, "admm_iters": ITERS,
                       "lsqr_iters_mean_per_xupdate": round(float(li.mean()), 2),
+                      "lsqr_iters_per_slice_all_runs": round(2 * ITERS * float(li.mean()), 2),     # (both run() calls: what a PMC pass over this process has seen)
                       "xupdate_ms_per_admm_iter": round(pr["ms_xupdate"] / it, 4), "xupdate_ms_per_slice_iter": round(pr["ms_xupdate"] / it / B, 4),
                       "denoiser_ms_per_admm_iter": round(pr["ms_denoiser"] / it, 4), "elementwise_ms_per_admm_iter": round(pr["ms_elementwise"] / it, 4),
                       "us_per_lsqr_iteration_incl_fixed": round(pr["ms_xupdate"] / it / max(float(li.mean()), 1e-9) * 1e3, 2)}), flush=True)
