@@ -282,9 +282,9 @@ def load_xupdate_traffic(key):
         with open(XUPDATE_TRAFFIC_FILE) as f:
             t = json.load(f)
         e = t["configs"][key]
-        return int(e["bytes_per_lsqr_iteration"]), e.get("kernels", "") + "; " + t.get("source", "")
+        return int(e["bytes_per_lsqr_iteration"]), e.get("kernels", "") + "; " + t.get("source", ""), t.get("one_launch_iteration_phases_us")
     except (OSError, KeyError, ValueError):
-        return None, f"no PMC pass for {key} in profiles/xupdate_traffic.json (tools/pmc_xupdate.sh)"
+        return None, f"no PMC pass for {key} in profiles/xupdate_traffic.json (tools/pmc_xupdate.sh)", None
 
 
 def xupdate_roofline(pr, ns, s, m, B, one_launch, traffic_key=None):
@@ -302,7 +302,7 @@ def xupdate_roofline(pr, ns, s, m, B, one_launch, traffic_key=None):
         # the x-updates ~ lsqr_iters / B (slices of a batch iterate together)
         us = pr["ms_lsqr_kernels"] * 1e3 / (li / B)
         gbs = byt * B / (us * 1e-6) / 1e9
-        traffic, tsrc = load_xupdate_traffic(traffic_key) if traffic_key else (None, None)
+        traffic, tsrc, phases = load_xupdate_traffic(traffic_key) if traffic_key else (None, None, None)
         # What bounds this stage is LATENCY, not bandwidth: the one-launch form keeps the iteration's state in registers and LDS and an iteration is two
         # grid-wide all-reduces of tagged granules.  `achieved` is therefore the ALGORITHMIC rate (the contract's definition: algorithmic bytes / duration)
         # and is labelled as an effective rate; `traffic` is what the PMC counters saw leave / enter the L2s per iteration, and `traffic_gbs` that over the
@@ -315,6 +315,7 @@ def xupdate_roofline(pr, ns, s, m, B, one_launch, traffic_key=None):
                                  "traffic_over_algorithmic": round(traffic / (byt * B), 4) if traffic else None,
                                  "binding_limit": "latency: " + ("two grid-wide all-reduces per LSQR iteration inside one launch" if one_launch else
                                                                   "two dependent launches per LSQR iteration") + f" = {us:.2f} us per iteration",
+                                 "one_launch_iteration_phases_us": phases if one_launch else None,
                                  "note": "achieved = algorithmic bytes of an iteration (all slices of the batch) / duration of the iteration's kernels from their own "
                                          "dispatch timestamps: an EFFECTIVE rate" + (" (the one-launch form keeps the state on chip; traffic = PMC bytes per iteration)" if one_launch else "")}})
     return out

@@ -26,6 +26,7 @@ const KnobDef g_knob_defs[K_COUNT] = {
     {"res_stamps", 0}, {"conv_stamps", 0}, {"conv_stamp_launch", -1}, {"lsqr_stamps", 0},
     {"conv_mt2", 1024}, {"conv_occ", 2},
     {"fuse_ew", 1}, {"lsqr_persist", 1}, {"lsqr_fold", 1}, {"dictw_lsp", 2}, {"verbose", 0},
+    {"pack_gpu", 1},
 };
 std::atomic<int> g_knob_val[K_COUNT];
 std::once_flag g_knob_once;
@@ -482,6 +483,11 @@ extern "C" int qmri_set_operator(qmri_ctx* ctx, int N, int M, int s, int T, cons
     ks.hst = nullptr; ks.st = ls.st; ks.pz = ls.pz; ks.nblk_z = ls.nblk_z; ks.yk = ls.yk; ks.pdiag = nullptr;
     o.xhat_valid = false;
     o.ginv_r = -1.0;
+    // Round 6: every table above went to the device by blocking copies on the NULL stream, and the kernels that read them run on this context's
+    // NON-BLOCKING stream, which is not ordered with it.  hipMemcpy returns once the host buffer has been consumed; beside another process on the
+    // device the transfer itself was seen to land AFTER kernels of a later call had started (tools/probe_under_contention.py: a set-up probe reading
+    // weights that had not arrived).  One device-wide synchronisation per plan closes that for every later launch.
+    QMRI_HIP(ctx, hipDeviceSynchronize());
     o.ready = true;
     return QMRI_OK;
 }
@@ -560,6 +566,7 @@ extern "C" int qmri_set_coils(qmri_ctx* ctx, int ncoil, const void* maps) {
     const size_t count = (size_t)ncoil * o.N * o.M;
     QMRI_HIP(ctx, hipMalloc((void**)&o.d_coils, count * sizeof(double2)));
     QMRI_HIP(ctx, hipMemcpy(o.d_coils, maps, count * sizeof(double2), hipMemcpyHostToDevice));
+    QMRI_HIP(ctx, hipDeviceSynchronize());                        // (as in qmri_set_operator: the copy must have landed before this context's stream reads it)
     o.ncoil = ncoil;
     return QMRI_OK;
 }

@@ -41,6 +41,7 @@ void qmri_free_net(qmri_ctx* ctx) {
     NetPlan& p = ctx->net;
     for (ConvLayer& L : p.layers) { if (L.wp) (void)hipFree(L.wp); if (L.d_tab) (void)hipFree(L.d_tab); if (L.wp6) (void)hipFree(L.wp6); }
     for (float* b : p.allocs) if (b) (void)hipFree(b);
+    if (p.d_wflat) (void)hipFree(p.d_wflat);
     if (p.d_counter) (void)hipFree(p.d_counter);
     if (p.d_stamps) (void)hipFree(p.d_stamps);
     if (p.d_c6part) (void)hipFree(p.d_c6part);
@@ -78,21 +79,68 @@ static int pack_layer6(qmri_ctx* ctx, ConvLayer& L, const float* w) {
     return QMRI_OK;
 }
 
+static size_t layer_weight_count(const ConvLayer& L) { return (size_t)L.Cin * L.Cout * ((L.kind == CONV_3X3 || L.kind == CONV_3X3N) ? 9 : 4); }
+
+// knob pack_gpu = 1 (default, round 6): the layer is only PLANNED here; net_pack_all_dev splits and orders every layer's weights on the device.
+// pack_gpu = 0: the host packers (round 1; kept as the reference of the packing and for the sanitised host build), layer by layer.
 static int add_layer(qmri_ctx* ctx, ConvKind kind, int Cin, int Cout, const float*& w) {
     ConvLayer L;
     conv_plan_layer(L, kind, Cin, Cout);
-    std::vector<float> packed;
-    L.wp_floats = conv_pack_weights(L, w, packed);
-    hipError_t e = hipMalloc((void**)&L.wp, packed.size() * sizeof(float));
-    if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
-    QMRI_HIP(ctx, hipMemcpy(L.wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.w_off = (size_t)(w - ctx->net.w_begin);
     L.sp6 = ctx->net.sp6;
-    QMRI_TRY(pack_layer6(ctx, L, w));                      // the same weights, split for the bf16 / f16 matrix-core kernels
-    const int taps = (kind == CONV_3X3) ? 9 : 4;
-    w += (size_t)Cin * Cout * taps;
+    if (!ctx->net.d_wflat) {
+        std::vector<float> packed;
+        L.wp_floats = conv_pack_weights(L, w, packed);
+        hipError_t e = hipMalloc((void**)&L.wp, packed.size() * sizeof(float));
+        if (e != hipSuccess) { qmri_set_error(ctx, "hipMalloc (weights) failed: %s", hipGetErrorString(e)); return QMRI_ERR_NOMEM; }
+        QMRI_HIP(ctx, hipMemcpy(L.wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        QMRI_TRY(pack_layer6(ctx, L, w));                      // the same weights, split for the bf16 / f16 matrix-core kernels
+    }
+    w += layer_weight_count(L);
     L.index = (int)ctx->net.layers.size();
     ctx->net.layers.push_back(L);
     return QMRI_OK;
+}
+
+static int pack_layer6_dev(qmri_ctx* ctx, ConvLayer& L) {
+    const NetPlan& p = ctx->net;
+    const float mx = (L.index >= 0 && (size_t)L.index < p.w_max.size()) ? p.w_max[L.index] : 0.f;
+    if (L.kind == CONV_3X3 || L.kind == CONV_3X3N) return conv6_pack_dev(ctx, L, p.d_wflat + L.w_off, mx);
+    return conv6s_pack_dev(ctx, L, p.d_wflat + L.w_off, mx);
+}
+
+// The device side of qmri_set_denoiser's weight handling: every layer's largest |w| (the f16 scheme's per-layer scale and its range check), then
+// the three packings per layer as kernels reading the flat blob in device memory.  One host synchronisation (the maxima).
+static int net_pack_all_dev(qmri_ctx* ctx) {
+    NetPlan& p = ctx->net;
+    const size_t nl = p.layers.size();
+    unsigned* d_max = nullptr;
+    QMRI_HIP(ctx, hipMalloc((void**)&d_max, std::max<size_t>(nl, 1) * sizeof(unsigned)));
+    int rc = QMRI_OK;
+    do {
+        if (hipMemsetAsync(d_max, 0, nl * sizeof(unsigned), ctx->stream) != hipSuccess) { rc = QMRI_ERR_HIP; break; }
+        for (size_t l = 0; l < nl && rc == QMRI_OK; ++l)
+            rc = ew_launch_absmax(ctx, p.d_wflat + p.layers[l].w_off, nullptr, layer_weight_count(p.layers[l]), d_max + l);
+        if (rc != QMRI_OK) break;
+        std::vector<unsigned> bits(nl);
+        if (hipMemcpyAsync(bits.data(), d_max, nl * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = QMRI_ERR_HIP; break; }
+        p.w_max.resize(nl);
+        bool fit = true;
+        for (size_t l = 0; l < nl; ++l) {
+            std::memcpy(&p.w_max[l], &bits[l], 4);
+            if (!(p.w_max[l] <= 60000.f)) fit = false;             // (conv6_weights_fit_f16: the f16 pieces carry |w| <= 6e4; NaN too)
+        }
+        if (p.sp6 == 2 && !fit) p.sp6 = 3;                         // weights beyond the f16 range: bf16 scheme
+        for (ConvLayer& L : p.layers) {
+            L.sp6 = p.sp6;
+            if ((rc = conv_pack_weights_dev(ctx, L, p.d_wflat + L.w_off)) != QMRI_OK) break;
+            if ((rc = pack_layer6_dev(ctx, L)) != QMRI_OK) break;
+        }
+    } while (0);
+    (void)hipFree(d_max);
+    if (rc == QMRI_ERR_HIP && ctx->err.empty()) qmri_set_error(ctx, "HIP failure while packing the denoiser's weights on the device");
+    return rc;
 }
 
 // Re-pack every layer for the other operand-splitting scheme (sp = 2: f16 x 3 products, sp = 3: bf16 x 6 products).
@@ -100,13 +148,13 @@ static int net_set_scheme(qmri_ctx* ctx, int sp) {
     NetPlan& p = ctx->net;
     if (p.sp6 == sp) return QMRI_OK;
     QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const float* w = p.w_host.data();
     for (ConvLayer& L : p.layers) {
         if (L.wp6) { (void)hipFree(L.wp6); L.wp6 = nullptr; }
         L.sp6 = sp;
-        QMRI_TRY(pack_layer6(ctx, L, w));
-        w += (size_t)L.Cin * L.Cout * ((L.kind == CONV_3X3 || L.kind == CONV_3X3N) ? 9 : 4);
+        if (p.d_wflat) QMRI_TRY(pack_layer6_dev(ctx, L));
+        else QMRI_TRY(pack_layer6(ctx, L, p.w_host.data() + L.w_off));
     }
+    if (!p.d_wflat) QMRI_HIP(ctx, hipDeviceSynchronize());         // (the host packers' copies travel on the NULL stream: see qmri_set_denoiser)
     p.sp6 = sp;
     return QMRI_OK;
 }
@@ -249,9 +297,17 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     qmri_free_net(ctx);
     NetPlan& p = ctx->net;
     p.desc = *desc; p.H = H; p.W = W; p.maxB = max_batch;
-    p.w_host.assign(weights, weights + nbytes / 4);
+    p.w_begin = weights;
     p.sp6 = conv6_default_sp();
-    if (p.sp6 == 2 && !conv6_weights_fit_f16(weights, nbytes / 4)) p.sp6 = 3;     // weights beyond the f16 range: bf16 scheme
+    const auto t_upload = std::chrono::steady_clock::now();
+    if (qmri_knob(K_PACK_GPU)) {
+        // the caller's blob goes to the device once, as it is; every packing is a kernel over it (net_pack_all_dev) and a later change of scheme re-packs from it
+        QMRI_HIP(ctx, hipMalloc((void**)&p.d_wflat, nbytes));
+        QMRI_HIP(ctx, hipMemcpyAsync(p.d_wflat, weights, nbytes, hipMemcpyHostToDevice, ctx->stream));   // (on the stream the packing kernels run on: ordered with them)
+    } else {
+        p.w_host.assign(weights, weights + nbytes / 4);
+        if (p.sp6 == 2 && !conv6_weights_fit_f16(weights, nbytes / 4)) p.sp6 = 3;     // weights beyond the f16 range: bf16 scheme
+    }
     QMRI_HIP(ctx, hipMalloc((void**)&p.d_range_flag, sizeof(unsigned)));
     QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof(unsigned)));
     p.h_range_words = 4096;
@@ -263,7 +319,7 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     // (qmri_get_health: where the set-up time goes -- the layers' weight packing and upload, the tensors, the calibration probe)
     typedef std::chrono::steady_clock Clk;
     const auto t_begin = Clk::now();
-    double ms_pack = 0.0;
+    double ms_pack = std::chrono::duration<double, std::milli>(t_begin - t_upload).count();      // (the blob's upload / host copy and range check)
     auto add_layer_timed = [&](qmri_ctx* c, ConvKind kind, int cin, int cout, const float*& wp) {
         const auto t0 = Clk::now();
         const int rc = add_layer(c, kind, cin, cout, wp);
@@ -311,6 +367,13 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
         QMRI_TRY(alloc_tensor(ctx, p.a[0], width, conv_cin_pad(CONV_3X3, width), H, W, B));
         QMRI_TRY(alloc_tensor(ctx, p.t[0], width, conv_cin_pad(CONV_3X3, width), H, W, B));
     }
+    if (p.d_wflat) {
+        const auto t0 = Clk::now();
+        QMRI_TRY(net_pack_all_dev(ctx));
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (the time of the packing kernels belongs to this figure)
+        ms_pack += std::chrono::duration<double, std::milli>(Clk::now() - t0).count();
+    }
+    p.w_begin = nullptr;                                           // (the caller's pointer is not kept)
     QMRI_TRY(alloc_tensor(ctx, p.in32, desc->in_nc, conv_cin_pad(CONV_3X3, desc->in_nc), H, W, B));
     QMRI_TRY(alloc_tensor(ctx, p.out32, desc->out_nc, desc->out_nc, H, W, B));
     // BLOCKED interior tensors (PTensor::blk): every layer on the conv6 kernels, every interior channel count a multiple of 8
@@ -326,13 +389,16 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
 #undef add_layer
     p.counter_base = 0;
     p.ready = true;
-    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (device-wide: the host packers' blocking copies travel on the NULL stream, which this context's non-blocking stream is not ordered with -- beside
+    //  another process on the device the set-up probe below was seen to read weights that had not landed and to choose the bf16 scheme for a network
+    //  that does not need it, five times out of six: tools/probe_under_contention.py, profiles/r06_e_*)
+    QMRI_HIP(ctx, hipDeviceSynchronize());
     const auto t_cal = Clk::now();
     if (p.sp6 == 2) QMRI_TRY(net_calibrate_scheme(ctx));
     const auto t_end = Clk::now();
     p.setup_ms[0] = ms_pack;
     p.setup_ms[2] = std::chrono::duration<double, std::milli>(t_end - t_cal).count();
-    p.setup_ms[1] = std::chrono::duration<double, std::milli>(t_cal - t_begin).count() - ms_pack;
+    p.setup_ms[1] = std::chrono::duration<double, std::milli>(t_cal - t_upload).count() - ms_pack;
     return QMRI_OK;
 }
 
@@ -932,6 +998,7 @@ extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const flo
         if (st != QMRI_OK) { qmri_free_dict(ctx); return st; }
         QMRI_HIP(ctx, hipMemcpy(d.d_normD, normD, (size_t)K * sizeof(float), hipMemcpyHostToDevice));
         QMRI_HIP(ctx, hipMemcpy(d.d_lut, lut, (size_t)K * Q * sizeof(float), hipMemcpyHostToDevice));
+        QMRI_HIP(ctx, hipDeviceSynchronize());                    // (blocking copies on the NULL stream; this context's stream is not ordered with it)
         d.ready = true;
         return QMRI_OK;
     }
@@ -985,6 +1052,7 @@ extern "C" int qmri_set_dictionary(qmri_ctx* ctx, int K, int s, int Q, const flo
             d.marg_coef = (float)(std::ldexp(1.0, -14) * r2max * (double)g * (double)g * 1.001);
         }
     }
+    QMRI_HIP(ctx, hipDeviceSynchronize());                        // (blocking copies on the NULL stream; this context's stream is not ordered with it)
     d.ready = true;
     return QMRI_OK;
 }

@@ -317,6 +317,39 @@ inline void host_split(int sp, float v, uint16_t (&h)[3], float scale = 1.f) {
         std::memcpy(&h[0], &hi, 2); std::memcpy(&h[1], &lo, 2); h[2] = 0;
     }
 }
+// the same pieces on the device (the weight packers of qmri_set_denoiser, round 6): integer arithmetic for bf16 exactly as host_bf16; the f16
+// conversions are the hardware's round-to-nearest-even, as the host compiler's (_Float16) casts; every fp32 step is a single rounded operation
+__device__ __forceinline__ unsigned short dev_bf16(float x) {
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void dev_split(int sp, float v, unsigned short (&h)[3], float scale) {
+    v = __fmul_rn(v, scale);
+    if (sp == 3) {
+        h[0] = dev_bf16(v);
+        const float r1 = __fsub_rn(v, __uint_as_float((unsigned)h[0] << 16));
+        h[1] = dev_bf16(r1);
+        const float r2 = __fsub_rn(r1, __uint_as_float((unsigned)h[1] << 16));
+        h[2] = dev_bf16(r2);
+    } else {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)__fmul_rn(__fsub_rn(v, (float)hi), LO_SCALE);
+        h[0] = __builtin_bit_cast(unsigned short, hi); h[1] = __builtin_bit_cast(unsigned short, lo); h[2] = 0;
+    }
+}
+// the layer's power-of-two weight scale from its largest |w| (conv6_weight_scale's arithmetic; the maximum itself comes from the device)
+static float conv6_scale_from_max(ConvLayer& L, float mx) {
+    L.w6_descale = 1.f;
+    if (L.sp6 != 2) return 1.f;
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+    int e = 0;
+    (void)std::frexp(mx, &e);
+    const int k = std::min(60, std::max(-60, 1 - e));
+    L.w6_descale = std::ldexp(1.f, -k);
+    return std::ldexp(1.f, k);
+}
 // f16 scheme: the layer's weights are packed times 2^k with the largest |w| in [1, 2), and the epilogue multiplies by 2^-k -- both
 // exact.  An f16 piece below 6.1e-5 is subnormal and carries an absolute, not a relative error; scaling keeps a layer of
 // uniformly small weights (say 1e-5) as accurate as any other.  Returns the factor and records its inverse in the layer.

@@ -63,8 +63,10 @@ __device__ __forceinline__ void conv6_body(const Conv6Args& A) {
     static_assert(SP == 3 ? (PXT * OTP * 4 <= 2 * 3 * 2 * NPX * 16) : (PXT * OTP * 4 <= (NABUF * AST + 2 * SP * 2 * NPX) * 16), "pixel-major output tile must fit the operand buffers");
     const int tid = threadIdx.x;
     int bid = A.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    // which 32-row half of the 64-row tile (MH = 2)
-    const int mh = (MH > 1) ? bid % MH : 0;
+    // (Measured and removed, round 6: at the 28 x 28 level, where a workgroup reads more weight than activation bytes, the PIXEL tiles of one
+    //  weight tile consecutive instead -- an XCD's L2 then shares weights, 1.2 MB read eight times, instead of activations: 871 / 875 against
+    //  867 / 875 ADMM it/s, profiles/r06_c_ab_deep_level_weight_major_tile_order_not_kept.txt: the loaders do not wait for the Infinity Cache.)
+    const int mh = (MH > 1) ? bid % MH : 0;                         // which 32-row half of the 64-row tile (MH = 2)
     if (MH > 1) bid /= MH;
     const int ct = bid % A.n_ct; bid /= A.n_ct;
     const int th = bid % A.tiles_h; bid /= A.tiles_h;
@@ -745,6 +747,48 @@ void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed
                             const size_t base = ((((size_t)ct * L.nchunk6 + chunk) * 9 + tap) * 2 + m) * SP;
                             for (int sp = 0; sp < SP; ++sp) packed[((base + sp) * 64 + lane) * 8 + j] = h[sp];
                         }
+}
+
+// The same packing on the device (round 6: qmri_set_denoiser spent 0.5 s splitting and ordering 32.6 M weights on one host thread -- four times the
+// reconstruction it serves).  One thread per (cout tile, chunk, tap, m, lane) entry gathers its 8 weights from the flat blob in device memory and
+// writes the SP uint4 of its pieces; entries outside the layer's channels are zeros, as conv6_plan_pack leaves them.  Same bits (tested).
+namespace {
+__global__ __launch_bounds__(256) void k_pack6_w(const float* __restrict__ w, uint4* __restrict__ out, int Cin, int Cout, int nchunk, long nent, int SP, float scale) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nent) return;
+    const int lane = (int)(e & 63), m = (int)((e >> 6) & 1);
+    long r = e >> 7;
+    const int tap = (int)(r % 9); r /= 9;
+    const int chunk = (int)(r % nchunk);
+    const int ct = (int)(r / nchunk);
+    const int row = ct * 64 + m * 32 + (lane & 31), ci0 = chunk * CK + 8 * (lane >> 5);
+    unsigned short h[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = ci0 + j;
+        const float v = (row < Cout && ci < Cin) ? w[((size_t)row * Cin + ci) * 9 + tap] : 0.f;
+        dev_split(SP, v, h[j], scale);
+    }
+    const long base = ((((long)ct * nchunk + chunk) * 9 + tap) * 2 + m) * SP;
+    for (int sp = 0; sp < SP; ++sp) {
+        uint4 o;
+        o.x = h[0][sp] | ((unsigned)h[1][sp] << 16); o.y = h[2][sp] | ((unsigned)h[3][sp] << 16);
+        o.z = h[4][sp] | ((unsigned)h[5][sp] << 16); o.w = h[6][sp] | ((unsigned)h[7][sp] << 16);
+        out[(base + sp) * 64 + lane] = o;
+    }
+}
+}  // namespace
+
+// d_w: this layer's weights in the flat blob on the device; wmax: its largest |w| (the scale's input).  Allocates L.wp6.
+int conv6_pack_dev(qmri_ctx* ctx, ConvLayer& L, const float* d_w, float wmax) {
+    L.nchunk6 = (L.Cin + CK - 1) / CK;
+    L.n_ct6 = (L.Cout + 63) / 64;
+    const float wscale = conv6_scale_from_max(L, wmax);
+    const long nent = (long)L.n_ct6 * L.nchunk6 * 9 * 2 * 64;
+    QMRI_HIP(ctx, hipMalloc(&L.wp6, (size_t)nent * L.sp6 * sizeof(uint4)));
+    k_pack6_w<<<dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_w, (uint4*)L.wp6, L.Cin, L.Cout, L.nchunk6, nent, L.sp6, wscale);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
 }
 
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,

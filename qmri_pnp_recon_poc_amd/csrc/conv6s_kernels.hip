@@ -333,6 +333,55 @@ void conv6s_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packe
                         }
 }
 
+// the same packing on the device (see conv6_pack_dev): one thread per (ct, step, plane, m, lane) entry
+namespace {
+__global__ __launch_bounds__(256) void k_pack6s_w(const float* __restrict__ w, uint4* __restrict__ out, int up, int Cin, int Cout, int nsteps, int nsteps_real,
+                                                   long nent, int SP, float scale) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nent) return;
+    const int lane = (int)(e & 63), m = (int)((e >> 6) & 1), plane = (int)((e >> 7) & 1);
+    long r = e >> 8;
+    const int g = (int)(r % nsteps);
+    const int ct = (int)(r / nsteps);
+    unsigned short h[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * (lane >> 5) + j;
+        float v = 0.f;
+        if (g < nsteps_real) {
+            if (up) {
+                const int kw = ct & 1, kh = m, co = (ct >> 1) * 32 + (lane & 31), ci = g * 32 + plane * 16 + k;
+                if (co < Cout && ci < Cin) v = w[(((size_t)ci * Cout + co) * 2 + kh) * 2 + kw];
+            } else {
+                const int kw = g & 1, kh = plane, row = ct * 64 + m * 32 + (lane & 31), ci = (g >> 1) * CK + k;
+                if (row < Cout && ci < Cin) v = w[(((size_t)row * Cin + ci) * 2 + kh) * 2 + kw];
+            }
+        }
+        dev_split(SP, v, h[j], scale);
+    }
+    const long base = ((((long)ct * nsteps + g) * 2 + plane) * 2 + m) * SP;
+    for (int sp = 0; sp < SP; ++sp) {
+        uint4 o;
+        o.x = h[0][sp] | ((unsigned)h[1][sp] << 16); o.y = h[2][sp] | ((unsigned)h[3][sp] << 16);
+        o.z = h[4][sp] | ((unsigned)h[5][sp] << 16); o.w = h[6][sp] | ((unsigned)h[7][sp] << 16);
+        out[(base + sp) * 64 + lane] = o;
+    }
+}
+}  // namespace
+
+int conv6s_pack_dev(qmri_ctx* ctx, ConvLayer& L, const float* d_w, float wmax) {
+    const bool up = (L.kind == CONV_UP);
+    L.nsteps6s = up ? (L.Cin + 31) / 32 : 2 * ((L.Cin + CK - 1) / CK);
+    L.nchunk6 = ((L.nsteps6s + 2) / 3) * 3;
+    L.n_ct6 = up ? 2 * ((L.Cout + 31) / 32) : (L.Cout + 63) / 64;
+    const float wscale = conv6_scale_from_max(L, wmax);
+    const long nent = (long)L.n_ct6 * L.nchunk6 * 2 * 2 * 64;
+    QMRI_HIP(ctx, hipMalloc(&L.wp6, (size_t)nent * L.sp6 * sizeof(uint4)));
+    k_pack6s_w<<<dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_w, (uint4*)L.wp6, up ? 1 : 0, L.Cin, L.Cout, L.nchunk6, L.nsteps6s, nent, L.sp6, wscale);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
 // returns false if the layer/tensors do not meet the kernel's alignment assumptions (the f32 kernel then runs)
 bool conv6s_usable(const ConvLayer& L, const PTensor& in, const PTensor& out) {
     if (!L.wp6 || (L.kind != CONV_DOWN && L.kind != CONV_UP)) return false;

@@ -494,6 +494,47 @@ size_t conv_pack_weights(const ConvLayer& L, const float* w, std::vector<float>&
     return total;
 }
 
+// the same packing on the device (round 6, see conv6_pack_dev): one thread per float4 of the packed layout
+namespace {
+__global__ __launch_bounds__(256) void k_pack_w32(const float* __restrict__ w, float4* __restrict__ out, int kind, int Cin, int Cout, int CC, int NTAP, int nch, long nent) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nent) return;
+    const int G = CC / 32;
+    const int lane = (int)(e & 63);
+    long r = e >> 6;
+    const int g = (int)(r % G); r /= G;
+    const int t = (int)(r % NTAP); r /= NTAP;
+    const int wave = (int)(r & 3); r >>= 2;
+    const int chunk = (int)(r % nch);
+    const int ct = (int)(r / nch);
+    const int row = ct * 32 + (lane & 31);
+    float v[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int ci = chunk * CC + wave * (CC / 4) + 2 * (4 * g + jj) + (lane >> 5);
+        v[jj] = 0.f;
+        if (ci >= Cin) continue;
+        if (kind == CONV_UP) {
+            const int kk = row / Cout, o = row - kk * Cout;
+            if (kk < 4) v[jj] = w[((size_t)ci * Cout + o) * 4 + kk];
+        } else if (row < Cout) v[jj] = w[((size_t)row * Cin + ci) * NTAP + t];
+    }
+    out[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+}  // namespace
+
+int conv_pack_weights_dev(qmri_ctx* ctx, ConvLayer& L, const float* d_w) {
+    const bool is3 = (L.kind == CONV_3X3 || L.kind == CONV_3X3N);
+    const int TH = is3 ? 3 : (L.kind == CONV_DOWN) ? 2 : 1;
+    const int CC = kind_cc(L.kind), NTAP = TH * TH, G = CC / 32, nch = L.cin_pad / CC;
+    const long nent = (long)L.n_ct * nch * 4 * NTAP * G * 64;
+    L.wp_floats = (size_t)nent * 4;
+    QMRI_HIP(ctx, hipMalloc((void**)&L.wp, L.wp_floats * sizeof(float)));
+    k_pack_w32<<<dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_w, (float4*)L.wp, (int)L.kind, L.Cin, L.Cout, CC, NTAP, nch, nent);
+    QMRI_HIP(ctx, hipGetLastError());
+    return QMRI_OK;
+}
+
 int conv_launch(qmri_ctx* ctx, ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                 const PTensor* add2, int relu_out) {
     if (L.wp6 && conv6_enabled() && !ctx->net.force_f32) {

@@ -245,6 +245,8 @@ __global__ __launch_bounds__(NT) void k_real_to_complex(size_t count, const doub
 int ew_launch_minmax_normalise(qmri_ctx* ctx, int B, size_t n, int plane, int H, int s, int multi_level, double noise_std,
                                const double2* x, const double2* u, double* mm, double* norm, int nblk, const PTensor& in32, bool mm_ready) {
     if (!mm_ready) k_minmax<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, x, u, mm);      // (else: nblk partials per slice are in mm already, k_adj_h)
+    // (measured and removed, round 6: 2 x / 4 x as many workgroups with shorter shares -- the grid need not equal the number of min / max partials --
+    //  865 ... 873 against 870 ADMM it/s, profiles/r06_c_ab_normalise_grid_multiplier_not_kept.txt)
     k_normalise<<<dim3(nblk, B), dim3(NT), 0, ctx->stream>>>(n, plane, H, s, multi_level, noise_std, x, u, mm, nblk, norm, in32.base1(),
                                                              in32.hp, (int)in32.plane(), in32.batch_stride());
     QMRI_HIP(ctx, hipGetLastError());

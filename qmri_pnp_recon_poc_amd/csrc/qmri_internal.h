@@ -62,6 +62,7 @@ enum QmriKnob {
     K_LSQR_FOLD,          // ... and the first Golub-Kahan step (k_ks_b<INIT>) inside that launch
     K_DICTW_LSP,
     K_VERBOSE,            // calibration / guard decisions on stderr
+    K_PACK_GPU,           // qmri_set_denoiser: weights split and ordered on the device (1, default) or on the host (0: the round-1 packers, same bits)
     K_COUNT
 };
 int qmri_knob(QmriKnob k);
@@ -173,6 +174,7 @@ struct ConvLayer {
     int nchunk6 = 0, n_ct6 = 0;   // 16-channel chunks (2x2 layers: K steps), 64-row output tiles of wp6
     int nsteps6s = 0;             // 2x2 layers: K steps that carry weights (nchunk6 is padded to a multiple of 3)
     int index = -1;               // position in NetPlan::layers (row of the |output| report, conv6_kernels.hip ACT_LOW)
+    size_t w_off = 0;             // first weight of this layer in the caller's flat blob (floats)
 };
 
 // activation tensor in HBM: [B][Cal][W+2][hp] fp32, h fastest, permanent zero halo, channels >= C are zero.
@@ -224,7 +226,10 @@ struct NetPlan {
     int sp6 = 2;                     // scheme the layers are packed for
     bool blk_ok = false;             // the network's interior tensors may be BLOCKED (PTensor::blk): every layer runs on the conv6 kernels, channels % 8 == 0
     int interior_fmt = -1;           // format the interior tensors were last written in (-1: untouched zeros, 0 planar, 1 blocked): a change re-zeroes them (halo)
-    std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme)
+    std::vector<float> w_host;       // the caller's weights (kept to re-pack the layers for the other scheme; knob pack_gpu = 0 only)
+    float* d_wflat = nullptr;        // ... on the device, in the caller's order (knob pack_gpu = 1, default: the packers run there)
+    const float* w_begin = nullptr;  // (inside qmri_set_denoiser only: start of the caller's blob, for the layers' offsets)
+    std::vector<float> w_max;        // ... and every layer's largest |w| (from the device): the f16 scheme's per-layer scale
     float* d_c6part = nullptr;       // split-K partial outputs of k_conv6 (conv6_kernels.hip), grown on demand
     size_t c6part_floats = 0;
     void* d_stamps = nullptr;        // diagnostic: per-workgroup timing stamps of the last conv launch (knob conv_stamps = 1)
@@ -407,6 +412,9 @@ int conv6_act_end(qmri_ctx* ctx);
 int conv6_default_sp();                                    // 2 = f16 x 3 products, 3 = bf16 x 6 products (knob conv_scheme = 3)
 bool conv6_weights_fit_f16(const float* w, size_t n);
 void conv6_plan_pack(ConvLayer& L, const float* w, std::vector<uint16_t>& packed);
+int conv6_pack_dev(qmri_ctx* ctx, ConvLayer& L, const float* d_w, float wmax);       // the same on the device from the flat blob there (allocates L.wp6)
+int conv6s_pack_dev(qmri_ctx* ctx, ConvLayer& L, const float* d_w, float wmax);
+int conv_pack_weights_dev(qmri_ctx* ctx, ConvLayer& L, const float* d_w);           // ... the f32 A-fragments of the fallback kernels (allocates L.wp)
 int conv6_launch(qmri_ctx* ctx, const ConvLayer& L, int B, const PTensor& in, const PTensor& out, const PTensor* add1,
                  const PTensor* add2, int relu_out);
 // a run of 3x3 layers of the full-resolution level as ONE launch with LDS-resident tiles (conv6_kernels.hip k_conv6r): nres = 2 nb ResBlock layers

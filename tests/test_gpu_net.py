@@ -572,3 +572,53 @@ def test_resident_tile_launch_other_image_sizes(engine_mod, synth, hw):
         assert np.array_equal(e.denoise(x), ref)
     assert e.conv_resident(1) == 0 and e.denoiser_scheme() == (2, 0)
     e.close()
+
+
+def test_weights_packed_on_the_device_equal_the_host_packers_bit_for_bit(engine_mod, synth):
+    """Round 6: qmri_set_denoiser splits and orders the weights on the device (knob pack_gpu = 1, default) instead of on one host thread
+    (0.5 s for the 32.6 M weights of the full network: four times the reconstruction it serves).  The packed weights must be the SAME bits as the
+    host packers' (knob pack_gpu = 0): checked through everything that reads them -- the f16 x 3 kernels, the bf16 x 6 kernels, the f32-MFMA
+    fallback kernels, a change of scheme after the first packing (net_set_scheme: the calibration probe moving a network to bf16 pieces), 10- and
+    11-channel inputs, the sequential architecture, channel counts that are no multiples of the tile sizes, weights spanning many decades (the
+    per-layer power-of-two scale comes from a device-side maximum)."""
+    from qmri_pnp_recon_poc_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+
+    def outputs(w, H, x, **net):
+        res = {}
+        for gpu in (0, 1):
+            assert L.qmri_debug_knob(b"pack_gpu", gpu) == 0
+            outs = []
+            for knobs in ((b"conv_scheme", 2), (b"conv_scheme", 3), (b"conv_f32", 1)):
+                assert L.qmri_debug_knob(knobs[0], knobs[1]) == 0
+                e = engine_mod.Engine(0)
+                e.set_denoiser(w, H, H, **net)
+                outs.append(e.denoise(x))
+                outs.append(np.array(e.denoiser_scheme()))
+                e.close()
+                assert L.qmri_debug_knob(b"conv_scheme", 2) == 0 and L.qmri_debug_knob(b"conv_f32", 0) == 0
+            res[gpu] = outs
+        assert L.qmri_debug_knob(b"pack_gpu", 1) == 0
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b)
+        assert np.all(np.isfinite(res[1][0]))
+        return res[1]
+
+    # full-width network at 32 x 32, weights under which every layer matters
+    o = outputs(synth.random_weights(seed=3, gain=0.7), 32, rng.random((32, 32, 10)), in_nc=10, out_nc=10, nc=(64, 128, 256, 512), nb=4)
+    assert tuple(o[1]) == (2, 0) and tuple(o[3]) == (3, 0)
+    # 11 input channels, odd channel counts (24 / 40 / 72 / 136: not multiples of 16, 32 or 64), layers scaled by 1e-2 ... 1e2 in turn
+    nc = (24, 40, 72, 136)
+    w = synth.random_weights(in_nc=11, nc=nc, nb=2, seed=5, gain=0.7).copy()
+    off = 0
+    for i, (_, shp) in enumerate(synth.unetres_weight_shapes(11, 10, nc, 2)):
+        n = int(np.prod(shp))
+        w[off:off + n] *= 10.0 ** ((i % 5) - 2)
+        off += n
+    outputs(w, 32, rng.random((32, 32, 11)), in_nc=11, out_nc=10, nc=nc, nb=2)
+    # the sequential architecture with a first layer of 1e-9-scale weights: the set-up probe moves it to bf16 pieces (net_set_scheme re-packs every
+    # layer from the copy of the blob the library keeps -- on the device with pack_gpu = 1, on the host with 0)
+    w2, x2 = _two_layer_case(synth, 1e-9, 1.0)
+    o = outputs(w2, 32, x2, in_nc=10, out_nc=10, nc=(32, 0, 0, 0), nb=2, arch=1)
+    assert tuple(o[1]) == (3, 0)                                    # (asked for f16 x 3, calibrated to bf16 x 6: the re-pack ran)
