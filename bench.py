@@ -105,6 +105,8 @@ def parse_args():
                     "part of configs[4]: a few seconds each)")
     ap.add_argument("--secondary-steps", type=int, default=20, help="... ADMM iterations timed for each of them")
     ap.add_argument("--slices-total", type=int, default=120, help="... its slice count")
+    ap.add_argument("--slices-batch", type=int, default=0, help="... slices advanced together per launch; 0 = auto: 30 where every rank holds at least 30 slices "
+                    "(N <= 4 of the 120-slice batch), else 15 -- what a rank holds at 8 GPUs (A/B on one box: 13.26 vs 12.83 slices/s, profiles/r06_f_*)")
     ap.add_argument("--slices-iters", type=int, default=100, help="... ADMM iterations per slice (PnP_ADMM.m: param.iter = 100)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="gloo", help="process-group backend of the barrier and the max over ranks -- the data path has "
                     "no collective (north_star: slices shard without RCCL), so the default is gloo on the host; nccl (= RCCL) does the same two things on the "
@@ -980,7 +982,8 @@ def worker(args):
     # ---- north_star's second metric in the same line: the fixed 120-slice batch over all ranks -----------------------------
     slices_obj = None
     if args.workload == "admm" and not args.no_slices and args.slices_total > 0:
-        slices_obj = slices_phase(args, rank, local_rank, world, dev, torch, dist, args.slices_total, args.batch, args.slices_iters, 2)
+        sb = args.slices_batch if args.slices_batch > 0 else (30 if args.slices_total // max(world, 1) >= 30 else 15)
+        slices_obj = slices_phase(args, rank, local_rank, world, dev, torch, dist, args.slices_total, sb, args.slices_iters, 2)
     # ---- the other single-GPU configurations of BASELINE.json on the same line (rank 0; the other ranks wait at the final barrier) ----------------
     secondary = {}
     if args.workload == "admm" and not args.no_secondary and rank == 0:

@@ -91,6 +91,13 @@ int qmri_adjoint_dev(qmri_ctx* ctx, const void* d_y, void* d_x, int batch);
 int qmri_set_coils(qmri_ctx* ctx, int ncoil, const void* maps);
 int qmri_forward_mc(qmri_ctx* ctx, const void* x, int x_is_complex, void* y);
 int qmri_adjoint_mc(qmri_ctx* ctx, const void* y, void* x);
+/* ... and the reconstruction on top of it (round 6; the same label: an extension, no reference counterpart, parity unpinned).  The x-update of
+ * PnP_ADMM.m:102,153-171 with A replaced by A_mc -- x = lsqr(@afun, [y_mc; sqrt(r) z], tol, maxit, [], [], x0), afun: [A_mc; sqrt(r) I] -- as an
+ * image-domain LSQR (coil maps act in image space, so the k-space iteration of the single-coil path does not apply), recurrences and stop rules as the
+ * single-coil restatement of MATLAB's lsqr; and the PnP-ADMM loop of PnP_ADMM.m:76-146 around it (x0 NULL: x = A_mc^H y as :84; returns x as :148).
+ * y_mc: m x ncoil complex doubles; z, x0, x_out: N x M x s complex doubles; lsqr_iters_out (nullable): prm->iters entries.  One slice, LSQR solver only. */
+int qmri_xupdate_mc(qmri_ctx* ctx, const void* y_mc, const void* z, double r, double tol, int maxit, const void* x0, void* x_out,
+                    int32_t* iters_out, int32_t* flag_out);
 /* The x-update alone: x = lsqr(@afun,[y; sqrt(r) z], tol, maxit, [], [], x)  (PnP_ADMM.m:102,153-171), or the
  * closed-form minimiser when solver == QMRI_SOLVER_DIRECT.  Host buffers; x is in/out (warm start). */
 int qmri_xupdate(qmri_ctx* ctx, const void* y, const void* z, double r, double tol, int maxit, int solver,
@@ -160,6 +167,8 @@ int qmri_pnp_admm_dev(qmri_ctx* ctx, int nslices, const void* d_y, const qmri_ad
  * What `PnP_ADMM_hip(Y, param)` calls for a measurement matrix; qmri_recon_batch is the pipelined multi-GPU form. */
 int qmri_pnp_admm_batch(qmri_ctx* ctx, int nslices, int slices_per_launch, const void* y, const qmri_admm_params* p, const void* x0,
                         const void* gt, void* x_out, double* diag_out, int32_t* lsqr_iters_out);
+/* Multi-coil extension of the loop (see qmri_xupdate_mc above: no reference counterpart, parity unpinned). */
+int qmri_pnp_admm_mc(qmri_ctx* ctx, const void* y_mc, const qmri_admm_params* prm, const void* x0, void* x_out, int32_t* lsqr_iters_out);
 
 /* ---- LRTV option: x = FISTA_deep(data, param), main_recon_tsmis_FFT.m:273-282 -------------------------- */
 /* FISTA with backtracking on 0.5 |y - F.forward(x)|^2 + K |x|_TV (FISTA_deep.m:31-104); the TV prox is unlocbox's

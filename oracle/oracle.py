@@ -178,6 +178,63 @@ class Operator:
             x += np.conj(maps[..., j, None]) * self.adjoint(y[:, j])
         return x
 
+    def lsqr_mc(self, y_mc, maps, z, r, tol=1e-4, maxit=100, x0=None):
+        """Multi-coil x-update (extension, no reference line): orc_lsqr.c's recurrences and stop rules, statement by statement, with the operator
+        replaced by forward_mc / adjoint_mc -- x = lsqr(@afun, [y_mc; sqrt(r) z], tol, maxit, [], [], x0), afun: [A_mc; sqrt(r) I].
+        Returns (x, iters, flag)."""
+        eps = np.finfo(np.float64).eps
+        y = np.asarray(y_mc, np.complex128)
+        z = np.asarray(z, np.complex128)
+        x = np.array(x0 if x0 is not None else np.zeros((self.N, self.M, self.s)), np.complex128)
+        sr = np.sqrt(r)
+        nsq = lambda a: float(np.sum(a.real ** 2) + np.sum(a.imag ** 2))
+        n2b = np.sqrt(nsq(y) + r * nsq(z))
+        tolb = tol * n2b
+        ut = y - self.forward_mc(x, maps)
+        ub = z * sr - x * sr
+        beta = np.sqrt(nsq(ut) + nsq(ub))
+        normr = beta
+        if beta != 0.0:
+            ut, ub = ut / beta, ub / beta
+        c, s_, phibar = 1.0, 0.0, beta
+        v = self.adjoint_mc(ut, maps) + ub * sr
+        alpha = np.sqrt(nsq(v))
+        if alpha != 0.0:
+            v = v / alpha
+        normar = alpha * beta
+        if normar == 0.0 or n2b == 0.0:
+            return x, 0, 0
+        d = np.zeros_like(x)
+        norma, stag, it, flag = 0.0, 0, maxit, 1
+        for ii in range(1, maxit + 1):
+            ut = self.forward_mc(v, maps) - alpha * ut
+            ub = v * sr - alpha * ub
+            beta = np.sqrt(nsq(ut) + nsq(ub))
+            ut, ub = ut / beta, ub / beta
+            norma = np.sqrt(norma * norma + alpha * alpha + beta * beta)
+            thet, rhot = -s_ * alpha, c * alpha
+            rho = np.sqrt(rhot * rhot + beta * beta)
+            c, s_ = rhot / rho, -beta / rho
+            phi = c * phibar
+            if phi == 0.0:
+                stag = 1
+            phibar = s_ * phibar
+            d = (v - thet * d) / rho
+            stag = stag + 1 if abs(phi) * np.sqrt(nsq(d)) < eps * np.sqrt(nsq(x)) else 0
+            if normar / (norma * normr) <= tol or normr <= tolb:
+                it, flag = ii - 1, 0
+                break
+            if stag >= 3:
+                it, flag = ii - 1, 3
+                break
+            x = x + phi * d
+            normr = abs(s_) * normr
+            v = (self.adjoint_mc(ut, maps) + ub * sr) - beta * v
+            alpha = np.sqrt(nsq(v))
+            v = v / alpha
+            normar = alpha * abs(s_ * phi)
+        return x, it, flag
+
     def lsqr(self, y, z, r, tol=1e-4, maxit=100, x0=None):
         yin, zin = _cplx_in(y), _cplx_in(z)
         x = _cplx_in(x0 if x0 is not None else np.zeros((self.N, self.M, self.s))).copy()
@@ -262,6 +319,27 @@ def pnp_admm(op: Operator, net: Net, y, gamma=0.05, iters=100, cg_tol=1e-4, cg_m
     lib().orc_pnp_admm(op.h, net.h, _dp(yin), C.byref(p), _dp(x0in), _dp(gtin), _dp(x), _dp(diag), _ip(li))
     xo = x.view(np.complex128).reshape((op.N, op.M, op.s), order="F")
     return xo, (diag.reshape(iters, 2) if diag is not None else None), li
+
+
+def pnp_admm_mc(op: Operator, net: Net, y_mc, maps, gamma=0.05, iters=100, cg_tol=1e-4, cg_maxit=100, multi_level=False, noise_std=0.01):
+    """Multi-coil extension (no reference counterpart, parity unpinned): the loop of PnP_ADMM.m:76-146 with F replaced by the SENSE operator
+    (Operator.forward_mc / adjoint_mc) -- x = F.adjoint(Y); v = x; uold = 0; repeat: x-update (lsqr_mc), min-max normalise real(x + uold) over the
+    whole stack, denoise in single precision, undo, dual update.  Returns (x, lsqr_iters)."""
+    x = op.adjoint_mc(y_mc, maps)
+    v = x.copy()
+    u = np.zeros_like(x)
+    li = np.zeros(iters, np.int32)
+    for it in range(iters):
+        x, li[it], _ = op.lsqr_mc(y_mc, maps, v - u, gamma, cg_tol, cg_maxit, x0=x)
+        w = np.real(x + u)
+        lo, hi = w.min(), w.max()
+        w = (w - lo) / (hi - lo)
+        if multi_level:
+            w = np.concatenate([w, np.full(w.shape[:2] + (1,), noise_std)], axis=2)
+        vv = net.denoise(w) * (hi - lo) + lo
+        u = u + x - vv
+        v = vv
+    return x, li
 
 
 def admm_stage_seconds() -> dict:

@@ -18,7 +18,7 @@ CSRC = os.path.join(_PKG, "csrc")
 SYMBOLS = [
     "qmri_abi_version", "qmri_create", "qmri_destroy", "qmri_last_error", "qmri_set_stream", "qmri_synchronize",
     "qmri_build_spiral", "qmri_build_epi", "qmri_set_operator", "qmri_operator_m", "qmri_forward", "qmri_adjoint",
-    "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_set_coils", "qmri_forward_mc", "qmri_adjoint_mc", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
+    "qmri_forward_f32", "qmri_adjoint_f32", "qmri_forward_dev", "qmri_adjoint_dev", "qmri_set_coils", "qmri_forward_mc", "qmri_adjoint_mc", "qmri_xupdate_mc", "qmri_pnp_admm_mc", "qmri_xupdate", "qmri_net_nparams", "qmri_set_denoiser", "qmri_denoise",
     "qmri_net_forward_dev", "qmri_denoiser_scheme", "qmri_pnp_admm", "qmri_pnp_admm_dev", "qmri_pnp_admm_batch", "qmri_set_dictionary", "qmri_dict_match",
     "qmri_dict_match_dev", "qmri_dict_match_xfit", "qmri_dict_match_xfit_dev", "qmri_recon_batch", "qmri_profile_enable", "qmri_profile_get", "qmri_get_health",
     "qmri_debug_lsqr_stamps", "qmri_debug_conv_stamps", "qmri_debug_lsqr_persist", "qmri_debug_dict_filter", "qmri_debug_conv_resident", "qmri_debug_knob",
@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
     L.qmri_set_coils.argtypes = [vp, i, vp]
     L.qmri_forward_mc.argtypes = [vp, vp, i, vp]
     L.qmri_adjoint_mc.argtypes = [vp, vp, vp]
+    L.qmri_xupdate_mc.argtypes = [vp, vp, vp, C.c_double, C.c_double, i, vp, vp, ip, ip]
+    L.qmri_pnp_admm_mc.argtypes = [vp, vp, C.POINTER(AdmmParams), vp, vp, ip]
     L.qmri_xupdate.argtypes = [vp, vp, vp, C.c_double, C.c_double, i, i, vp, ip, ip]
     L.qmri_net_nparams.restype = C.c_size_t
     L.qmri_net_nparams.argtypes = [C.POINTER(NetDesc)]

@@ -890,6 +890,94 @@ static int pnp_admm_dev_impl(qmri_ctx* ctx, int nslices, const void* d_y, const 
     return QMRI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Multi-coil extension (no reference counterpart: README.md:63 -- parity unpinned; mc_kernels.hip): the x-update and the PnP-ADMM loop of
+// PnP_ADMM.m:76-146 with A replaced by the SENSE operator of qmri_set_coils.  One slice; host arrays in, host arrays out.
+// ---------------------------------------------------------------------------------------------------
+int qmri_lsqr_mc_dev(qmri_ctx* ctx, const double2* d_y, const double2* d_z, double r, double tol, int maxit, double2* d_x, int32_t* iters_out, int32_t* flag_out);
+
+struct McStage {                                   // device copies of one multi-coil problem
+    double2 *y = nullptr, *z = nullptr, *x = nullptr;
+    ~McStage() { if (y) (void)hipFree(y); if (z) (void)hipFree(z); if (x) (void)hipFree(x); }
+};
+
+extern "C" int qmri_xupdate_mc(qmri_ctx* ctx, const void* y_mc, const void* z, double r, double tol, int maxit, const void* x0, void* x_out,
+                               int32_t* iters_out, int32_t* flag_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    OpHost& o = ctx->op;
+    if (!o.ready) { qmri_set_error(ctx, "operator not set: call qmri_set_operator first"); return QMRI_ERR_STATE; }
+    if (!o.ncoil) { qmri_set_error(ctx, "no coil maps set: call qmri_set_coils first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, y_mc && z && x_out && r > 0 && maxit >= 0, "y / z / x_out must not be NULL, r > 0, maxit >= 0");
+    const size_t n = (size_t)o.N * o.M * o.s, mtot = (size_t)o.ncoil * o.m;
+    McStage st;
+    QMRI_HIP(ctx, hipMalloc((void**)&st.y, mtot * sizeof(double2)));
+    QMRI_HIP(ctx, hipMalloc((void**)&st.z, n * sizeof(double2)));
+    QMRI_HIP(ctx, hipMalloc((void**)&st.x, n * sizeof(double2)));
+    QMRI_HIP(ctx, hipMemcpyAsync(st.y, y_mc, mtot * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    QMRI_HIP(ctx, hipMemcpyAsync(st.z, z, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    if (x0) QMRI_HIP(ctx, hipMemcpyAsync(st.x, x0, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    else QMRI_HIP(ctx, hipMemsetAsync(st.x, 0, n * sizeof(double2), ctx->stream));
+    QMRI_TRY(qmri_lsqr_mc_dev(ctx, st.y, st.z, r, tol, maxit, st.x, iters_out, flag_out));
+    QMRI_HIP(ctx, hipMemcpyAsync(x_out, st.x, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QMRI_OK;
+}
+
+extern "C" int qmri_pnp_admm_mc(qmri_ctx* ctx, const void* y_mc, const qmri_admm_params* prm, const void* x0, void* x_out, int32_t* lsqr_iters_out) {
+    if (!ctx) return QMRI_ERR_INVALID_ARG;
+    QMRI_HIP(ctx, hipSetDevice(ctx->device));
+    OpHost& o = ctx->op;
+    NetPlan& net = ctx->net;
+    if (!o.ready) { qmri_set_error(ctx, "operator not set: call qmri_set_operator first"); return QMRI_ERR_STATE; }
+    if (!o.ncoil) { qmri_set_error(ctx, "no coil maps set: call qmri_set_coils first"); return QMRI_ERR_STATE; }
+    if (!net.ready) { qmri_set_error(ctx, "denoiser not set: call qmri_set_denoiser first"); return QMRI_ERR_STATE; }
+    QMRI_CHECK_ARG(ctx, y_mc && prm && x_out, "y / params / x_out must not be NULL");
+    QMRI_CHECK_ARG(ctx, prm->iters >= 0 && prm->gamma > 0 && prm->cg_maxit >= 0 && prm->solver == QMRI_SOLVER_LSQR, "iters >= 0, gamma > 0, cg_maxit >= 0, LSQR solver required");
+    const int multi = prm->denoiser_type == QMRI_DENOISER_MULTI_LEVEL;
+    if (net.H != o.N || net.W != o.M || net.desc.in_nc != o.s + (multi ? 1 : 0) || net.desc.out_nc != o.s) {
+        qmri_set_error(ctx, "denoiser (%d x %d, %d -> %d channels) does not fit the operator (%d x %d x %d)", net.H, net.W, net.desc.in_nc, net.desc.out_nc, o.N, o.M, o.s);
+        return QMRI_ERR_INVALID_ARG;
+    }
+    const size_t plane = (size_t)o.N * o.M, n = plane * o.s, mtot = (size_t)o.ncoil * o.m;
+    McStage st;
+    QMRI_HIP(ctx, hipMalloc((void**)&st.y, mtot * sizeof(double2)));
+    QMRI_HIP(ctx, hipMalloc((void**)&st.x, n * sizeof(double2)));
+    QMRI_HIP(ctx, hipMemcpyAsync(st.y, y_mc, mtot * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    double2* scr = nullptr;                                        // [max_batch][n] coil images of the initial adjoint
+    QMRI_HIP(ctx, hipMalloc((void**)&scr, (size_t)o.maxB * n * sizeof(double2)));
+    struct Scr { double2* p; ~Scr() { if (p) (void)hipFree(p); } } scr_guard{scr};
+    if (x0) QMRI_HIP(ctx, hipMemcpyAsync(st.x, x0, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    else {                                                         // x = F.adjoint(Y)  (PnP_ADMM.m:84)
+        for (int j0 = 0; j0 < o.ncoil; j0 += o.maxB) {
+            const int cnt = std::min(o.maxB, o.ncoil - j0);
+            QMRI_TRY(dc_launch_adj(ctx, qmri_opdev(ctx), cnt, st.y + (size_t)j0 * o.m, o.d_tmp, scr));
+            QMRI_TRY(ew_launch_coil_sum(ctx, n, plane, cnt, scr, o.d_coils + (size_t)j0 * plane, st.x, j0 > 0));
+        }
+    }
+    QMRI_HIP(ctx, hipMemcpyAsync(o.d_vv, st.x, n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));          // v = x
+    QMRI_HIP(ctx, hipMemsetAsync(o.d_u, 0, n * sizeof(double2), ctx->stream));                                          // uold = 0
+    QMRI_TRY(dc_launch_prepare_z(ctx, qmri_opdev(ctx), o.ls, 1, o.d_vv, o.d_u, o.d_z));                                 // z = v - uold
+    bool again = false;
+    for (int it = 0; it < prm->iters; ++it) {
+        int32_t li = 0;
+        QMRI_TRY(qmri_lsqr_mc_dev(ctx, st.y, o.d_z, prm->gamma, prm->cg_tol, prm->cg_maxit, st.x, &li, nullptr));      // PnP_ADMM.m:102
+        if (lsqr_iters_out) lsqr_iters_out[it] = li;
+        QMRI_TRY(ew_launch_minmax_normalise(ctx, 1, n, (int)plane, o.N, o.s, multi, prm->noise_std, st.x, o.d_u, o.d_mm, o.d_norm, o.ls.nblk_z, net.in32, false));
+        QMRI_TRY(net_forward(ctx, 1));
+        QMRI_TRY(ew_launch_unnormalise_dual(ctx, 1, n, (int)plane, o.N, net.out32, net.in32, net.desc.residual_noise, o.d_norm, st.x, o.d_u, nullptr, o.d_z,
+                                            o.ls.pz, o.ls.nblk_z));
+        QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        QMRI_TRY(net_range_tripped(ctx, again));                   // (f16 range / hand-off guards: the network is re-packed or the form switched; repeat from the start)
+        if (again) break;
+    }
+    if (again) { ctx->admm_repeats += 1; return qmri_pnp_admm_mc(ctx, y_mc, prm, x0, x_out, lsqr_iters_out); }
+    QMRI_HIP(ctx, hipMemcpyAsync(x_out, st.x, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));                // returns x, not v
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    o.xhat_valid = false;
+    return QMRI_OK;
+}
+
 extern "C" int qmri_pnp_admm(qmri_ctx* ctx, const void* y, const qmri_admm_params* p, const void* x0, const void* gt,
                              void* x_out, double* diag_out, int32_t* lsqr_iters_out) {
     if (!ctx) return QMRI_ERR_INVALID_ARG;

@@ -210,6 +210,31 @@ class Engine:
         self._check(self.L.qmri_adjoint_mc(self.h, _vp(yb), _vp(x)))
         return x.reshape((self.N, self.M, self.s), order="F")
 
+    def xupdate_mc(self, y_mc, z, r, tol=1e-4, maxit=100, x0=None):
+        """Multi-coil extension (no reference counterpart): x = lsqr(afun_mc, [y_mc; sqrt(r) z], tol, maxit, [], [], x0).  y_mc [m, ncoil].  Returns (x, iters, flag)."""
+        yb, zb = _cbuf(y_mc), _cbuf(z)
+        nc = getattr(self, "ncoil", 0)
+        if nc and yb.size != self.m * nc:
+            raise ValueError(f"y_mc must be {self.m} x {nc}")
+        x0b = _cbuf(x0) if x0 is not None else None
+        x = np.empty(self.N * self.M * self.s, np.complex128)
+        it, fl = C.c_int32(0), C.c_int32(0)
+        self._check(self.L.qmri_xupdate_mc(self.h, _vp(yb), _vp(zb), float(r), float(tol), int(maxit), _vp(x0b), _vp(x), C.byref(it), C.byref(fl)))
+        return x.reshape((self.N, self.M, self.s), order="F"), it.value, fl.value
+
+    def pnp_admm_mc(self, y_mc, gamma=0.05, iters=100, cg_tol=1e-4, cg_maxit=100, multi_level=False, noise_std=0.01, x0=None):
+        """Multi-coil extension: PnP_ADMM(y, param) with F replaced by the SENSE operator of set_coils.  Returns (x, lsqr_iters)."""
+        p = AdmmParams(float(gamma), int(iters), float(cg_tol), int(cg_maxit), SOLVER_LSQR, int(bool(multi_level)), float(noise_std), 0)
+        yb = _cbuf(y_mc)
+        nc = getattr(self, "ncoil", 0)
+        if nc and yb.size != self.m * nc:
+            raise ValueError(f"y_mc must be {self.m} x {nc}")
+        x0b = _cbuf(x0) if x0 is not None else None
+        x = np.empty(self.N * self.M * self.s, np.complex128)
+        li = np.zeros(max(iters, 1), np.int32)
+        self._check(self.L.qmri_pnp_admm_mc(self.h, _vp(yb), C.byref(p), _vp(x0b), _vp(x), li.ctypes.data_as(C.POINTER(C.c_int32))))
+        return x.reshape((self.N, self.M, self.s), order="F"), li[:iters]
+
     def xupdate(self, y, z, r, tol=1e-4, maxit=100, x0=None, solver="lsqr"):
         """The x-update of PnP_ADMM.m:102 alone.  Returns (x, iters, flag)."""
         yb, zb = _cbuf(y), _cbuf(z)

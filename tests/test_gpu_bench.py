@@ -22,7 +22,7 @@ def _run(args, timeout=900):
 def test_bench_two_ranks_without_a_launcher():
     """`bench.py --gpus 2` alone: two worker processes (here both on device 0 over gloo: one-GPU box), one line, n_gpus 2."""
     out = _run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "4", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-secondary",
-                "--slices-total", "5", "--slices-iters", "2", "--batch", "2"])
+                "--slices-total", "5", "--slices-iters", "2", "--slices-batch", "2"])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
     assert out["scaling"] == "weak" and out["config"]["parallelism"].startswith("slice-parallel x2")
     sl = out["slices"]                                               # the fixed total sharded over the two ranks: 3 + 2
@@ -36,14 +36,14 @@ def test_bench_many_ranks_rehearsed_on_one_device():
     on one device at once -- both co-residency kernels (k_ks_persist, k_conv6r) must run or fall back cleanly when they do not get the chip to
     themselves -- and the max-over-ranks line.  (N = 8 itself: tests/test_dist_gloo.py, --plumbing-only, on the CPU.)"""
     out = _run(["--gpus", "5", "--backend", "gloo", "--one-device", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-secondary",
-                "--slices-total", "10", "--slices-iters", "2", "--batch", "2"], timeout=1200)
+                "--slices-total", "10", "--slices-iters", "2", "--slices-batch", "2"], timeout=1200)
     assert out["n_gpus"] == 5 and out["steps"] == 3 and out["value"] > 0 and out["config"]["parallelism"].startswith("slice-parallel x5")
     sl = out["slices"]
     assert sl["n_gpus"] == 5 and sl["total_slices"] == 10 and sl["slices_on_rank0"] == 2 and sl["value"] > 0 and sl["scaling"] == "strong"
 
 
 def test_bench_line_has_roofline_cpu_baseline_and_parity():
-    out = _run(["--steps", "6", "--warmup", "2", "--cpu-iters", "6", "--slices-total", "6", "--slices-iters", "3", "--batch", "3", "--secondary-steps", "4"])
+    out = _run(["--steps", "6", "--warmup", "2", "--cpu-iters", "6", "--slices-total", "6", "--slices-iters", "3", "--slices-batch", "3", "--secondary-steps", "4"])
     assert out["n_gpus"] == 1 and out["unit"] == "ADMM iters/s" and out["dtype"] == "f32"
     # north_star's second metric rides in the same line (default: 120 slices x 100 iterations; here 6 x 3): slices/s, the batched conv
     # kernel's roofline and the dictionary match against the f16 pipe it runs on (a fraction <= 1)

@@ -136,6 +136,62 @@ def test_multi_coil_operator_extension(engine_mod, oracle):
         e.close()
 
 
+def _coil_maps(N, nc):
+    hh, ww = np.meshgrid(np.linspace(-1, 1, N), np.linspace(-1, 1, N), indexing="ij")
+    m = np.stack([np.exp(-((hh - np.cos(a)) ** 2 + (ww - np.sin(a)) ** 2)) * np.exp(1j * (a + hh * ww)) for a in np.linspace(0, 2 * np.pi, nc, endpoint=False)], axis=2)
+    return m / np.sqrt(np.sum(np.abs(m) ** 2, axis=2, keepdims=True))          # sum_j |C_j|^2 = 1: the usual normalisation, ||A_mc|| <= 1
+
+
+def test_multi_coil_x_update_and_reconstruction_extension(engine_mod, oracle, synth):
+    """Round 6, BASELINE.json configs[4]: the reconstruction on top of the multi-coil operator -- the x-update of PnP_ADMM.m:102
+    with [A_mc; sqrt(r) I] as an image-domain LSQR, and the loop of PnP_ADMM.m:76-146 around it.  The reference is single-coil (README.md:63): NO
+    reference counterpart, parity unpinned; the checker is the oracle's numpy restatement (Operator.lsqr_mc / pnp_admm_mc: orc_lsqr.c's recurrences
+    statement by statement on forward_mc / adjoint_mc).  Checked: x, iteration count and flag of the x-update against it (tol 1e-4 and a tight solve,
+    warm start, maxit reached), the tight solve against the normal equations' residual, ONE all-ones coil == the single-coil x-update (count equal,
+    x to 1e-10: same Krylov iteration in another domain), the full loop against the oracle's, more coils than max_batch, and the error paths."""
+    rng = np.random.default_rng(33)
+    N, T, s, S, nc = 32, 24, 6, 120, 5
+    dic = synth.make_dictionary(T=T, n_t1=24, n_t2=16, s=s)
+    fp, k = oracle.spiral_mask(N, S, T)
+    op = oracle.Operator(N, N, dic["V"], fp, k)
+    maps = _coil_maps(N, nc)
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=0), dic)
+    y_mc = op.forward_mc(X0, maps)
+    y_mc = y_mc + 0.01 * np.abs(y_mc).mean() * (rng.standard_normal(y_mc.shape) + 1j * rng.standard_normal(y_mc.shape))
+    z = X0 + 0.05 * (rng.standard_normal(X0.shape) + 1j * rng.standard_normal(X0.shape))
+    e = engine_mod.Engine(0)
+    e.set_operator(N, N, dic["V"], fp, k, max_batch=2)              # 5 coils through chunks of 2
+    with pytest.raises(engine_mod.QmriError):
+        e.xupdate_mc(y_mc, z, 0.05)                                 # no maps yet
+    e.set_coils(maps)
+    r = 0.05
+    for tol, maxit, x0 in ((1e-4, 100, None), (1e-12, 200, None), (1e-4, 100, op.adjoint_mc(y_mc, maps)), (1e-12, 3, None)):
+        xg, ig, fg = e.xupdate_mc(y_mc, z, r, tol=tol, maxit=maxit, x0=x0)
+        xo, io, fo = op.lsqr_mc(y_mc, maps, z, r, tol=tol, maxit=maxit, x0=x0)
+        assert (ig, fg) == (io, fo) and rel_err(xg, xo) < 1e-10, (tol, maxit, ig, io, fg, fo)
+        if tol < 1e-10 and maxit > 100:                             # the minimiser: (A^H A + r I) x = A^H y + r z
+            lhs = op.adjoint_mc(op.forward_mc(xg, maps), maps) + r * xg
+            assert fg == 0 and rel_err(lhs, op.adjoint_mc(y_mc, maps) + r * z) < 1e-9
+    # one all-ones coil: the multi-coil x-update IS the single-coil one (image-domain iteration here, k-space iteration there)
+    e.set_coils(np.ones((N, N, 1)))
+    y1 = y_mc[:, :1].copy()
+    xm, im, fm = e.xupdate_mc(y1, z, r)
+    x1, i1, f1 = e.xupdate(y1[:, 0], z, r)
+    assert (im, fm) == (i1, f1) and rel_err(xm, x1) < 1e-10
+    # the loop
+    nch = (8, 16, 16, 32)
+    w = synth.structured_weights(in_nc=s, out_nc=s, nc=nch, nb=2, seed=3, eps=0.05)
+    e.set_coils(maps)
+    with pytest.raises(engine_mod.QmriError):
+        e.pnp_admm_mc(y_mc, iters=2)                                # no denoiser yet
+    e.set_denoiser(w, N, N, in_nc=s, out_nc=s, nc=nch, nb=2)
+    xg, lg = e.pnp_admm_mc(y_mc, iters=4)
+    xo, lo = oracle.pnp_admm_mc(op, oracle.Net(w, in_nc=s, out_nc=s, nc=nch, nb=2), y_mc, maps, iters=4)
+    assert np.array_equal(lg, lo) and rel_err(xg, xo) < 1e-4
+    assert rel_err(xg, X0) < rel_err(op.adjoint_mc(y_mc, maps), X0)  # (and it is a reconstruction: closer to the truth than the adjoint it started from)
+    e.close()
+
+
 @pytest.mark.parametrize("mask,T", [("epi", 200), ("spiral", 1000), ("epi", 100)])
 def test_lsqr_one_launch_with_the_other_unit_shapes_epi_and_cut0(engine_mod, oracle, mask, T):
     """Round 5: a single slice under an EPI mask (every k location sampled ~2.7 times: 784 units of 64 slots) or at cut0 (T = 1000: 56 samples per k,

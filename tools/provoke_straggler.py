@@ -36,7 +36,7 @@ while time.time() - t0 < float(sys.argv[1]):
     del h
 """
 BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-cold-start", "--no-roofline",
-         "--slices-total", "30", "--slices-iters", "100"]
+         "--slices-total", "30", "--slices-iters", "100", "--slices-batch", "15"]
 
 
 def run(label, hog_src, seconds=75):
