@@ -397,6 +397,21 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nlhs > 2) plhs[2] = mt; else mxDestroyArray(mt);
         if (nlhs > 3) plhs[3] = dm; else mxDestroyArray(dm);
         if (nlhs > 4) plhs[4] = xfit;
+    } else if (c == "health") {                      // h = qmri_mex('health'): qmri_get_health of the gateway's context as a struct
+        qmri_health h;
+        check(qmri_get_health(ctx(), &h));
+        const char* names[] = {"denoiser_scheme", "denoiser_fallbacks", "resident_armed", "resident_timeouts", "lsqr_one_launch", "lsqr_timeouts",
+                               "repeated_calls", "last_call_wall_ms", "last_call_stage_ms", "set_denoiser_ms"};
+        plhs[0] = mxCreateStructMatrix(1, 1, 10, names);
+        const double v[8] = {(double)h.denoiser_scheme, (double)h.denoiser_fallbacks, (double)h.resident_armed, (double)h.resident_timeouts,
+                             (double)h.lsqr_one_launch, (double)h.lsqr_timeouts, (double)h.repeated_calls, h.last_call_wall_ms};
+        for (int i = 0; i < 8; ++i) mxSetFieldByNumber(plhs[0], 0, i, mxCreateDoubleScalar(v[i]));
+        mxArray* st = mxCreateDoubleMatrix(1, 4, mxREAL);           // x-update, denoiser, elementwise, diagnostics
+        for (int i = 0; i < 4; ++i) mxGetDoubles(st)[i] = h.last_call_stage_ms[i];
+        mxSetFieldByNumber(plhs[0], 0, 8, st);
+        mxArray* sd = mxCreateDoubleMatrix(1, 3, mxREAL);           // pack + upload, tensors, calibration probe
+        for (int i = 0; i < 3; ++i) mxGetDoubles(sd)[i] = h.set_denoiser_ms[i];
+        mxSetFieldByNumber(plhs[0], 0, 9, sd);
     } else if (c == "release") {
         cleanup();
         if (mexIsLocked()) mexUnlock();

@@ -60,6 +60,9 @@ def test_single_slice_commands_equal_the_python_host_side(mex, engine_mod, oracl
         mex.qmri_mex("device", 900.0)
     assert err.value.id == "qmri:create"
     assert np.array_equal(mex.qmri_mex("denoise", img, float(s), nargout=1), e.denoise(img))
+    hh = mex.qmri_mex("health", nargout=1)                          # round 6: the context's health record as a MATLAB struct
+    assert hh["denoiser_scheme"] == 2 and hh["denoiser_fallbacks"] == 0 and hh["lsqr_timeouts"] == 0 and hh["repeated_calls"] == 0
+    assert np.asarray(hh["set_denoiser_ms"]).size == 3 and np.asarray(hh["last_call_stage_ms"]).size == 4
     prm = {"gamma": 0.05, "iter": 5, "cg_tol": 1e-4, "multi_level": 0, "noise_std": 0.01}
     x, diag, li = mex.qmri_mex("pnp_admm", y.astype(np.complex128), prm, np.zeros((0, 0)), np.asarray(X0, np.complex128), np.array([N, N, s], np.float64), nargout=3)
     xe, de, le = e.pnp_admm(y, iters=5, gt=X0, want_diag=True)
