@@ -156,6 +156,7 @@ extern "C" int qmri_destroy(qmri_ctx* ctx) {
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_state) (void)hipEventDestroy(ctx->ev_state);
     for (hipEvent_t e : ctx->chain) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->marks) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return QMRI_OK;

@@ -326,20 +326,19 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
         ms_pack += std::chrono::duration<double, std::milli>(Clk::now() - t0).count();
         return rc;
     };
-#define add_layer add_layer_timed
     if (desc->arch == QMRI_ARCH_UNETRES) {
         const int32_t* nc = desc->nc;
-        QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, nc[0], w));
+        QMRI_TRY(add_layer_timed(ctx, CONV_3X3, desc->in_nc, nc[0], w));
         for (int l = 0; l < 3; ++l) {
-            for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[l], nc[l], w));
-            QMRI_TRY(add_layer(ctx, CONV_DOWN, nc[l], nc[l + 1], w));
+            for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer_timed(ctx, CONV_3X3, nc[l], nc[l], w));
+            QMRI_TRY(add_layer_timed(ctx, CONV_DOWN, nc[l], nc[l + 1], w));
         }
-        for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[3], nc[3], w));
+        for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer_timed(ctx, CONV_3X3, nc[3], nc[3], w));
         for (int l = 3; l > 0; --l) {
-            QMRI_TRY(add_layer(ctx, CONV_UP, nc[l], nc[l - 1], w));
-            for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer(ctx, CONV_3X3, nc[l - 1], nc[l - 1], w));
+            QMRI_TRY(add_layer_timed(ctx, CONV_UP, nc[l], nc[l - 1], w));
+            for (int b = 0; b < 2 * nb; ++b) QMRI_TRY(add_layer_timed(ctx, CONV_3X3, nc[l - 1], nc[l - 1], w));
         }
-        QMRI_TRY(add_layer(ctx, CONV_3X3, nc[0], desc->out_nc, w));
+        QMRI_TRY(add_layer_timed(ctx, CONV_3X3, nc[0], desc->out_nc, w));
         for (int l = 0; l < 4; ++l) {
             // channels allocated = the largest padded Cin of any layer that reads a level-l tensor
             int cal = conv_cin_pad(CONV_3X3, nc[l]);
@@ -358,11 +357,11 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
         }
     } else {
         const int width = desc->nc[0];
-        if (nb == 1) QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, desc->out_nc, w));
+        if (nb == 1) QMRI_TRY(add_layer_timed(ctx, CONV_3X3, desc->in_nc, desc->out_nc, w));
         else {
-            QMRI_TRY(add_layer(ctx, CONV_3X3, desc->in_nc, width, w));
-            for (int l = 1; l < nb - 1; ++l) QMRI_TRY(add_layer(ctx, CONV_3X3, width, width, w));
-            QMRI_TRY(add_layer(ctx, CONV_3X3, width, desc->out_nc, w));
+            QMRI_TRY(add_layer_timed(ctx, CONV_3X3, desc->in_nc, width, w));
+            for (int l = 1; l < nb - 1; ++l) QMRI_TRY(add_layer_timed(ctx, CONV_3X3, width, width, w));
+            QMRI_TRY(add_layer_timed(ctx, CONV_3X3, width, desc->out_nc, w));
         }
         QMRI_TRY(alloc_tensor(ctx, p.a[0], width, conv_cin_pad(CONV_3X3, width), H, W, B));
         QMRI_TRY(alloc_tensor(ctx, p.t[0], width, conv_cin_pad(CONV_3X3, width), H, W, B));
@@ -386,7 +385,6 @@ extern "C" int qmri_set_denoiser(qmri_ctx* ctx, const qmri_net_desc* desc, const
     QMRI_TRY(dev_alloc(ctx, &p.d_counter, (size_t)1));
     QMRI_HIP(ctx, hipMemset(p.d_counter, 0, sizeof(unsigned)));
     if (qmri_knob(K_CONV_STAMPS)) { QMRI_HIP(ctx, hipMalloc(&p.d_stamps, 4096 * 11 * sizeof(unsigned long long))); }
-#undef add_layer
     p.counter_base = 0;
     p.ready = true;
     // (device-wide: the host packers' blocking copies travel on the NULL stream, which this context's non-blocking stream is not ordered with -- beside
