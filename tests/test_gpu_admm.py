@@ -289,6 +289,38 @@ def test_cut0_T1000_admm_and_match_at_bench_K(engine_mod, oracle, synth):
     e.close()
 
 
+def test_config4_cut0_multi_coil_reconstruction_and_match_as_one_pipeline(engine_mod, oracle, synth):
+    """BASELINE.json configs[4] as far as it can be defined without a reference counterpart (the reference is single-coil, README.md:63 -- the multi-coil
+    parts are a labelled extension, parity unpinned): cut0 (T = 1000, m = 617 780 samples PER COIL), a complex-valued multi-coil forward operator with
+    8 coils, PnP-ADMM on top of it (the image-domain x-update of mc_kernels.hip) with the full-size network, and the dictionary match at K = 98 304 --
+    one pipeline at 224 x 224, against the oracle's numpy restatement of the same loop; maps bit-exact for the same X."""
+    T, N, nc = 1000, 224, 8
+    dic = synth.make_dictionary(T=T, n_t1=384, n_t2=256)
+    X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=0), dic)
+    fp, k = oracle.spiral_mask(N, 771, T)
+    op = oracle.Operator(N, N, dic["V"], fp, k)
+    hh, ww = np.meshgrid(np.linspace(-1, 1, N), np.linspace(-1, 1, N), indexing="ij")
+    maps = np.stack([np.exp(-((hh - np.cos(a)) ** 2 + (ww - np.sin(a)) ** 2)) * np.exp(1j * (a + hh * ww)) for a in np.linspace(0, 2 * np.pi, nc, endpoint=False)], axis=2)
+    maps = maps / np.sqrt(np.sum(np.abs(maps) ** 2, axis=2, keepdims=True))
+    y_mc = np.stack([synth.awgn_measured(col, 30.0, seed=j) for j, col in enumerate(op.forward_mc(X0, maps).T)], axis=1)
+    w = synth.structured_weights(seed=2, eps=0.3)
+    e = engine_mod.Engine(0)
+    e.set_operator(N, N, dic["V"], fp, k, max_batch=4)              # 8 coils through chunks of 4
+    e.set_coils(maps)
+    e.set_denoiser(w, N, N)
+    e.set_dictionary(dic["D"], dic["normD"], dic["lut"])
+    xg, lg = e.pnp_admm_mc(y_mc, iters=2)
+    xo, lo = oracle.pnp_admm_mc(op, oracle.Net(w), y_mc, maps, iters=2)
+    err = rel_err(xg, xo)
+    print(f"cut0 x 8 coils: m {int(fp[-1])} per coil, lsqr gpu {lg.tolist()} oracle {lo.tolist()}, rel_err {err:.2e}")
+    assert np.array_equal(lg, lo) and err < 1e-4
+    mg = e.dict_match(xg)
+    mx = oracle.dict_match(xg, dic["D"], dic["normD"], dic["lut"])
+    assert np.array_equal(mg["dm"], mx["dm"]) and np.array_equal(mg["qmap"], mx["qmap"]) and np.array_equal(mg["pd"], mx["pd"])
+    assert_atoms_close(mg, oracle.dict_match(xo, dic["D"], dic["normD"], dic["lut"]), dic, "cut0 x 8 coils")
+    e.close()
+
+
 def test_recon_batch_two_workers(engine_mod, oracle, synth, capfd):
     """qmri_recon_batch with two workers (host threads, one context each) -- both on device 0 here, one per GPU on a node: the
     slice shards are disjoint, every slice comes back in its own slot, results equal the single-worker run bit for bit."""
