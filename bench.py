@@ -403,6 +403,38 @@ def _secondary_config(args, torch, dev, eng, name, T, mask, B, multi, steps, dic
     return out
 
 
+def multicoil_config(torch, local_rank, steps, ncoil=8):
+    """BASELINE configs[4]'s multi-coil part, a labelled EXTENSION (the reference is single-coil, README.md:63: no counterpart, parity unpinned): cut0
+    (T = 1000), `ncoil` coils, PnP-ADMM over the SENSE operator (image-domain LSQR, mc_kernels.hip) with the 10-channel network, one slice, through the
+    host-array entry point (copies included: the entry point has no device-resident form).  Not a tuned path: the LSQR scalars travel through the host."""
+    from qmri_pnp_recon_poc_amd import engine as E, synth
+    N, T, s = 224, 1000, 10
+    dic = cached_dictionary(synth, T, 32, 16, s)
+    fp, k = E.build_spiral(N, 771, T)
+    hh, ww = np.meshgrid(np.linspace(-1, 1, N), np.linspace(-1, 1, N), indexing="ij")
+    maps = np.stack([np.exp(-((hh - np.cos(a)) ** 2 + (ww - np.sin(a)) ** 2)) * np.exp(1j * (a + hh * ww)) for a in np.linspace(0, 2 * np.pi, ncoil, endpoint=False)], axis=2)
+    maps = maps / np.sqrt(np.sum(np.abs(maps) ** 2, axis=2, keepdims=True))
+    eng = E.Engine(local_rank)
+    try:
+        eng.set_operator(N, N, dic["V"], fp, k, max_batch=4)
+        eng.set_coils(maps)
+        eng.set_denoiser(synth.structured_weights(seed=2, eps=0.02), N, N)
+        X0 = synth.synthesize_tsmi(synth.make_phantom_qmaps(N, seed=0), dic)
+        y_mc = np.stack([synth.awgn_measured(col, 30.0, seed=j) for j, col in enumerate(eng.forward_mc(X0).T)], axis=1)
+        eng.pnp_admm_mc(y_mc, iters=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, li = eng.pnp_admm_mc(y_mc, iters=steps)
+        dt = time.perf_counter() - t0
+        return {"workload": f"EXTENSION (no reference counterpart, parity unpinned): cut0 (T = 1000, m = {eng.m} per coil) x {ncoil} coils, PnP-ADMM over the multi-coil "
+                            "operator (image-domain LSQR) + 10-channel UNetRes, one slice, host arrays in and out",
+                "value": round(steps / dt, 3), "unit": "ADMM iters/s", "steps": steps, "ms_per_admm_iteration": round(dt / steps * 1e3, 2),
+                "lsqr_iters_mean": round(float(np.mean(li)), 2), "ms_per_lsqr_iteration": round(dt / max(float(np.sum(li)), 1.0) * 1e3, 3),
+                "rel_err_to_ground_truth": round(float(np.linalg.norm((x - X0).ravel()) / np.linalg.norm(X0.ravel())), 4), "health": eng.health()}
+    finally:
+        eng.close()
+
+
 def slices_phase(args, rank, local_rank, world, dev, torch, dist, total, batch, iters, warmup_iters, dict_grid=(384, 256)):
     """north_star metric 2: a FIXED batch of `total` slices (120 = 8 subjects x 15, BASELINE configs[3]) sharded over the ranks in contiguous
     blocks; each rank walks its block in launches of `batch` slices (k_conv6p, batched LSQR), every slice = `iters` PnP-ADMM iterations + the
@@ -1013,6 +1045,11 @@ def worker(args):
             except Exception as exc:                                # noqa: BLE001
                 secondary[key] = {"workload": cfg_args[0], "value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
                 print(f"bench.py: secondary configuration {key} failed: {exc}", file=sys.stderr)
+        try:
+            secondary["cut0_multicoil8"] = multicoil_config(torch, local_rank, max(2, min(args.secondary_steps, 5)))
+        except Exception as exc:                                    # noqa: BLE001
+            secondary["cut0_multicoil8"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:400]}
+            print(f"bench.py: multi-coil configuration failed: {exc}", file=sys.stderr)
     if rank == 0:
         strong = args.workload == "slices" and args.total_slices > 0
         if args.workload == "admm":

@@ -97,6 +97,8 @@ def test_bench_line_has_roofline_cpu_baseline_and_parity():
         r = xo["roofline"]
         assert r["effective_gbs"] == r["achieved"] and r["binding_limit"].startswith("latency") and (r["traffic"] is None or r["traffic"] > 0)
     assert cb["slices_K"] == 98304 and cb["dict_match_s_at_slices_K"] > 0
+    mcx = out["cut0_multicoil8"]                                     # configs[4]'s multi-coil part: a labelled extension with its own figure
+    assert mcx["value"] > 0 and mcx["workload"].startswith("EXTENSION") and mcx["lsqr_iters_mean"] > 0 and mcx["health"]["repeated_calls"] == 0
     wd = out["with_diagnostics"]                                                                      # PnP_ADMM.m:106-109 on the GPU side too
     # (6 steps each: which of the two short timed regions is faster is noise; a sanity bound)
     assert 0 < wd["value"] <= out["value"] * 1.5 and 0 < wd["last_data_fidelity_rel"] < 1 and 0 < wd["last_gt_rel_err"] < 1
