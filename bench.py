@@ -922,7 +922,7 @@ def worker(args):
             p2 = eng.profile_get(reset=True)
             eng.profile_enable(0)
             ns_k = int(np.unique(k).size)
-            result_extra["xupdate"] = xupdate_roofline(p2, ns_k, s, int(fp[-1]), 1, p2["n_lsqr_launches"] <= p2["admm_iters"])
+            result_extra["xupdate"] = xupdate_roofline(p2, ns_k, s, int(fp[-1]), 1, p2["n_lsqr_launches"] <= p2["admm_iters"], f"spiral_T{T}_B1")
             result_extra["xupdate"]["us_per_lsqr_iteration_incl_fixed_launches"] = round(pr["ms_xupdate"] / it / max(pr["lsqr_iters"] / it, 1e-9) * 1e3, 2)
 
     # ---- CPU baseline + parity: the oracle on this box's host cores, bounded sample -----------------------
