@@ -273,7 +273,9 @@ def conv_roofline(pr, B, kernel_text, traffic=None, traffic_source=None):
         tf = pr["ms_net_forward"] / pr["n_net_forward"] * 1e-3
         ex = SPLIT_PRODUCTS * DENOISER_FLOP * B
         roof["whole_denoiser"] = {"what": "the whole forward pass between two stream events (all 64 layers, the |output| report, every launch gap): 3 x 213.25 GFLOP "
-                                          "per slice / its duration", "ms_per_forward": round(tf * 1e3, 4), "executed_flop": ex,
+                                          "per slice / its duration -- UNDER THE PER-LAUNCH PROFILE, whose event bookkeeping makes the pass 20 - 25 % longer than inside "
+                                          "the ADMM loop: `frac` above comes from the units' own dispatch timestamps, `whole_denoiser_in_admm_loop` from the loop's own stage",
+                                  "ms_per_forward": round(tf * 1e3, 4), "executed_flop": ex,
                                   "achieved": round(ex / tf / 1e12, 3), "frac": round(ex / tf / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
     return roof
 
