@@ -166,12 +166,15 @@ static int net_range_tripped(qmri_ctx* ctx, bool& tripped) {
     tripped = false;
     if (p.sp6 != 2 || !p.d_range_flag) return QMRI_OK;
     unsigned f = 0;
-    QMRI_HIP(ctx, hipMemcpy(&f, p.d_range_flag, sizeof f, hipMemcpyDeviceToHost));
+    // (on the context's own stream: the callers have synchronised it, and the kernels of the repeated run that raise this flag again are ordered
+    //  behind the reset -- a NULL-stream memset is not ordered with a non-blocking stream, see qmri_set_denoiser)
+    QMRI_HIP(ctx, hipMemcpyAsync(&f, p.d_range_flag, sizeof f, hipMemcpyDeviceToHost, ctx->stream));
+    QMRI_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #ifdef QMRI_TIMING_ONLY
     f = 0;
 #endif
     if (!f) return QMRI_OK;
-    QMRI_HIP(ctx, hipMemset(p.d_range_flag, 0, sizeof f));
+    QMRI_HIP(ctx, hipMemsetAsync(p.d_range_flag, 0, sizeof f, ctx->stream));
     if (p.h_range_flag) std::memset(p.h_range_flag, 0, (size_t)p.h_range_words * sizeof(unsigned));
     tripped = true;
     if (f & 4u) {                                                   // a hand-off of the resident-tile launch timed out: its results are garbage, and so
